@@ -1,0 +1,136 @@
+/* include/m4ri_amd.h -- C ABI of libm4ri_amd.so, the MI355X-native drop-in for M4RI's dense GF(2)
+ * multiply path (mzd_mul -> Strassen-Winograd -> M4RM).  Plain pointers and sizes only.
+ *
+ * Part 1 is the drop-in boundary: the exact symbols (names, signatures, semantics, fatal-error
+ * behaviour) a libm4ri user of this path binds, each citing the reference declaration it replaces.
+ * Part 2 is the device-resident API those entry points are built from; hosts that keep matrices
+ * in HBM across calls (bench.py, the multi-GPU driver, chains of products) call it directly.
+ *
+ * All file:line citations are relative to the reference tree (malb/m4ri @ 20251207).
+ */
+#ifndef M4RI_AMD_H
+#define M4RI_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types: m4ri/misc.h:72,81,87 -------------------------------------------------------------- */
+typedef int rci_t;      /* row/column index */
+typedef int64_t wi_t;   /* word index       */
+typedef uint64_t word;  /* 64 columns, LSB = lowest column */
+
+/* mzd_t: layout-identical to m4ri/mzd.h:68-99 (sizeof == 64; nrows@0 ncols@4 width@8 rowstride@16
+ * flags@24 high_bitmask@48 data@56).  Bit (r,c) = (data[r*rowstride + c/64] >> (c%64)) & 1.
+ * A program that already includes <m4ri/m4ri.h> must NOT include this header's struct: define
+ * M4RI_AMD_NO_MZD_T first and use M4RI's own declaration -- the two are the same bytes. */
+#ifndef M4RI_AMD_NO_MZD_T
+typedef struct mzd_t {
+  rci_t nrows;
+  rci_t ncols;
+  wi_t width;
+  wi_t rowstride;
+  uint8_t flags;        /* 0x2 non-zero excess, 0x4 windowed (mzd.h:144,150) */
+  uint8_t padding[23];
+  word high_bitmask;
+  word *data;
+} mzd_t;
+#endif
+
+/* =================================================================================================
+ * Part 1 -- drop-in entry points (host mzd_t in, host mzd_t out, blocking)
+ *
+ * Common contract: C == NULL => C is allocated with the host program's mzd_init
+ * (resolved with dlsym; see m4ri_amd_mzd_init below when no libm4ri is loaded) and returned;
+ * otherwise C must be A->nrows x B->ncols.  A, B, C may be windows; words at index >= width and
+ * bits outside high_bitmask of a windowed C are never written; for a non-window C they end up 0.
+ * `cutoff` and `k` are performance hints: every value yields the same bits.  A == B is legal.
+ * Dimension mismatch or cutoff < 0 prints to stderr and abort()s, like m4ri_die (misc.c:36-42);
+ * so does any HIP failure -- there is no CPU fallback.
+ * ============================================================================================== */
+
+/* C = A*B.  Replaces mzd_mul, m4ri/strassen.h:52 (strassen.c:345-365). */
+mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+/* C += A*B.  Replaces mzd_addmul, m4ri/strassen.h:68 (strassen.c:675-700). */
+mzd_t *mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+/* Unchecked variants L4 calls directly.  m4ri/strassen.h:88, :109, :126. */
+mzd_t *_mzd_mul_even(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+mzd_t *_mzd_addmul_even(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+mzd_t *_mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+/* Squaring entry points mzd_mul/_mzd_addmul dispatch to when A == B; exported by libm4ri although
+ * not declared in strassen.h (strassen.c:210, :528). */
+mzd_t *_mzd_sqr_even(mzd_t *C, mzd_t const *A, int cutoff);
+mzd_t *_mzd_addsqr_even(mzd_t *C, mzd_t const *A, int cutoff);
+/* M4RM leaf only (no Strassen).  m4ri/brilliantrussian.h:274, :291, :317. */
+mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
+mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
+mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear);
+/* OpenMP block-parallel entry points, m4ri/mp.h:47, :62: same results; here they run the same
+ * single-GPU schedule (the GPU grid replaces the omp sections). */
+mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+
+/* Allocation used for C == NULL when the process has no libm4ri (standalone use, our tests):
+ * same layout rules as mzd_init/mzd_free (mzd.c:142-157,179-185). */
+mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c);
+void m4ri_amd_mzd_free(mzd_t *A);
+
+/* =================================================================================================
+ * Part 2 -- device-resident API.  Matrices live in HBM in the same bit-packed row-major layout:
+ * `data` is a device pointer to word (0,0), `stride` the distance between rows in words.
+ * Invariant the caller keeps: bits at column >= ncols inside the last word of a row are zero
+ * (m4ri_amd_fill_dev and every product below preserve it; m4ri_amd_mask_tail_dev establishes it).
+ * All calls are asynchronous on `stream` (a hipStream_t; NULL = the null stream) unless noted and
+ * return 0 on success or a hipError_t value.
+ * ============================================================================================== */
+
+/* Bind the calling thread's HIP device for later calls and create the engine (idempotent). */
+int m4ri_amd_init(int device);
+int m4ri_amd_device_count(void);
+
+/* C (+)= A*B on the device: Strassen-Winograd levels over batched M4RM leaves.
+ * C: m x n, A: m x l, B: l x n.  add != 0 accumulates.  cutoff: 0 = engine default, otherwise the
+ * reference's meaning (recurse until 3*dim < 4*cutoff for some dim, strassen.c:39,51). */
+int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                     int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int cutoff,
+                     void *stream);
+/* One M4RM leaf launch, no Strassen (the device twin of _mzd_mul_m4rm).  ksplit: 0 = automatic. */
+int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                      int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit,
+                      void *stream);
+/* C = A ^ B on rows x ncols bits (the device twin of _mzd_add, mzd.c:1471; in-place allowed). */
+int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                     int64_t b_stride, int64_t rows, int64_t ncols, void *stream);
+/* Deterministic fill: word (r, j) = splitmix64 stream `seed`, output number r*width + j, last word
+ * masked -- the order mzd_randomize_custom fills a matrix in (mzd.c:1282-1292). */
+int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed, void *stream);
+int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, void *stream);
+
+/* Schedule statistics of the most recent m4ri_amd_mul_dev / m4ri_amd_m4rm_dev on this thread's
+ * engine.  With profiling on, every leaf launch is bracketed by HIP events on its own stream and
+ * leaf_ms is their sum (reading it synchronises the stream). */
+typedef struct m4ri_amd_stats {
+  int32_t levels;           /* Strassen-Winograd levels used                       */
+  int32_t leaf_launches;    /* kernel launches of the M4RM leaf                     */
+  int64_t leaf_products;    /* products those launches computed (batch members)     */
+  int32_t leaf_m, leaf_l, leaf_n; /* shape of the batched leaves                     */
+  int32_t reserved;
+  double leaf_ms;           /* sum of leaf launch durations (profiling on), else 0  */
+  double leaf_bytes;        /* algorithmic bytes of the leaf launches:
+                               8*(m*W(l) + l*W(n) + m*W(n)) per product             */
+  double aux_bytes;         /* declared bytes of the fused down/up passes           */
+  double workspace_bytes;   /* HBM held by the engine's workspace                   */
+} m4ri_amd_stats;
+void m4ri_amd_set_profiling(int on);
+int m4ri_amd_get_stats(m4ri_amd_stats *out);
+
+/* Release the engine's workspace (device memory pool). */
+void m4ri_amd_release_workspace(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M4RI_AMD_H */

@@ -1,0 +1,187 @@
+"""m4ri_amd -- MI355X-native drop-in for M4RI's dense GF(2) multiply path.
+
+The product is `libm4ri_amd.so` (HIP kernels for gfx950 + the host scheduler + a C ABI that exports
+M4RI's own entry points, see include/m4ri_amd.h).  This package is the thin Python binding over that
+C ABI: the functions below have M4RI's names and argument meaning (reference m4ri/strassen.h:52-126,
+m4ri/brilliantrussian.h:274-317) and simply forward `Mzd` host matrices to the library.
+
+There is no CPU implementation here: if the shared library is missing or there is no GPU, calls
+fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .mzd import Mzd, MzdPtr, MzdStruct, from_struct_ptr, splitmix_words  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm4ri_amd.so")
+_lib = None
+
+
+class Stats(ctypes.Structure):
+    """m4ri_amd_stats (include/m4ri_amd.h)."""
+
+    _fields_ = [
+        ("levels", ctypes.c_int32),
+        ("leaf_launches", ctypes.c_int32),
+        ("leaf_products", ctypes.c_int64),
+        ("leaf_m", ctypes.c_int32),
+        ("leaf_l", ctypes.c_int32),
+        ("leaf_n", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("leaf_ms", ctypes.c_double),
+        ("leaf_bytes", ctypes.c_double),
+        ("aux_bytes", ctypes.c_double),
+        ("workspace_bytes", ctypes.c_double),
+    ]
+
+
+# every symbol include/m4ri_amd.h declares, with its ctypes signature
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I = ctypes.c_int
+_MULSIG = (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I])
+_DEVSIG = (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P])
+SYMBOLS = {
+    "mzd_mul": _MULSIG,
+    "mzd_addmul": _MULSIG,
+    "_mzd_mul_even": _MULSIG,
+    "_mzd_addmul_even": _MULSIG,
+    "_mzd_addmul": _MULSIG,
+    "_mzd_sqr_even": (MzdPtr, [MzdPtr, MzdPtr, _I]),
+    "_mzd_addsqr_even": (MzdPtr, [MzdPtr, MzdPtr, _I]),
+    "mzd_mul_m4rm": _MULSIG,
+    "mzd_addmul_m4rm": _MULSIG,
+    "_mzd_mul_m4rm": (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I, _I]),
+    "mzd_mul_mp": _MULSIG,
+    "mzd_addmul_mp": _MULSIG,
+    "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
+    "m4ri_amd_mzd_free": (None, [MzdPtr]),
+    "m4ri_amd_init": (_I, [_I]),
+    "m4ri_amd_device_count": (_I, []),
+    "m4ri_amd_mul_dev": _DEVSIG,
+    "m4ri_amd_m4rm_dev": _DEVSIG,
+    "m4ri_amd_xor_dev": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P]),
+    "m4ri_amd_fill_dev": (_I, [_P, _I64, _I64, _I64, ctypes.c_uint64, _P]),
+    "m4ri_amd_mask_tail_dev": (_I, [_P, _I64, _I64, _I64, _P]),
+    "m4ri_amd_set_profiling": (None, [_I]),
+    "m4ri_amd_get_stats": (_I, [ctypes.POINTER(Stats)]),
+    "m4ri_amd_release_workspace": (None, []),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load libm4ri_amd.so (RTLD_LOCAL: its M4RI-named symbols must not interpose a libm4ri that
+    happens to be loaded in the same process, e.g. the reference build used as the test oracle)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m m4ri_amd.build` (hipcc, gfx950). "
+                "m4ri_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _p(m: Mzd | None):
+    return m.ptr if m is not None else None
+
+
+def _ret(C: Mzd | None, r) -> Mzd:
+    if C is not None:
+        return C
+    return from_struct_ptr(r, lib().m4ri_amd_mzd_free)
+
+
+# ---- M4RI-named host entry points ---------------------------------------------------------------
+def mzd_mul(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    """C = A*B (strassen.h:52).  C=None allocates.  Fatal (abort) on dimension mismatch, like M4RI."""
+    return _ret(C, lib().mzd_mul(_p(C), A.ptr, B.ptr, cutoff))
+
+
+def mzd_addmul(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    """C += A*B (strassen.h:68)."""
+    return _ret(C, lib().mzd_addmul(_p(C), A.ptr, B.ptr, cutoff))
+
+
+def _mzd_mul_even(C: Mzd, A: Mzd, B: Mzd, cutoff: int) -> Mzd:
+    lib()._mzd_mul_even(C.ptr, A.ptr, B.ptr, cutoff)
+    return C
+
+
+def _mzd_addmul_even(C: Mzd, A: Mzd, B: Mzd, cutoff: int) -> Mzd:
+    lib()._mzd_addmul_even(C.ptr, A.ptr, B.ptr, cutoff)
+    return C
+
+
+def _mzd_addmul(C: Mzd, A: Mzd, B: Mzd, cutoff: int) -> Mzd:
+    lib()._mzd_addmul(C.ptr, A.ptr, B.ptr, cutoff)
+    return C
+
+
+def mzd_mul_m4rm(C: Mzd | None, A: Mzd, B: Mzd, k: int = 0) -> Mzd:
+    """C = A*B by one M4RM leaf, no Strassen (brilliantrussian.h:274).  k is a hint only."""
+    return _ret(C, lib().mzd_mul_m4rm(_p(C), A.ptr, B.ptr, k))
+
+
+def mzd_addmul_m4rm(C: Mzd, A: Mzd, B: Mzd, k: int = 0) -> Mzd:
+    lib().mzd_addmul_m4rm(C.ptr, A.ptr, B.ptr, k)
+    return C
+
+
+def _mzd_mul_m4rm(C: Mzd, A: Mzd, B: Mzd, k: int, clear: int) -> Mzd:
+    lib()._mzd_mul_m4rm(C.ptr, A.ptr, B.ptr, k, clear)
+    return C
+
+
+def mzd_mul_mp(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    return _ret(C, lib().mzd_mul_mp(_p(C), A.ptr, B.ptr, cutoff))
+
+
+def mzd_addmul_mp(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    return _ret(C, lib().mzd_addmul_mp(_p(C), A.ptr, B.ptr, cutoff))
+
+
+# ---- device-resident API -------------------------------------------------------------------------
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"m4ri_amd: {what} failed with hipError_t {rc}")
+
+
+def init(device: int = 0) -> None:
+    _check(lib().m4ri_amd_init(device), "m4ri_amd_init")
+
+
+def mul_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int, m: int, l: int, n: int,
+            add: bool = False, cutoff: int = 0, stream: int = 0) -> None:
+    """C (+)= A*B on device pointers (ints), Strassen-Winograd over batched M4RM leaves."""
+    _check(lib().m4ri_amd_mul_dev(C, c_stride, A, a_stride, B, b_stride, m, l, n, int(add), cutoff, stream), "m4ri_amd_mul_dev")
+
+
+def m4rm_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int, m: int, l: int, n: int,
+             add: bool = False, ksplit: int = 0, stream: int = 0) -> None:
+    _check(lib().m4ri_amd_m4rm_dev(C, c_stride, A, a_stride, B, b_stride, m, l, n, int(add), ksplit, stream), "m4ri_amd_m4rm_dev")
+
+
+def xor_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int, rows: int, ncols: int, stream: int = 0) -> None:
+    _check(lib().m4ri_amd_xor_dev(C, c_stride, A, a_stride, B, b_stride, rows, ncols, stream), "m4ri_amd_xor_dev")
+
+
+def fill_dev(M: int, stride: int, rows: int, ncols: int, seed: int, stream: int = 0) -> None:
+    _check(lib().m4ri_amd_fill_dev(M, stride, rows, ncols, seed, stream), "m4ri_amd_fill_dev")
+
+
+def set_profiling(on: bool) -> None:
+    lib().m4ri_amd_set_profiling(int(on))
+
+
+def get_stats() -> Stats:
+    s = Stats()
+    _check(lib().m4ri_amd_get_stats(ctypes.byref(s)), "m4ri_amd_get_stats")
+    return s

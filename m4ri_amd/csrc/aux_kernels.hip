@@ -1,0 +1,223 @@
+// aux_kernels.hip -- the HBM-bound helpers around the M4RM leaf: the two fused Strassen-Winograd
+// passes, strided XOR / copy, tail masking and the deterministic fill.
+//
+// They replace the reference's 15 separate quadrant additions per recursion node
+// (_mzd_add, /root/reference m4ri/mzd.c:1471-1583, called from m4ri/strassen.c:111-150) by one
+// "down" pass per operand and one "up" pass per level: every operand word is read once and every
+// result word written once per level (33 quadrant transfers per node instead of 45).
+//
+// All of these are pure streaming kernels: one 64-bit word (or a 16-byte pair) per lane, rows
+// contiguous, grid-stride -- bounded by HBM bandwidth, nothing to tile.
+#include <hip/hip_runtime.h>
+#include "gf2_common.h"
+
+namespace {
+
+constexpr int AUX_THREADS = 256;
+
+// ---- Winograd operand combinations ----------------------------------------------------------
+// With the parent split into quadrants X11 X12 / X21 X22 the 7 children of the A side are
+//   [A11, A12, S4, A22, S1, S2, S3],  S1 = A21+A22, S2 = S1+A11, S3 = A11+A21, S4 = A12+S2
+// and of the B side
+//   [B11, B21, B22, T4, T1, T2, T3],  T1 = B12+B11, T2 = B22+T1, T3 = B22+B12, T4 = T2+B21
+// so that product j = Achild_j * Bchild_j is P1..P7 of the Strassen-Winograd scheme.
+template <typename V, bool BSIDE>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down_kernel(
+    const V *__restrict__ parent, int64_t p_stride, int64_t p_bs,  // parent array (units of V)
+    V *__restrict__ child, int64_t c_bs,                           // child array, stride == cw
+    int64_t nparents, int64_t crows, int64_t cw, int64_t qoff_rows, int64_t qoff_cols) {
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const V *p       = parent + pi * p_bs + r * p_stride + w;
+    const V x11 = p[0], x12 = p[qoff_cols], x21 = p[qoff_rows * p_stride],
+            x22 = p[qoff_rows * p_stride + qoff_cols];
+    V *c = child + (pi * 7) * c_bs + r * cw + w;
+    if (!BSIDE) {
+      const V s1 = x21 ^ x22, s2 = s1 ^ x11, s3 = x11 ^ x21, s4 = x12 ^ s2;
+      c[0 * c_bs] = x11; c[1 * c_bs] = x12; c[2 * c_bs] = s4; c[3 * c_bs] = x22;
+      c[4 * c_bs] = s1;  c[5 * c_bs] = s2;  c[6 * c_bs] = s3;
+    } else {
+      const V t1 = x12 ^ x11, t2 = x22 ^ t1, t3 = x22 ^ x12, t4 = t2 ^ x21;
+      c[0 * c_bs] = x11; c[1 * c_bs] = x21; c[2 * c_bs] = x22; c[3 * c_bs] = t4;
+      c[4 * c_bs] = t1;  c[5 * c_bs] = t2;  c[6 * c_bs] = t3;
+    }
+  }
+}
+
+// ---- Winograd recombination ------------------------------------------------------------------
+//   U2 = P1+P6, U3 = U2+P7, U4 = U2+P5
+//   C11 = P1+P2, C12 = U4+P3, C21 = U3+P4, C22 = U3+P5        (ACC: parent ^= instead of =)
+template <typename V, bool ACC>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_up_kernel(
+    const V *__restrict__ prod, int64_t p_bs,                      // products, stride == cw
+    V *__restrict__ parent, int64_t o_stride, int64_t o_bs,        // parent array
+    int64_t nparents, int64_t crows, int64_t cw, int64_t qoff_rows, int64_t qoff_cols) {
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const V *q       = prod + (pi * 7) * p_bs + r * cw + w;
+    const V p1 = q[0], p2 = q[p_bs], p3 = q[2 * p_bs], p4 = q[3 * p_bs], p5 = q[4 * p_bs],
+            p6 = q[5 * p_bs], p7 = q[6 * p_bs];
+    const V u2 = p1 ^ p6, u3 = u2 ^ p7, u4 = u2 ^ p5;
+    V c11 = p1 ^ p2, c12 = u4 ^ p3, c21 = u3 ^ p4, c22 = u3 ^ p5;
+    V *o = parent + pi * o_bs + r * o_stride + w;
+    if (ACC) {
+      c11 ^= o[0]; c12 ^= o[qoff_cols]; c21 ^= o[qoff_rows * o_stride];
+      c22 ^= o[qoff_rows * o_stride + qoff_cols];
+    }
+    o[0]                                  = c11;
+    o[qoff_cols]                          = c12;
+    o[qoff_rows * o_stride]               = c21;
+    o[qoff_rows * o_stride + qoff_cols]   = c22;
+  }
+}
+
+// C = A ^ B (whole words) on strided views; op 1: C = A (copy); op 2: C = 0
+__global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *__restrict__ C, int64_t cs,
+                                                              const word *__restrict__ A, int64_t as,
+                                                              const word *__restrict__ B, int64_t bs,
+                                                              int64_t rows, int64_t w, int op) {
+  const int64_t total  = rows * w;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / w, k = i - r * w;
+    word v = 0;
+    if (op == 0) v = A[r * as + k] ^ B[r * bs + k];
+    else if (op == 1) v = A[r * as + k];
+    C[r * cs + k] = v;
+  }
+}
+
+// zero the bits at column >= ncols of the last valid word of every row (establishes the engine's
+// "zero excess" invariant for operands uploaded from windows, mzd.h:117-123)
+__global__ __launch_bounds__(AUX_THREADS) void mask_tail_kernel(word *__restrict__ M, int64_t stride,
+                                                                int64_t rows, int64_t w, word mask) {
+  const int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x;
+  if (i < rows) M[i * stride + (w - 1)] &= mask;
+}
+
+// row r, word j of the matrix := splitmix64 output number r*w + j of the stream seeded `seed`,
+// last word masked: the fill order of mzd_randomize_custom (mzd.c:1282-1292) with a counter-based
+// generator, so device and host fills (m4ri_amd/mzd.py fill_splitmix) are bit-identical.
+__global__ __launch_bounds__(AUX_THREADS) void fill_splitmix_kernel(word *__restrict__ M, int64_t stride,
+                                                                    int64_t rows, int64_t w, word mask,
+                                                                    uint64_t seed) {
+  const int64_t total  = rows * w;
+  const int64_t gstr   = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += gstr) {
+    const int64_t r = i / w, j = i - r * w;
+    uint64_t z = seed + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+    z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    if (j == w - 1) z &= mask;
+    M[r * stride + j] = z;
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t g = (total + AUX_THREADS - 1) / AUX_THREADS;
+  if (g > 256 * 16) g = 256 * 16;  // 16 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+inline bool vec_ok(const void *p, int64_t stride, int64_t bs, int64_t cw, int64_t qcols) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (stride % 2 == 0) && (bs % 2 == 0) &&
+         (cw % 2 == 0) && (qcols % 2 == 0);
+}
+
+}  // namespace
+
+typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
+
+extern "C" hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent,
+                                               int64_t p_stride, int64_t p_bs, word *child,
+                                               int64_t nparents, int64_t crows, int64_t cw) {
+  // child matrices: crows x cw words, contiguous (stride cw), batch stride crows*cw
+  const int64_t c_bs = crows * cw;
+  if (nparents * c_bs == 0) return hipSuccess;
+  if (vec_ok(parent, p_stride, p_bs, cw, cw) && vec_ok(child, cw, c_bs, cw, cw)) {
+    const int64_t total = nparents * crows * (cw / 2);
+    if (bside)
+      hipLaunchKernelGGL((winograd_down_kernel<word2, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(parent), p_stride / 2, p_bs / 2,
+                         reinterpret_cast<word2 *>(child), c_bs / 2, nparents, crows, cw / 2, crows, cw / 2);
+    else
+      hipLaunchKernelGGL((winograd_down_kernel<word2, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(parent), p_stride / 2, p_bs / 2,
+                         reinterpret_cast<word2 *>(child), c_bs / 2, nparents, crows, cw / 2, crows, cw / 2);
+  } else {
+    const int64_t total = nparents * crows * cw;
+    if (bside)
+      hipLaunchKernelGGL((winograd_down_kernel<word, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         parent, p_stride, p_bs, child, c_bs, nparents, crows, cw, crows, cw);
+    else
+      hipLaunchKernelGGL((winograd_down_kernel<word, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         parent, p_stride, p_bs, child, c_bs, nparents, crows, cw, crows, cw);
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word *prod, word *parent,
+                                             int64_t o_stride, int64_t o_bs, int64_t nparents,
+                                             int64_t crows, int64_t cw) {
+  const int64_t p_bs = crows * cw;
+  if (nparents * p_bs == 0) return hipSuccess;
+  if (vec_ok(prod, cw, p_bs, cw, cw) && vec_ok(parent, o_stride, o_bs, cw, cw)) {
+    const int64_t total = nparents * crows * (cw / 2);
+    if (acc)
+      hipLaunchKernelGGL((winograd_up_kernel<word2, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(prod), p_bs / 2, reinterpret_cast<word2 *>(parent),
+                         o_stride / 2, o_bs / 2, nparents, crows, cw / 2, crows, cw / 2);
+    else
+      hipLaunchKernelGGL((winograd_up_kernel<word2, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(prod), p_bs / 2, reinterpret_cast<word2 *>(parent),
+                         o_stride / 2, o_bs / 2, nparents, crows, cw / 2, crows, cw / 2);
+  } else {
+    const int64_t total = nparents * crows * cw;
+    if (acc)
+      hipLaunchKernelGGL((winograd_up_kernel<word, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         prod, p_bs, parent, o_stride, o_bs, nparents, crows, cw, crows, cw);
+    else
+      hipLaunchKernelGGL((winograd_up_kernel<word, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         prod, p_bs, parent, o_stride, o_bs, nparents, crows, cw, crows, cw);
+  }
+  return hipGetLastError();
+}
+
+// op 0: C = A ^ B, 1: C = A, 2: C = 0  (whole words of `w` words per row)
+extern "C" hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A,
+                                         int64_t as, const word *B, int64_t bs, int64_t rows, int64_t w) {
+  if (rows * w == 0) return hipSuccess;
+  hipLaunchKernelGGL(rowwise_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, B, bs, rows, w, op);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols) {
+  if (rows == 0 || ncols == 0 || (ncols % 64) == 0) return hipSuccess;
+  const word mask = (~(word)0) >> (64 - ncols % 64);
+  hipLaunchKernelGGL(mask_tail_kernel, dim3((unsigned)((rows + AUX_THREADS - 1) / AUX_THREADS)), dim3(AUX_THREADS), 0, s,
+                     M, stride, rows, words_of(ncols), mask);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int64_t rows,
+                                               int64_t ncols, uint64_t seed) {
+  if (rows == 0 || ncols == 0) return hipSuccess;
+  const int64_t w = words_of(ncols);
+  const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
+  hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, M, stride, rows, w, mask, seed);
+  return hipGetLastError();
+}

@@ -1,0 +1,351 @@
+// engine.hip -- host-side scheduler of the MI355X GF(2) multiply engine + the device-resident C ABI
+// (include/m4ri_amd.h, part 2).
+//
+// Replaces the reference's recursive, memory-frugal Strassen-Winograd driver
+//   _mzd_mul_even / _mzd_addmul_even      /root/reference m4ri/strassen.c:41-208, :367-526
+// by a BREADTH-FIRST schedule sized for 288 GB of HBM: for L levels
+//   L "down" passes per operand  (each parent -> its 7 Winograd operand combinations, fused),
+//   ONE batched M4RM leaf launch (all 7^L products at once: >> 256 workgroups, one launch),
+//   L "up" passes                (7 products -> the 4 quadrants of the parent, fused; the last one
+//                                 writes, or XORs into, the caller's C).
+// The depth-first reference needs 2-3 quadrant temporaries per level and runs 7^L small leaves one
+// after another; on a GPU that starves the chip (a 4096^3 leaf is 8 workgroups).  Breadth-first
+// keeps (7/4)^d copies of the operands per level -- 15.6 GiB at n = 65536, L = 3 -- which is
+// nothing here, and turns the whole product into 3L+1 large launches on one stream.
+// Remainders that do not fit the even 2^L split are peeled with direct leaf launches exactly like
+// strassen.c:170-204.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "gf2_common.h"
+#include "../../include/m4ri_amd.h"
+
+extern "C" {
+hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
+hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
+                                    int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word *prod, word *parent, int64_t o_stride,
+                                  int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A, int64_t as,
+                              const word *B, int64_t bs, int64_t rows, int64_t w);
+hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols);
+hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed);
+}
+
+namespace {
+
+constexpr int MAX_LEVELS      = 6;
+constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(m,l,n)/2 >= this (leaf >= 8192)
+constexpr int NUM_DEVICES_MAX = 16;
+
+#define HIPTRY(expr)                                                  \
+  do {                                                                \
+    hipError_t e_ = (expr);                                           \
+    if (e_ != hipSuccess) return (int)e_;                             \
+  } while (0)
+
+struct Engine {
+  int device            = -1;
+  word *ws              = nullptr;  // grow-only workspace
+  size_t ws_cap         = 0;
+  size_t ws_used        = 0;
+  bool profiling        = false;
+  m4ri_amd_stats stats  = {};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
+  std::vector<hipEvent_t> event_pool;
+  hipStream_t pending_stream = nullptr;
+};
+
+std::mutex g_mu;
+Engine g_engines[NUM_DEVICES_MAX];
+
+Engine *engine_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NUM_DEVICES_MAX) return nullptr;
+  Engine *e = &g_engines[dev];
+  e->device = dev;
+  return e;
+}
+
+int ws_reserve(Engine *e, size_t words) {
+  e->ws_used = 0;
+  if (words <= e->ws_cap) return 0;
+  HIPTRY(hipDeviceSynchronize());
+  if (e->ws) HIPTRY(hipFree(e->ws));
+  e->ws = nullptr; e->ws_cap = 0;
+  HIPTRY(hipMalloc(reinterpret_cast<void **>(&e->ws), words * sizeof(word)));
+  e->ws_cap = words;
+  return 0;
+}
+
+word *ws_take(Engine *e, size_t words) {
+  words = (words + 31) & ~(size_t)31;  // 256-byte granules: keeps every sub-buffer 16-byte aligned
+  word *p = e->ws + e->ws_used;
+  e->ws_used += words;
+  return p;
+}
+
+hipEvent_t take_event(Engine *e) {
+  if (!e->event_pool.empty()) { hipEvent_t ev = e->event_pool.back(); e->event_pool.pop_back(); return ev; }
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+  return ev;
+}
+
+// ---- leaf launch ------------------------------------------------------------------------------
+int pick_rg(int64_t m) {
+  // tile heights 1024 / 768 / 512 rows: least padded rows wins, taller tile on ties
+  const int cand[3] = {32, 24, 16};
+  int best = 32; int64_t best_pad = INT64_MAX;
+  for (int rg : cand) {
+    const int64_t R = 32 * rg, pad = ((m + R - 1) / R) * R;
+    if (pad < best_pad) { best_pad = pad; best = rg; }
+  }
+  return best;
+}
+
+int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
+                const word *B, int64_t bs, int64_t bbs, int64_t m, int64_t l, int64_t n, int64_t batch,
+                bool add, int ksplit_req) {
+  if (m == 0 || n == 0 || batch == 0) return 0;
+  if (m > INT32_MAX || l > INT32_MAX || n > INT32_MAX) return (int)hipErrorInvalidValue;
+  // 32-bit byte offsets inside one operand (raw buffer addressing)
+  if ((uint64_t)m * (uint64_t)as * 8 >= (1ull << 32) || (uint64_t)l * (uint64_t)bs * 8 >= (1ull << 32))
+    return (int)hipErrorInvalidValue;
+  const int rg       = pick_rg(m);
+  const int64_t R    = 32 * rg;
+  const int64_t wn   = words_of(n);
+  const int64_t tiles = ((m + R - 1) / R) * ((wn + LEAF_TW - 1) / LEAF_TW) * batch;
+  const int64_t stages = (l + LEAF_STAGE - 1) / LEAF_STAGE;
+  int ksplit = ksplit_req;
+  if (ksplit <= 0) {
+    // fill the chip: aim for >= 512 workgroups (2 per CU), but keep >= 64 stages (1024 inner
+    // bits) per split so the C tile traffic stays amortised
+    ksplit = 1;
+    if (tiles < 512) {
+      int64_t want = (512 + tiles - 1) / tiles;
+      int64_t cap  = stages / 64;
+      if (cap < 1) cap = 1;
+      ksplit = (int)(want < cap ? want : cap);
+    }
+  }
+  if (l == 0 || (ksplit > 1 && !add)) {  // empty inner dimension, or atomics need a zeroed C
+    if (!add)
+      for (int64_t b = 0; b < batch; ++b)
+        HIPTRY(gf2_launch_rowwise(st, 2, C + b * cbs, cs, nullptr, 0, nullptr, 0, m, wn));
+    if (l == 0) return 0;
+  }
+  LeafArgs a{};
+  a.A = A; a.B = B; a.C = C;
+  a.a_stride = as; a.b_stride = bs; a.c_stride = cs;
+  a.a_bs = abs_; a.b_bs = bbs; a.c_bs = cbs;
+  a.m = (int32_t)m; a.l = (int32_t)l; a.n = (int32_t)n;
+  a.batch = (int32_t)batch; a.ksplit = ksplit;
+  a.mode  = (add || ksplit > 1) ? 1 : 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling) {
+    e0 = take_event(e); e1 = take_event(e);
+    if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
+  }
+  HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
+  if (e->profiling && e0 && e1) {
+    HIPTRY(hipEventRecord(e1, st));
+    e->pending.emplace_back(e0, e1);
+    e->pending_stream = st;
+  }
+  e->stats.leaf_launches += 1;
+  e->stats.leaf_products += batch;
+  e->stats.leaf_m = (int32_t)m; e->stats.leaf_l = (int32_t)l; e->stats.leaf_n = (int32_t)n;
+  e->stats.leaf_bytes += 8.0 * (double)batch * ((double)m * words_of(l) + (double)l * wn + (double)m * wn * (add ? 2 : 1));
+  return 0;
+}
+
+// ---- level planning ----------------------------------------------------------------------------
+bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strassen.c:39
+
+int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
+  int L = 0;
+  if (cutoff == 0) {
+    int64_t mn = m < l ? m : l; if (n < mn) mn = n;
+    while (L < MAX_LEVELS && mn / 2 >= DEFAULT_CUTOFF) { mn /= 2; ++L; }
+  } else {
+    // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
+    int64_t a = m, b = l, c = n;
+    while (L < MAX_LEVELS && !(closer(a, cutoff) || closer(b, cutoff) || closer(c, cutoff))) { a /= 2; b /= 2; c /= 2; ++L; }
+  }
+  // every level halves l and n on word boundaries and m on rows: need a non-empty even block
+  while (L > 0 && ((m >> L) == 0 || (l / (64ll << L)) == 0 || (n / (64ll << L)) == 0)) --L;
+  return L;
+}
+
+int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
+
+// breadth-first Strassen-Winograd on the even block: C (m x n) (+)= A (m x l) * B (l x n), with
+// m % 2^L == 0 and l, n % (64 * 2^L) == 0.
+int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) {
+  const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  // workspace plan
+  size_t need = 0;
+  auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
+  for (int d = 1; d <= L; ++d) {
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
+    need += pad((size_t)cnt * md * wl) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
+  }
+  if (int rc = ws_reserve(e, need)) return rc;
+  std::vector<word *> Al(L + 1), Bl(L + 1), Pl(L + 1);
+  for (int d = 1; d <= L; ++d) {
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
+    Al[d] = ws_take(e, (size_t)cnt * md * wl);
+    Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
+    Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
+  }
+  e->stats.workspace_bytes = (double)e->ws_cap * 8.0;
+  // down passes
+  for (int d = 0; d < L; ++d) {
+    const int64_t cnt = ipow7(d);
+    const int64_t cm = m >> (d + 1), cl = l >> (d + 1), cn = n >> (d + 1);
+    const word *pa = d == 0 ? A.p : Al[d];
+    const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
+    HIPTRY(gf2_launch_winograd_down(st, 0, pa, pas, pabs, Al[d + 1], cnt, cm, cl / 64));
+    const word *pb = d == 0 ? B.p : Bl[d];
+    const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
+    HIPTRY(gf2_launch_winograd_down(st, 1, pb, pbs, pbbs, Bl[d + 1], cnt, cl, cn / 64));
+    e->stats.aux_bytes += 8.0 * cnt * 11.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));
+  }
+  // all 7^L leaf products in one launch
+  {
+    const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = ipow7(L);
+    if (int rc = launch_leaf(e, st, Pl[L], ln / 64, lm * (ln / 64), Al[L], ll / 64, lm * (ll / 64), Bl[L], ln / 64,
+                             ll * (ln / 64), lm, ll, ln, cnt, false, 1))
+      return rc;
+  }
+  // up passes
+  for (int d = L - 1; d >= 0; --d) {
+    const int64_t cnt = ipow7(d);
+    const int64_t cm = m >> (d + 1), cn = n >> (d + 1);
+    word *out            = d == 0 ? C.p : Pl[d];
+    const int64_t ostr   = d == 0 ? C.stride : (n >> d) / 64;
+    const int64_t obs    = d == 0 ? 0 : (m >> d) * ostr;
+    HIPTRY(gf2_launch_winograd_up(st, (d == 0 && add) ? 1 : 0, Pl[d + 1], out, ostr, obs, cnt, cm, cn / 64));
+    e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * ((d == 0 && add) ? 15.0 : 11.0);
+  }
+  return 0;
+}
+
+int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
+  const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  if (m == 0 || n == 0) return 0;
+  int L = plan_levels(m, l, n, cutoff);
+  e->stats.levels = L;
+  if (L == 0) return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
+  const int64_t me = m - m % (1ll << L), le = l - l % (64ll << L), ne = n - n % (64ll << L);
+  if (int rc = bfs_product(e, st, dview(C, 0, 0, me, ne), dview(A, 0, 0, me, le), dview(B, 0, 0, le, ne), add, L)) return rc;
+  // remainder strips (strassen.c:170-204): right columns, bottom rows, trailing inner slab
+  if (n > ne)
+    if (int rc = launch_leaf(e, st, C.p + ne / 64, C.stride, 0, A.p, A.stride, 0, B.p + ne / 64, B.stride, 0, m, l, n - ne, 1, add, 0)) return rc;
+  if (m > me)
+    if (int rc = launch_leaf(e, st, C.p + me * C.stride, C.stride, 0, A.p + me * A.stride, A.stride, 0, B.p, B.stride, 0, m - me, l, ne, 1, add, 0)) return rc;
+  if (l > le)
+    if (int rc = launch_leaf(e, st, C.p, C.stride, 0, A.p + le / 64, A.stride, 0, B.p + le * B.stride, B.stride, 0, me, l - le, ne, 1, true, 0)) return rc;
+  return 0;
+}
+
+void reset_stats(Engine *e) {
+  const double ws = (double)e->ws_cap * 8.0;
+  // keep un-read profiling events out of the next call's sum
+  for (auto &pr : e->pending) { e->event_pool.push_back(pr.first); e->event_pool.push_back(pr.second); }
+  e->pending.clear();
+  e->stats = m4ri_amd_stats{};
+  e->stats.workspace_bytes = ws;
+}
+
+}  // namespace
+
+// ================================ C ABI (part 2 of include/m4ri_amd.h) ==========================
+extern "C" {
+
+int m4ri_amd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int m4ri_amd_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIPTRY(hipSetDevice(device));
+  Engine *e = engine_for_current_device();
+  return e ? 0 : (int)hipErrorInvalidDevice;
+}
+
+int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                     int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int cutoff, void *stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (!e || cutoff < 0 || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
+  reset_stats(e);
+  if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
+  DMat dC{C, m, n, c_stride}, dA{const_cast<word *>(A), m, l, a_stride}, dB{const_cast<word *>(B), l, n, b_stride};
+  return engine_mul(e, (hipStream_t)stream, dC, dA, dB, add != 0, cutoff);
+}
+
+int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                      int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit, void *stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
+  reset_stats(e);
+  return launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit);
+}
+
+int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
+                     int64_t b_stride, int64_t rows, int64_t ncols, void *stream) {
+  return (int)gf2_launch_rowwise((hipStream_t)stream, 0, C, c_stride, A, a_stride, B, b_stride, rows, words_of(ncols));
+}
+
+int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed, void *stream) {
+  return (int)gf2_launch_fill_splitmix((hipStream_t)stream, M, stride, rows, ncols, seed);
+}
+
+int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, void *stream) {
+  return (int)gf2_launch_mask_tail((hipStream_t)stream, M, stride, rows, ncols);
+}
+
+void m4ri_amd_set_profiling(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (e) e->profiling = on != 0;
+}
+
+int m4ri_amd_get_stats(m4ri_amd_stats *out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (!e || !out) return (int)hipErrorInvalidValue;
+  if (!e->pending.empty()) {
+    HIPTRY(hipEventSynchronize(e->pending.back().second));
+    double sum = 0;
+    for (auto &pr : e->pending) {
+      float ms = 0;
+      HIPTRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+      sum += ms;
+      e->event_pool.push_back(pr.first); e->event_pool.push_back(pr.second);
+    }
+    e->pending.clear();
+    e->stats.leaf_ms += sum;
+  }
+  *out = e->stats;
+  return 0;
+}
+
+void m4ri_amd_release_workspace(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (!e || !e->ws) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(e->ws);
+  e->ws = nullptr; e->ws_cap = 0; e->ws_used = 0;
+}
+
+}  // extern "C"

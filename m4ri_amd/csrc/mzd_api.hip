@@ -1,0 +1,209 @@
+// mzd_api.hip -- the drop-in boundary (include/m4ri_amd.h, part 1): M4RI's own entry points for the
+// multiply path, taking and returning host mzd_t matrices, implemented on the device engine.
+//
+// Reference interfaces replaced (same names, argument meaning and fatal-error behaviour):
+//   mzd_mul, mzd_addmul, _mzd_mul_even, _mzd_addmul_even, _mzd_addmul   m4ri/strassen.h:52-126
+//   _mzd_sqr_even, _mzd_addsqr_even                                      m4ri/strassen.c:210,528
+//   mzd_mul_m4rm, mzd_addmul_m4rm, _mzd_mul_m4rm                         m4ri/brilliantrussian.h:274-317
+//   mzd_mul_mp, mzd_addmul_mp                                            m4ri/mp.h:47,62
+//
+// Each call: upload A and B (hipMemcpy2D straight out of the caller's rows, so windows cost
+// nothing extra), zero the excess bits on the device, run the engine, and copy C back touching only
+// the words and bits the reference would touch (mzd.h:117-123).  There is NO CPU fallback: a HIP
+// failure is fatal, like every other error on this path (misc.c:36-42).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "gf2_common.h"
+#include "../../include/m4ri_amd.h"
+
+namespace {
+
+constexpr uint8_t FLAG_EXCESS = 0x2;  // mzd.h:144
+constexpr uint8_t FLAG_WINDOW = 0x4;  // mzd.h:150
+
+std::mutex g_api_mu;
+
+[[noreturn]] void die(const char *fmt, ...) {  // misc.c:36-42
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  abort();
+}
+
+#define HIPDIE(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t e_ = (hipError_t)(expr);                                                         \
+    if (e_ != hipSuccess) die("m4ri_amd: HIP failure '%s' in %s (%s:%d)\n", hipGetErrorString(e_), #expr, __FILE__, __LINE__); \
+  } while (0)
+
+mzd_t *result_init(rci_t r, rci_t c) {
+  // the caller will mzd_free() the result, so it has to come from the host program's libm4ri
+  // allocator when there is one
+  typedef mzd_t *(*init_fn)(rci_t, rci_t);
+  static init_fn host_init = reinterpret_cast<init_fn>(dlsym(RTLD_DEFAULT, "mzd_init"));
+  return host_init ? host_init(r, c) : m4ri_amd_mzd_init(r, c);
+}
+
+struct DevMat {
+  word *p       = nullptr;
+  int64_t stride = 0;
+  ~DevMat() { if (p) (void)hipFree(p); }
+};
+
+void dev_alloc(DevMat &d, int64_t rows, int64_t ncols) {
+  int64_t w = words_of(ncols);
+  d.stride  = (w + 1) & ~(int64_t)1;  // even: rows stay 16-byte aligned
+  size_t bytes = (size_t)(rows > 0 ? rows : 1) * (size_t)(d.stride > 0 ? d.stride : 2) * 8;
+  HIPDIE(hipMalloc(reinterpret_cast<void **>(&d.p), bytes));
+}
+
+// host rows -> fresh device matrix with zero excess
+void upload(DevMat &d, const mzd_t *M) {
+  dev_alloc(d, M->nrows, M->ncols);
+  if (M->nrows == 0 || M->width == 0) return;
+  if (d.stride != M->width)  // padding word must not stay uninitialised (it is never read as data,
+    HIPDIE(hipMemsetAsync(d.p, 0, (size_t)M->nrows * d.stride * 8, 0));  // but keep it deterministic)
+  HIPDIE(hipMemcpy2D(d.p, (size_t)d.stride * 8, M->data, (size_t)M->rowstride * 8, (size_t)M->width * 8,
+                     (size_t)M->nrows, hipMemcpyHostToDevice));
+  HIPDIE(m4ri_amd_mask_tail_dev(d.p, d.stride, M->nrows, M->ncols, nullptr));
+}
+
+// device result -> host C, writing words [0, width) only and, in the last word, only the bits
+// inside high_bitmask when C is a window with excess
+void download(const DevMat &d, mzd_t *C) {
+  if (C->nrows == 0 || C->width == 0) return;
+  const bool dangerous = (C->flags & FLAG_WINDOW) && (C->ncols % 64 != 0);
+  if (!dangerous) {
+    HIPDIE(hipMemcpy2D(C->data, (size_t)C->rowstride * 8, d.p, (size_t)d.stride * 8, (size_t)C->width * 8,
+                       (size_t)C->nrows, hipMemcpyDeviceToHost));
+    return;
+  }
+  if (C->width > 1)
+    HIPDIE(hipMemcpy2D(C->data, (size_t)C->rowstride * 8, d.p, (size_t)d.stride * 8, (size_t)(C->width - 1) * 8,
+                       (size_t)C->nrows, hipMemcpyDeviceToHost));
+  std::vector<word> last((size_t)C->nrows);
+  HIPDIE(hipMemcpy2D(last.data(), 8, d.p + (C->width - 1), (size_t)d.stride * 8, 8, (size_t)C->nrows, hipMemcpyDeviceToHost));
+  const word mask = C->high_bitmask;
+  for (rci_t i = 0; i < C->nrows; ++i) {
+    word *w = C->data + (int64_t)i * C->rowstride + (C->width - 1);
+    *w      = (*w & ~mask) | (last[(size_t)i] & mask);
+  }
+}
+
+int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
+  if (cutoff < 0) die("%s: cutoff must be >= 0.\n", who);
+  return cutoff;  // 0 = engine default; >0 normalised inside m4ri_amd_mul_dev
+}
+
+// the whole product: strassen == true runs the Strassen-Winograd engine, false a single leaf
+mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  if (C->nrows == 0 || C->ncols == 0) return C;  // strassen.c:44
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  DevMat dA, dB, dC;
+  upload(dA, A);
+  const bool same = (A == B);
+  if (!same) upload(dB, B);
+  const word *pB      = same ? dA.p : dB.p;
+  const int64_t sB    = same ? dA.stride : dB.stride;
+  if (add) upload(dC, C);
+  else dev_alloc(dC, C->nrows, C->ncols);
+  if (strassen)
+    HIPDIE(m4ri_amd_mul_dev(dC.p, dC.stride, dA.p, dA.stride, pB, sB, A->nrows, A->ncols, B->ncols, add, cutoff, nullptr));
+  else
+    HIPDIE(m4ri_amd_m4rm_dev(dC.p, dC.stride, dA.p, dA.stride, pB, sB, A->nrows, A->ncols, B->ncols, add, 0, nullptr));
+  download(dC, C);
+  HIPDIE(hipDeviceSynchronize());
+  return C;
+}
+
+}  // namespace
+
+extern "C" {
+
+mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c) {  // mzd.c:142-157
+  mzd_t *A = static_cast<mzd_t *>(calloc(1, sizeof(mzd_t)));
+  if (!A) die("m4ri_amd_mzd_init: out of memory\n");
+  A->nrows        = r;
+  A->ncols        = c;
+  A->width        = c > 0 ? (c - 1) / 64 + 1 : 0;
+  A->rowstride    = (A->width & 1) ? A->width + 1 : A->width;
+  A->high_bitmask = (~(word)0) >> ((64 - c % 64) % 64);
+  A->flags        = (A->high_bitmask != ~(word)0) ? FLAG_EXCESS : 0;
+  if (r && c) {
+    void *p = nullptr;
+    const size_t bytes = (size_t)r * (size_t)A->rowstride * 8;
+    if (posix_memalign(&p, 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
+    memset(p, 0, bytes);
+    A->data = static_cast<word *>(p);
+  }
+  return A;
+}
+
+void m4ri_amd_mzd_free(mzd_t *A) {  // mzd.c:179-185
+  if (!A) return;
+  if (!(A->flags & FLAG_WINDOW)) free(A->data);
+  free(A);
+}
+
+mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {  // strassen.c:345-365
+  if (A->ncols != B->nrows) die("mzd_mul: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
+  cutoff = norm_cutoff(cutoff, "mzd_mul");
+  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols)
+    die("mzd_mul: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", C->nrows, C->ncols, A->nrows, B->ncols);
+  return run(C, A, B, false, true, cutoff);
+}
+
+mzd_t *mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {  // strassen.c:675-700
+  if (A->ncols != B->nrows) die("mzd_addmul: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
+  cutoff = norm_cutoff(cutoff, "mzd_addmul");
+  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols)
+    die("mzd_addmul: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", C->nrows, C->ncols, A->nrows, B->ncols);
+  if (A->nrows == 0 || A->ncols == 0 || B->ncols == 0) return C;
+  return run(C, A, B, true, true, cutoff);
+}
+
+mzd_t *_mzd_mul_even(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return run(C, A, B, false, true, cutoff); }
+mzd_t *_mzd_addmul_even(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return run(C, A, B, true, true, cutoff); }
+mzd_t *_mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return run(C, A, B, true, true, cutoff); }
+mzd_t *_mzd_sqr_even(mzd_t *C, mzd_t const *A, int cutoff) { return run(C, A, A, false, true, cutoff); }
+mzd_t *_mzd_addsqr_even(mzd_t *C, mzd_t const *A, int cutoff) { return run(C, A, A, true, true, cutoff); }
+
+mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // brilliantrussian.c:999-1012
+  (void)k;
+  if (A->ncols != B->nrows) die("mzd_mul_m4rm: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
+  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols)
+    die("mzd_mul_m4rm: C (%d x %d) has wrong dimensions.\n", C->nrows, C->ncols);
+  return run(C, A, B, false, false, 0);
+}
+
+mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // brilliantrussian.c:1014-1028
+  (void)k;
+  if (C == NULL) die("mzd_addmul_m4rm: C must not be NULL.\n");  // the reference dereferences C first (:1018)
+  if (C->ncols == 0 || C->nrows == 0) return C;
+  if (A->ncols != B->nrows) die("mzd_mul_m4rm A ncols (%d) need to match B nrows (%d) .\n", A->ncols, B->nrows);
+  if (C->nrows != A->nrows || C->ncols != B->ncols) die("mzd_mul_m4rm: C has wrong dimensions.\n");
+  return run(C, A, B, true, false, 0);
+}
+
+mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear) {  // brilliantrussian.c:1032
+  (void)k;
+  return run(C, A, B, clear == 0, false, 0);
+}
+
+mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mzd_mul(C, A, B, cutoff); }        // mp.c:277-297
+mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mzd_addmul(C, A, B, cutoff); }  // mp.c:299-324
+
+}  // extern "C"

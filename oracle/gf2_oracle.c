@@ -1,0 +1,401 @@
+/* oracle/gf2_oracle.c -- TEST INFRASTRUCTURE ONLY (see gf2_oracle.h).
+ *
+ * CPU restatement of the reference's mzd_mul path.  Every function names the reference lines whose
+ * OBSERVABLE behaviour it reproduces (result bits, window/excess rules, fatal errors); the code is
+ * our own and deliberately simple -- one lookup table at a time, direct table indexing instead of
+ * the codebook's ord/inc arrays, no SSE2, no caches.  Tuning knobs (k, cutoff) change the order of
+ * operations only, never a bit of the result, exactly as in the reference.
+ */
+#include "gf2_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define RADIX 64
+#define FFFF (~(gf2o_word)0)
+
+static void die(const char *msg) { /* misc.c:36-42 m4ri_die: print + abort */
+  fprintf(stderr, "gf2_oracle: %s\n", msg);
+  abort();
+}
+
+/* __M4RI_LEFT_BITMASK(n), misc.h:272: the n lowest bits; n == 0 means a full word */
+static gf2o_word left_mask(int n) { return FFFF >> ((RADIX - n) % RADIX); }
+
+static gf2o_word *row_of(const gf2o_mat *M, int64_t r) { return M->data + r * M->rowstride; }
+
+/* ---- allocation / views: mzd.c:142-185 --------------------------------------------------- */
+gf2o_mat *gf2o_init(int32_t r, int32_t c) {
+  gf2o_mat *A = (gf2o_mat *)calloc(1, sizeof(gf2o_mat));
+  if (!A) die("out of memory");
+  A->nrows        = r;
+  A->ncols        = c;
+  A->width        = c > 0 ? (c - 1) / RADIX + 1 : 0;
+  A->rowstride    = (A->width & 1) ? A->width + 1 : A->width; /* even stride, mzd.c:147-148 */
+  A->high_bitmask = left_mask(c % RADIX);
+  A->flags        = (A->high_bitmask != FFFF) ? GF2O_FLAG_EXCESS : 0;
+  if (r && c) {
+    size_t bytes = (size_t)r * (size_t)A->rowstride * sizeof(gf2o_word);
+    if (posix_memalign((void **)&A->data, 64, bytes)) die("out of memory");
+    memset(A->data, 0, bytes);
+  }
+  return A;
+}
+
+gf2o_mat *gf2o_init_window(gf2o_mat *M, int32_t lowr, int32_t lowc, int32_t highr, int32_t highc) {
+  if (lowc % RADIX) die("window must start on a word boundary"); /* assert at mzd.c:161 */
+  gf2o_mat *W = (gf2o_mat *)calloc(1, sizeof(gf2o_mat));
+  if (!W) die("out of memory");
+  int32_t nrows = highr - lowr;
+  if (M->nrows - lowr < nrows) nrows = M->nrows - lowr;
+  W->nrows        = nrows;
+  W->ncols        = highc - lowc;
+  W->rowstride    = M->rowstride;
+  W->width        = (W->ncols + RADIX - 1) / RADIX;
+  W->high_bitmask = left_mask(W->ncols % RADIX);
+  W->flags        = GF2O_FLAG_WINDOW | ((W->ncols % RADIX) ? GF2O_FLAG_EXCESS : 0);
+  W->data         = M->data + (int64_t)lowr * M->rowstride + lowc / RADIX;
+  return W;
+}
+
+void gf2o_free(gf2o_mat *A) {
+  if (!A) return;
+  if (!(A->flags & GF2O_FLAG_WINDOW)) free(A->data);
+  free(A);
+}
+
+/* ---- deterministic fill: mzd.c:1282-1292 fill order with splitmix64 -------------------------- */
+uint64_t gf2o_splitmix_next(uint64_t *state) {
+  uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+  z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+void gf2o_fill_splitmix(gf2o_mat *A, uint64_t seed) {
+  if (A->width == 0) return;
+  uint64_t st = seed;
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    gf2o_word *row = row_of(A, i);
+    for (int64_t j = 0; j + 1 < A->width; ++j) row[j] = gf2o_splitmix_next(&st);
+    gf2o_word r = gf2o_splitmix_next(&st);
+    row[A->width - 1] ^= (row[A->width - 1] ^ r) & A->high_bitmask;
+  }
+}
+
+/* ---- element-wise helpers --------------------------------------------------------------------- */
+/* _mzd_add, mzd.c:1471-1583: C = A ^ B over min rows; last word of C keeps its bits outside
+ * C->high_bitmask; in-place and mixed-stride operands allowed. */
+gf2o_mat *gf2o_add(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B) {
+  int64_t nrows = A->nrows < B->nrows ? A->nrows : B->nrows;
+  if (C->nrows < nrows) nrows = C->nrows;
+  const int64_t w = A->width;
+  if (w == 0) return C;
+  for (int64_t i = 0; i < nrows; ++i) {
+    const gf2o_word *a = row_of(A, i), *b = row_of(B, i);
+    gf2o_word *c = row_of(C, i);
+    for (int64_t j = 0; j + 1 < w; ++j) c[j] = a[j] ^ b[j];
+    c[w - 1] ^= (a[w - 1] ^ b[w - 1] ^ c[w - 1]) & C->high_bitmask;
+  }
+  return C;
+}
+
+/* mzd_copy, mzd.c:1363-1382: masked copy, allocates when N == NULL */
+gf2o_mat *gf2o_copy(gf2o_mat *N, const gf2o_mat *P) {
+  if (N == P) return N;
+  if (!N) N = gf2o_init(P->nrows, P->ncols);
+  else if (N->nrows < P->nrows || N->ncols < P->ncols) die("copy: target matrix is too small");
+  if (P->width == 0) return N;
+  for (int64_t i = 0; i < P->nrows; ++i) {
+    const gf2o_word *p = row_of(P, i);
+    gf2o_word *n = row_of(N, i);
+    for (int64_t j = 0; j + 1 < P->width; ++j) n[j] = p[j];
+    n[P->width - 1] = (n[P->width - 1] & ~P->high_bitmask) | (p[P->width - 1] & P->high_bitmask);
+  }
+  return N;
+}
+
+/* mzd_set_ui(A, 0), mzd.c:1294-1302: clears valid bits only */
+void gf2o_set_zero(gf2o_mat *A) {
+  if (A->width == 0) return;
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    gf2o_word *r = row_of(A, i);
+    for (int64_t j = 0; j + 1 < A->width; ++j) r[j] = 0;
+    r[A->width - 1] &= ~A->high_bitmask;
+  }
+}
+
+/* mzd_equal, mzd.c:1314-1331: valid bits only */
+int gf2o_equal(const gf2o_mat *A, const gf2o_mat *B) {
+  if (A->nrows != B->nrows || A->ncols != B->ncols) return 0;
+  if (A == B || A->width == 0) return 1;
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    const gf2o_word *a = row_of(A, i), *b = row_of(B, i);
+    for (int64_t j = 0; j + 1 < A->width; ++j)
+      if (a[j] != b[j]) return 0;
+    if ((a[A->width - 1] ^ b[A->width - 1]) & A->high_bitmask) return 0;
+  }
+  return 1;
+}
+
+uint64_t gf2o_fingerprint(const gf2o_mat *A) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (int64_t i = 0; i < A->nrows; ++i) {
+    const gf2o_word *a = row_of(A, i);
+    for (int64_t j = 0; j < A->width; ++j) {
+      gf2o_word v = a[j];
+      if (j == A->width - 1) v &= A->high_bitmask;
+      for (int b = 0; b < 8; ++b) {
+        h ^= (v >> (8 * b)) & 0xff;
+        h *= 0x100000001b3ull;
+      }
+    }
+  }
+  return h;
+}
+
+/* mzd_read_bits, mzd.h:892-901: n <= 64 bits starting at column y, column y lands on bit 0 */
+static gf2o_word read_bits(const gf2o_mat *M, int64_t x, int64_t y, int n) {
+  const int spot     = (int)(y % RADIX);
+  const int64_t blk  = y / RADIX;
+  const int spill    = spot + n - RADIX;
+  const gf2o_word *r = row_of(M, x);
+  gf2o_word t = (spill <= 0) ? r[blk] << -spill : (r[blk + 1] << (RADIX - spill)) | (r[blk] >> spill);
+  return t >> (RADIX - n);
+}
+
+/* row XOR of the valid words of B's row j into C's row i; B's last word is masked so C's bits at
+ * columns >= ncols are never disturbed (mzd_combine / mzd.h:993-1048 on whole rows). */
+static void xor_row(gf2o_mat *C, int64_t i, const gf2o_mat *B, int64_t j) {
+  gf2o_word *c = row_of(C, i);
+  const gf2o_word *b = row_of(B, j);
+  for (int64_t w = 0; w + 1 < B->width; ++w) c[w] ^= b[w];
+  c[B->width - 1] ^= b[B->width - 1] & B->high_bitmask;
+}
+
+/* ---- definitional product: _mzd_mul_va, mzd.c:1256-1268 --------------------------------------- */
+gf2o_mat *gf2o_mul_naive(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int clear) {
+  if (A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols) die("mul_naive: wrong dimensions");
+  if (clear) gf2o_set_zero(C);
+  if (B->width == 0) return C;
+  for (int64_t i = 0; i < A->nrows; ++i)
+    for (int64_t j = 0; j < A->ncols; ++j)
+      if ((row_of(A, i)[j / RADIX] >> (j % RADIX)) & 1) xor_row(C, i, B, j);
+  return C;
+}
+
+/* ---- Method of the Four Russians: _mzd_mul_m4rm, brilliantrussian.c:1032-1190 ---------------- */
+/* One table of 2^k combinations of k consecutive rows of B at a time (the reference keeps eight;
+ * same sums).  T[x] = XOR of rows r+b for the set bits b of x, built in Gray-code order so each
+ * entry is one row XOR (mzd_make_table, :163-211; the doc table in graycode.h is stale, the code's
+ * ord[] is the reflected Gray code i^(i>>1)).  Table rows carry zero excess bits (:165-168,:206),
+ * which is what preserves the excess bits of a windowed C.  Bit b of the index is column r+b of A
+ * (mzd_read_bits puts column r on bit 0). */
+gf2o_mat *gf2o_mul_m4rm(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int k, int clear) {
+  if (A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols) die("mul_m4rm: wrong dimensions");
+  if (clear) gf2o_set_zero(C);
+  if (C->nrows == 0 || C->ncols == 0 || A->ncols == 0) return C;
+  if (k <= 0) k = 8; /* :1075-1089 picks k from cache sizes; any k gives the same bits */
+  if (k > 8) k = 8;
+  const int64_t w = B->width, l = A->ncols;
+  gf2o_word *T = (gf2o_word *)malloc(((size_t)1 << k) * (size_t)w * sizeof(gf2o_word));
+  if (!T) die("out of memory");
+  for (int64_t r = 0; r < l; r += k) {
+    const int kk = (l - r < k) ? (int)(l - r) : k; /* tails :1157-1178 */
+    memset(T, 0, (size_t)w * sizeof(gf2o_word));
+    unsigned prev = 0;
+    for (unsigned i = 1; i < (1u << kk); ++i) {
+      const unsigned g = i ^ (i >> 1);
+      const int bit    = __builtin_ctz(i); /* gray(i) ^ gray(i-1) == 1 << ctz(i) */
+      const gf2o_word *b = row_of(B, r + bit);
+      gf2o_word *t = T + (size_t)g * w, *tp = T + (size_t)prev * w;
+      for (int64_t j = 0; j + 1 < w; ++j) t[j] = tp[j] ^ b[j];
+      t[w - 1] = tp[w - 1] ^ (b[w - 1] & B->high_bitmask);
+      prev = g;
+    }
+    for (int64_t j = 0; j < A->nrows; ++j) {
+      const gf2o_word x = read_bits(A, j, r, kk);
+      const gf2o_word *t = T + (size_t)x * w;
+      gf2o_word *c = row_of(C, j);
+      for (int64_t q = 0; q < w; ++q) c[q] ^= t[q];
+    }
+  }
+  free(T);
+  return C;
+}
+
+/* ---- Strassen-Winograd, Bodrato's sequence ------------------------------------------------------ */
+static int closer(int64_t a, int cutoff) { return 3 * a < 4 * (int64_t)cutoff; } /* strassen.c:39 */
+
+static gf2o_mat *win(const gf2o_mat *M, int64_t r0, int64_t c0, int64_t r1, int64_t c1) {
+  return gf2o_init_window((gf2o_mat *)M, (int32_t)r0, (int32_t)c0, (int32_t)r1, (int32_t)c1);
+}
+
+/* split sizes, strassen.c:69-80: halves are word-aligned and even down the whole recursion */
+static void split_sizes(int64_t m, int64_t k, int64_t n, int cutoff, int64_t *mmm, int64_t *kkk, int64_t *nnn) {
+  int64_t mult = RADIX, width = (m < n ? m : n);
+  if (k < width) width = k;
+  width /= 2;
+  while (width > cutoff) { width /= 2; mult *= 2; }
+  *mmm = (((m - m % mult) / RADIX) >> 1) * RADIX;
+  *kkk = (((k - k % mult) / RADIX) >> 1) * RADIX;
+  *nnn = (((n - n % mult) / RADIX) >> 1) * RADIX;
+}
+
+/* remainder strips after the even block, strassen.c:170-204 (mul) and :488-522 (addmul) */
+static void peel(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int64_t mmm, int64_t kkk, int64_t nnn, int clear) {
+  const int64_t m = A->nrows, k = A->ncols, n = B->ncols;
+  nnn *= 2; mmm *= 2; kkk *= 2;
+  if (n > nnn) { /* last columns: full A times the right strip of B */
+    gf2o_mat *Bl = win(B, 0, nnn, k, n), *Cl = win(C, 0, nnn, m, n);
+    gf2o_mul_m4rm(Cl, A, Bl, 0, clear);
+    gf2o_free(Bl); gf2o_free(Cl);
+  }
+  if (m > mmm) { /* last rows */
+    gf2o_mat *Al = win(A, mmm, 0, m, k), *Bf = win(B, 0, 0, k, nnn), *Cl = win(C, mmm, 0, m, nnn);
+    gf2o_mul_m4rm(Cl, Al, Bf, 0, clear);
+    gf2o_free(Al); gf2o_free(Bf); gf2o_free(Cl);
+  }
+  if (k > kkk) { /* last inner slab: always accumulates into the bulk */
+    gf2o_mat *Al = win(A, 0, kkk, mmm, k), *Bl = win(B, kkk, 0, k, nnn), *Cb = win(C, 0, 0, mmm, nnn);
+    gf2o_mul_m4rm(Cb, Al, Bl, 0, 0);
+    gf2o_free(Al); gf2o_free(Bl); gf2o_free(Cb);
+  }
+}
+
+/* _mzd_mul_even, strassen.c:41-208 */
+gf2o_mat *gf2o_mul_even(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff) {
+  if (C->nrows == 0 || C->ncols == 0) return C;
+  const int64_t m = A->nrows, k = A->ncols, n = B->ncols;
+  if (closer(m, cutoff) || closer(k, cutoff) || closer(n, cutoff)) /* leaf :51-67 */
+    return gf2o_mul_m4rm(C, A, B, 0, 1);
+
+  int64_t mmm, kkk, nnn;
+  split_sizes(m, k, n, cutoff, &mmm, &kkk, &nnn);
+
+  gf2o_mat *A11 = win(A, 0, 0, mmm, kkk), *A12 = win(A, 0, kkk, mmm, 2 * kkk);
+  gf2o_mat *A21 = win(A, mmm, 0, 2 * mmm, kkk), *A22 = win(A, mmm, kkk, 2 * mmm, 2 * kkk);
+  gf2o_mat *B11 = win(B, 0, 0, kkk, nnn), *B12 = win(B, 0, nnn, kkk, 2 * nnn);
+  gf2o_mat *B21 = win(B, kkk, 0, 2 * kkk, nnn), *B22 = win(B, kkk, nnn, 2 * kkk, 2 * nnn);
+  gf2o_mat *C11 = win(C, 0, 0, mmm, nnn), *C12 = win(C, 0, nnn, mmm, 2 * nnn);
+  gf2o_mat *C21 = win(C, mmm, 0, 2 * mmm, nnn), *C22 = win(C, mmm, nnn, 2 * mmm, 2 * nnn);
+
+  /* 7 products, 15 additions, strassen.c:108-150 */
+  gf2o_mat *X = gf2o_init((int32_t)mmm, (int32_t)kkk); /* Wmk */
+  gf2o_mat *Y = gf2o_init((int32_t)kkk, (int32_t)nnn); /* Wkn */
+  gf2o_add(Y, B22, B12);
+  gf2o_add(X, A22, A12);
+  gf2o_mul_even(C21, X, Y, cutoff);
+  gf2o_add(X, A22, A21);
+  gf2o_add(Y, B22, B21);
+  gf2o_mul_even(C22, X, Y, cutoff);
+  gf2o_add(Y, Y, B12);
+  gf2o_add(X, X, A12);
+  gf2o_mul_even(C11, X, Y, cutoff);
+  gf2o_add(X, X, A11);
+  gf2o_mul_even(C12, X, B12, cutoff);
+  gf2o_add(C12, C12, C22);
+  gf2o_free(X);
+  X = gf2o_init((int32_t)mmm, (int32_t)nnn); /* :137: a fresh product A12*B21 */
+  gf2o_mul_even(X, A12, B21, cutoff);
+  gf2o_add(C11, C11, X);
+  gf2o_add(C12, C11, C12);
+  gf2o_add(C11, C21, C11);
+  gf2o_add(Y, Y, B11);
+  gf2o_mul_even(C21, A21, Y, cutoff);
+  gf2o_free(Y);
+  gf2o_add(C21, C11, C21);
+  gf2o_add(C22, C22, C11);
+  gf2o_mul_even(C11, A11, B11, cutoff);
+  gf2o_add(C11, C11, X);
+  gf2o_free(X);
+
+  gf2o_free(A11); gf2o_free(A12); gf2o_free(A21); gf2o_free(A22);
+  gf2o_free(B11); gf2o_free(B12); gf2o_free(B21); gf2o_free(B22);
+  gf2o_free(C11); gf2o_free(C12); gf2o_free(C21); gf2o_free(C22);
+
+  peel(C, A, B, mmm, kkk, nnn, 1);
+  return C;
+}
+
+/* _mzd_addmul_even, strassen.c:367-526 */
+gf2o_mat *gf2o_addmul_even(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff) {
+  if (C->nrows == 0 || C->ncols == 0) return C;
+  const int64_t m = A->nrows, k = A->ncols, n = B->ncols;
+  if (closer(m, cutoff) || closer(k, cutoff) || closer(n, cutoff)) /* leaf :377-394 */
+    return gf2o_mul_m4rm(C, A, B, 0, 0);
+
+  int64_t mmm, kkk, nnn;
+  split_sizes(m, k, n, cutoff, &mmm, &kkk, &nnn);
+
+  gf2o_mat *A11 = win(A, 0, 0, mmm, kkk), *A12 = win(A, 0, kkk, mmm, 2 * kkk);
+  gf2o_mat *A21 = win(A, mmm, 0, 2 * mmm, kkk), *A22 = win(A, mmm, kkk, 2 * mmm, 2 * kkk);
+  gf2o_mat *B11 = win(B, 0, 0, kkk, nnn), *B12 = win(B, 0, nnn, kkk, 2 * nnn);
+  gf2o_mat *B21 = win(B, kkk, 0, 2 * kkk, nnn), *B22 = win(B, kkk, nnn, 2 * kkk, 2 * nnn);
+  gf2o_mat *C11 = win(C, 0, 0, mmm, nnn), *C12 = win(C, 0, nnn, mmm, 2 * nnn);
+  gf2o_mat *C21 = win(C, mmm, 0, 2 * mmm, nnn), *C22 = win(C, mmm, nnn, 2 * mmm, 2 * nnn);
+
+  /* 14 additions, 2 products + 5 accumulating products, strassen.c:436-466 */
+  gf2o_mat *S = gf2o_init((int32_t)mmm, (int32_t)kkk);
+  gf2o_mat *T = gf2o_init((int32_t)kkk, (int32_t)nnn);
+  gf2o_mat *U = gf2o_init((int32_t)mmm, (int32_t)nnn);
+  gf2o_add(S, A22, A21);
+  gf2o_add(T, B22, B21);
+  gf2o_mul_even(U, S, T, cutoff);
+  gf2o_add(C22, U, C22);
+  gf2o_add(C12, U, C12);
+  gf2o_mul_even(U, A12, B21, cutoff);
+  gf2o_add(C11, U, C11);
+  gf2o_addmul_even(C11, A11, B11, cutoff);
+  gf2o_add(S, S, A12);
+  gf2o_add(T, T, B12);
+  gf2o_addmul_even(U, S, T, cutoff);
+  gf2o_add(C12, C12, U);
+  gf2o_add(S, A11, S);
+  gf2o_addmul_even(C12, S, B12, cutoff);
+  gf2o_add(T, B11, T);
+  gf2o_addmul_even(C21, A21, T, cutoff);
+  gf2o_add(S, A22, A12);
+  gf2o_add(T, B22, B12);
+  gf2o_addmul_even(U, S, T, cutoff);
+  gf2o_add(C21, C21, U);
+  gf2o_add(C22, C22, U);
+  gf2o_free(S); gf2o_free(T); gf2o_free(U);
+
+  gf2o_free(A11); gf2o_free(A12); gf2o_free(A21); gf2o_free(A22);
+  gf2o_free(B11); gf2o_free(B12); gf2o_free(B21); gf2o_free(B22);
+  gf2o_free(C11); gf2o_free(C12); gf2o_free(C21); gf2o_free(C22);
+
+  peel(C, A, B, mmm, kkk, nnn, 0);
+  return C;
+}
+
+/* cutoff normalisation shared by mzd_mul / mzd_addmul, strassen.c:348-354 / :679-685.  The
+ * reference's default is MIN(sqrt(4*L3), 4096) (strassen.h:133-135) = 4096 for any L3 >= 4 MiB. */
+static int norm_cutoff(int cutoff, const char *who) {
+  if (cutoff < 0) { fprintf(stderr, "gf2_oracle: %s: cutoff must be >= 0.\n", who); abort(); }
+  if (cutoff == 0) cutoff = 4096;
+  cutoff = cutoff / RADIX * RADIX;
+  if (cutoff < RADIX) cutoff = RADIX;
+  return cutoff;
+}
+
+/* mzd_mul, strassen.c:345-365.  A == B runs _mzd_sqr_even there (:210-343); its result is that of
+ * the general routine with B := A, which is what this does. */
+gf2o_mat *gf2o_mul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff) {
+  if (A->ncols != B->nrows) die("mul: A ncols need to match B nrows");
+  cutoff = norm_cutoff(cutoff, "mul");
+  if (!C) C = gf2o_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols) die("mul: C has wrong dimensions");
+  return gf2o_mul_even(C, A, B, cutoff);
+}
+
+/* mzd_addmul, strassen.c:675-700 */
+gf2o_mat *gf2o_addmul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff) {
+  if (A->ncols != B->nrows) die("addmul: A ncols need to match B nrows");
+  cutoff = norm_cutoff(cutoff, "addmul");
+  if (!C) C = gf2o_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols) die("addmul: C has wrong dimensions");
+  if (A->nrows == 0 || A->ncols == 0 || B->ncols == 0) return C;
+  return gf2o_addmul_even(C, A, B, cutoff);
+}

@@ -1,0 +1,75 @@
+/* oracle/gf2_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, single-threaded CPU restatement of M4RI's dense GF(2) multiply path
+ * (mzd_mul -> Strassen-Winograd -> M4RM leaf).  It exists so the HIP path can be checked bit for
+ * bit; nothing under m4ri_amd/ may include, link or call it.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it.
+ *
+ * Pinning: tests/test_oracle_vs_reference.py runs every function here against the real reference
+ * built from /root/reference into oracle/_ref/ (oracle/Makefile) on the shapes of the reference's
+ * own tests/test_multiplication.c and tests/test_smallops.c, and tests/golden/ holds fixtures
+ * generated from that reference build (tests/golden/make_golden.py).
+ *
+ * The matrix descriptor is layout-identical to the reference's mzd_t
+ * (/root/reference m4ri/mzd.h:68-99: nrows@0, ncols@4, width@8, rowstride@16, flags@24,
+ * high_bitmask@48, data@56, sizeof == 64) so one ctypes structure serves oracle, reference and
+ * product alike.
+ */
+#ifndef GF2_ORACLE_H
+#define GF2_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t gf2o_word;
+
+typedef struct gf2o_mat {
+  int32_t nrows;
+  int32_t ncols;
+  int64_t width;        /* words holding valid bits: ceil(ncols/64)            */
+  int64_t rowstride;    /* words between rows                                  */
+  uint8_t flags;        /* 0x2: ncols%64 != 0 ("non-zero excess"), 0x4: window */
+  uint8_t pad[23];
+  gf2o_word high_bitmask; /* valid bits of word width-1                        */
+  gf2o_word *data;
+} gf2o_mat;
+
+#define GF2O_FLAG_EXCESS 0x2
+#define GF2O_FLAG_WINDOW 0x4
+
+/* allocation / views (mzd.c:142-185) */
+gf2o_mat *gf2o_init(int32_t r, int32_t c);
+gf2o_mat *gf2o_init_window(gf2o_mat *M, int32_t lowr, int32_t lowc, int32_t highr, int32_t highc);
+void gf2o_free(gf2o_mat *A);
+
+/* fill: exactly `width` PRNG words per row, row-major, last one masked into the row
+ * (mzd.c:1282-1292 mzd_randomize_custom); PRNG = splitmix64 seeded with `seed`. */
+void gf2o_fill_splitmix(gf2o_mat *A, uint64_t seed);
+uint64_t gf2o_splitmix_next(uint64_t *state);
+
+/* element-wise helpers: mzd.c:1471 (_mzd_add), :1363 (mzd_copy), :1294 (mzd_set_ui(.,0)),
+ * :1314 (mzd_equal: valid bits only) */
+gf2o_mat *gf2o_add(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B);
+gf2o_mat *gf2o_copy(gf2o_mat *N, const gf2o_mat *P);
+void gf2o_set_zero(gf2o_mat *A);
+int gf2o_equal(const gf2o_mat *A, const gf2o_mat *B);
+
+/* products.  `clear` != 0: C = A*B, else C ^= A*B.  All return C. */
+gf2o_mat *gf2o_mul_naive(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int clear);       /* mzd.c:1256-1268 */
+gf2o_mat *gf2o_mul_m4rm(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int k, int clear);  /* brilliantrussian.c:1032-1190 */
+gf2o_mat *gf2o_mul_even(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);        /* strassen.c:41-208 */
+gf2o_mat *gf2o_addmul_even(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);     /* strassen.c:367-526 */
+gf2o_mat *gf2o_mul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);             /* strassen.c:345-365 */
+gf2o_mat *gf2o_addmul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);          /* strassen.c:675-700 */
+
+/* FNV-1a over the valid bits, row-major, excess masked: a size-independent fingerprint used for
+ * the large fixtures (the reference's own mzd_hash is unusable: debug_dump.h:35 shifts by data). */
+uint64_t gf2o_fingerprint(const gf2o_mat *A);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

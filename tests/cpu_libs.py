@@ -1,0 +1,152 @@
+"""ctypes bindings of the two CPU checkers used by the tests (never by the product path):
+
+  * oracle/liboracle_gf2.so      our plain-C restatement (oracle/gf2_oracle.c), built on demand;
+  * oracle/_ref/libm4ri_ref.so   the real reference compiled from /root/reference by oracle/Makefile
+                                 (present in the build container and, as a binary, on the GPU box).
+
+All three libraries (these two and libm4ri_amd.so) share one descriptor layout, m4ri_amd.mzd.MzdStruct.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+from m4ri_amd.mzd import Mzd, MzdPtr, from_struct_ptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_I = ctypes.c_int
+
+
+def _stale(target, deps):
+    return (not os.path.exists(target)) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
+class Oracle:
+    def __init__(self, path):
+        L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        self.L = L
+        sig4 = (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I])
+        for name, (res, args) in {
+            "gf2o_mul": sig4, "gf2o_addmul": sig4, "gf2o_mul_even": sig4, "gf2o_addmul_even": sig4,
+            "gf2o_mul_naive": sig4,
+            "gf2o_mul_m4rm": (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I, _I]),
+            "gf2o_add": (MzdPtr, [MzdPtr, MzdPtr, MzdPtr]),
+            "gf2o_copy": (MzdPtr, [MzdPtr, MzdPtr]),
+            "gf2o_set_zero": (None, [MzdPtr]),
+            "gf2o_equal": (_I, [MzdPtr, MzdPtr]),
+            "gf2o_fill_splitmix": (None, [MzdPtr, ctypes.c_uint64]),
+            "gf2o_fingerprint": (ctypes.c_uint64, [MzdPtr]),
+            "gf2o_free": (None, [MzdPtr]),
+        }.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+
+    def _ret(self, C, r):
+        return C if C is not None else from_struct_ptr(r, self.L.gf2o_free)
+
+    def mul(self, C, A, B, cutoff=0):
+        return self._ret(C, self.L.gf2o_mul(C.ptr if C else None, A.ptr, B.ptr, cutoff))
+
+    def addmul(self, C, A, B, cutoff=0):
+        return self._ret(C, self.L.gf2o_addmul(C.ptr if C else None, A.ptr, B.ptr, cutoff))
+
+    def mul_naive(self, C, A, B, clear=1):
+        self.L.gf2o_mul_naive(C.ptr, A.ptr, B.ptr, clear)
+        return C
+
+    def mul_m4rm(self, C, A, B, k=0, clear=1):
+        self.L.gf2o_mul_m4rm(C.ptr, A.ptr, B.ptr, k, clear)
+        return C
+
+    def add(self, C, A, B):
+        self.L.gf2o_add(C.ptr, A.ptr, B.ptr)
+        return C
+
+    def fill(self, A, seed):
+        self.L.gf2o_fill_splitmix(A.ptr, seed)
+
+    def fingerprint(self, A):
+        return int(self.L.gf2o_fingerprint(A.ptr))
+
+    def equal(self, A, B):
+        return bool(self.L.gf2o_equal(A.ptr, B.ptr))
+
+
+class Reference:
+    """The real M4RI, for pinning the oracle (and as bench.py's cpu_baseline when present)."""
+
+    def __init__(self, path):
+        L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        self.L = L
+        sig4 = (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I])
+        sig3 = (MzdPtr, [MzdPtr, MzdPtr, MzdPtr])
+        table = {
+            "mzd_mul": sig4, "mzd_addmul": sig4, "_mzd_mul_even": sig4, "_mzd_addmul_even": sig4, "_mzd_addmul": sig4,
+            "mzd_mul_m4rm": sig4, "mzd_addmul_m4rm": sig4,
+            "_mzd_mul_m4rm": (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I, _I]),
+            "mzd_mul_naive": sig3, "mzd_addmul_naive": sig3, "_mzd_add": sig3,
+            "mzd_copy": (MzdPtr, [MzdPtr, MzdPtr]),
+            "mzd_equal": (_I, [MzdPtr, MzdPtr]),
+            "mzd_free": (None, [MzdPtr]),
+            "mzd_init": (MzdPtr, [_I, _I]),
+        }
+        for name, (res, args) in table.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        self.has_mp = hasattr(L, "mzd_mul_mp")
+        if self.has_mp:
+            L.mzd_mul_mp.restype, L.mzd_mul_mp.argtypes = sig4
+            L.mzd_addmul_mp.restype, L.mzd_addmul_mp.argtypes = sig4
+
+    def _ret(self, C, r):
+        return C if C is not None else from_struct_ptr(r, self.L.mzd_free)
+
+    def mul(self, C, A, B, cutoff=0):
+        return self._ret(C, self.L.mzd_mul(C.ptr if C else None, A.ptr, B.ptr, cutoff))
+
+    def addmul(self, C, A, B, cutoff=0):
+        return self._ret(C, self.L.mzd_addmul(C.ptr if C else None, A.ptr, B.ptr, cutoff))
+
+    def mul_m4rm(self, C, A, B, k=0):
+        return self._ret(C, self.L.mzd_mul_m4rm(C.ptr if C else None, A.ptr, B.ptr, k))
+
+    def addmul_m4rm(self, C, A, B, k=0):
+        self.L.mzd_addmul_m4rm(C.ptr, A.ptr, B.ptr, k)
+        return C
+
+    def mul_naive(self, C, A, B):
+        return self._ret(C, self.L.mzd_mul_naive(C.ptr if C else None, A.ptr, B.ptr))
+
+    def mul_mp(self, C, A, B, cutoff=0):
+        return self._ret(C, self.L.mzd_mul_mp(C.ptr if C else None, A.ptr, B.ptr, cutoff))
+
+    def add(self, C, A, B):
+        self.L._mzd_add(C.ptr, A.ptr, B.ptr)
+        return C
+
+
+_oracle = None
+_refs = {}
+
+
+def oracle() -> Oracle:
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ORACLE_DIR, "liboracle_gf2.so")
+        deps = [os.path.join(ORACLE_DIR, f) for f in ("gf2_oracle.c", "gf2_oracle.h")]
+        if _stale(so, deps):
+            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle_gf2.so"], check=True, capture_output=True)
+        _oracle = Oracle(so)
+    return _oracle
+
+
+def reference(openmp: bool = False) -> Reference | None:
+    name = "libm4ri_ref_omp.so" if openmp else "libm4ri_ref.so"
+    if name not in _refs:
+        so = os.path.join(ORACLE_DIR, "_ref", name)
+        if not os.path.exists(so) and os.path.exists("/root/reference/m4ri/mzd.c"):
+            subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
+        _refs[name] = Reference(so) if os.path.exists(so) else None
+    return _refs[name]

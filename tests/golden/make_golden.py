@@ -1,0 +1,134 @@
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libm4ri_ref.so, built from
+/root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py [--large]
+
+Two kinds of fixture (the reference tree itself holds none -- all its tests are differential):
+  kat_small.npz   full input/output words for small cases of the reference's own test shapes
+                  (tests/test_multiplication.c:251-322) plus window cases (tests/test_smallops.c);
+  fingerprints.npz  FNV-1a fingerprints (oracle gf2o_fingerprint / Mzd.fingerprint) of large products
+                  whose inputs are regenerated from splitmix64 seeds, so nothing big is committed.
+Inputs are always Mzd.random(rows, cols, seed) = the fill order of mzd_randomize_custom
+(mzd.c:1282-1292) fed with the splitmix64 stream `seed`.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cpu_libs  # noqa: E402
+import shapes  # noqa: E402
+from m4ri_amd.mzd import Mzd  # noqa: E402
+
+ref = cpu_libs.reference()
+assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+orc = cpu_libs.oracle()
+
+
+def kat_small():
+    out = {}
+    idx = 0
+    cases = []
+    for (m, l, n, k, cutoff) in shapes.MUL + shapes.EDGE:
+        if max(m, l, n) <= 257:
+            cases.append(("mul", m, l, n, cutoff))
+            cases.append(("m4rm", m, l, n, k))
+    for (m, l, n, k, cutoff) in shapes.ADDMUL:
+        if max(m, l, n) <= 257:
+            cases.append(("addmul", m, l, n, cutoff))
+    for (n, k, cutoff) in shapes.SQR:
+        if n <= 257:
+            cases.append(("sqr", n, n, n, cutoff))
+    for (op, m, l, n, par) in cases:
+        sa, sb, sc = shapes.seed_of(21, idx, 1), shapes.seed_of(21, idx, 2), shapes.seed_of(21, idx, 3)
+        A = Mzd.random(m, l, sa)
+        B = A if op == "sqr" else Mzd.random(l, n, sb)
+        if op in ("mul", "sqr"):
+            C = ref.mul(None, A, B, par)
+        elif op == "m4rm":
+            if not (m and l and n):
+                continue
+            C = ref.mul_m4rm(None, A, B, par)
+        else:
+            C = ref.addmul(Mzd.random(m, n, sc), A, B, par)
+        out[f"case{idx}_meta"] = np.array([m, l, n, par], dtype=np.int64)
+        out[f"case{idx}_op"] = np.array(op)
+        out[f"case{idx}_seeds"] = np.array([sa, sb, sc], dtype=np.uint64)
+        out[f"case{idx}_A"] = A.masked()
+        out[f"case{idx}_B"] = B.masked()
+        out[f"case{idx}_C"] = C.masked()
+        idx += 1
+    # window cases (cutoff 0, the path test_smallops.c exercises): parent buffers before/after
+    for (M, N, m, n) in shapes.SMALLOPS[:2]:
+        pat = np.uint64(shapes.SMALLOPS_PATTERN)
+        PA, PB, PC = Mzd.init(M, N), Mzd.init(M, N), Mzd.init(M, N)
+        for P in (PA, PB, PC):
+            P.rows()[:, :] = pat
+        k = min(m, n)
+        a, b, c = PA.window(0, 0, m, k), PB.window(0, 0, k, n), PC.window(0, 0, m, n)
+        a.fill_splitmix(shapes.seed_of(22, M, N, 1))
+        b.fill_splitmix(shapes.seed_of(22, M, N, 2))
+        c.fill_splitmix(shapes.seed_of(22, M, N, 3))
+        ref.addmul(c, a, b, 0)
+        out[f"win{M}_{N}_{m}_{n}_parentC"] = PC.buf.copy()
+    out["ncases"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "kat_small.npz"), **out)
+    print("kat_small.npz:", idx, "cases")
+
+
+def fingerprints(large):
+    rows = []
+    todo = [("mul", 1025, 1025, 1025, 256), ("mul", 2048, 2048, 4096, 1024), ("mul", 4096, 3528, 4096, 1024),
+            ("addmul", 4096, 4096, 4096, 2048), ("mul", 4096, 4096, 4096, 0), ("m4rm", 4096, 4096, 4096, 0),
+            ("mul", 1710, 1290, 1000, 256), ("mul", 8192, 8192, 8192, 0), ("mul", 3000, 5000, 7001, 0)]
+    if large:
+        todo += [("mul", 16384, 16384, 16384, 0)]
+    for i, (op, m, l, n, par) in enumerate(todo):
+        sa, sb, sc = 1000 + 3 * i, 1001 + 3 * i, 1002 + 3 * i
+        t = time.time()
+        A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
+        if op == "mul":
+            C = ref.mul(None, A, B, par)
+        elif op == "m4rm":
+            C = ref.mul_m4rm(None, A, B, par)
+        else:
+            C = ref.addmul(Mzd.random(m, n, sc), A, B, par)
+        fp = orc.fingerprint(C)
+        rows.append((op, m, l, n, par, sa, sb, sc, fp))
+        print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fingerprints.npz"),
+                        ops=np.array([r[0] for r in rows]),
+                        meta=np.array([r[1:5] for r in rows], dtype=np.int64),
+                        seeds=np.array([r[5:8] for r in rows], dtype=np.uint64),
+                        fp=np.array([r[8] for r in rows], dtype=np.uint64))
+
+
+def fingerprints_xl():
+    """BASELINE.json configs 3 and 5 at full size (minutes of reference CPU time, ~5 GiB of RAM)."""
+    rows = []
+    for (op, m, l, n, par, sa, sb) in [("mul", 65536, 65536, 65536, 0, 3, 4), ("mul", 131072, 8192, 131072, 0, 5, 6)]:
+        t = time.time()
+        A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
+        C = ref.mul(None, A, B, par)
+        fp = orc.fingerprint(C)
+        rows.append((op, m, l, n, par, sa, sb, 0, fp))
+        print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)
+        del A, B, C
+    np.savez_compressed(os.path.join(HERE, "fingerprints_xl.npz"),
+                        ops=np.array([r[0] for r in rows]),
+                        meta=np.array([r[1:5] for r in rows], dtype=np.int64),
+                        seeds=np.array([r[5:8] for r in rows], dtype=np.uint64),
+                        fp=np.array([r[8] for r in rows], dtype=np.uint64))
+
+
+if __name__ == "__main__":
+    if "--xl" in sys.argv:
+        fingerprints_xl()
+    else:
+        kat_small()
+        fingerprints("--large" in sys.argv)

@@ -1,0 +1,302 @@
+"""Parity proper (needs an MI355X): the HIP path, called through the C ABI of libm4ri_amd.so, against
+the CPU oracle on the same seeded inputs, against the committed golden fixtures (generated from the
+real reference), and -- at BASELINE.json's full sizes -- against reference fingerprints and
+size-independent identities.  Bit-exact everywhere: this is integer work.
+
+Shapes are the reference's own (tests/test_multiplication.c:251-322, tests/test_smallops.c:115-121)
+plus empty / ragged / word-boundary edges.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import m4ri_amd
+import shapes
+from m4ri_amd.mzd import Mzd
+from test_golden_oracle import GOLD, load_kats, run_kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    L = m4ri_amd.lib()
+    assert L.m4ri_amd_device_count() >= 1, "no HIP device visible: the gpu tests have nothing to run on"
+    m4ri_amd.init(0)
+
+
+def _pair(m, l, n, tag):
+    return Mzd.random(m, l, shapes.seed_of(tag, m, l, n, 1)), Mzd.random(l, n, shapes.seed_of(tag, m, l, n, 2))
+
+
+# ---- the reference's own differential shapes ------------------------------------------------------
+@pytest.mark.parametrize("m,l,n,k,cutoff", shapes.MUL + shapes.EDGE)
+def test_mul(oracle, m, l, n, k, cutoff):
+    A, B = _pair(m, l, n, 31)
+    want = oracle.mul(None, A, B, cutoff)
+    assert m4ri_amd.mzd_mul(None, A, B, cutoff).equal(want)            # C == NULL: allocated result
+    assert m4ri_amd.mzd_mul(Mzd.random(m, n, 5), A, B, cutoff).equal(want)  # dirty C is overwritten
+    assert m4ri_amd.mzd_mul_m4rm(None, A, B, k).equal(want)            # leaf only
+    assert m4ri_amd.mzd_mul_mp(None, A, B, cutoff).equal(want)
+    if m and n:
+        assert m4ri_amd._mzd_mul_even(Mzd.init(m, n), A, B, max(64, cutoff)).equal(want)
+        assert m4ri_amd._mzd_mul_m4rm(Mzd.random(m, n, 6), A, B, k, 1).equal(want)
+
+
+@pytest.mark.parametrize("m,l,n,k,cutoff", shapes.ADDMUL)
+def test_addmul(oracle, m, l, n, k, cutoff):
+    A, B = _pair(m, l, n, 32)
+    C0 = Mzd.random(m, n, shapes.seed_of(32, m, l, n, 3))
+    want = oracle.addmul(C0.copy(), A, B, cutoff)
+    assert m4ri_amd.mzd_addmul(C0.copy(), A, B, cutoff).equal(want)
+    assert m4ri_amd.mzd_addmul_m4rm(C0.copy(), A, B, k).equal(want)
+    assert m4ri_amd._mzd_addmul(C0.copy(), A, B, max(64, cutoff)).equal(want)
+    assert m4ri_amd._mzd_addmul_even(C0.copy(), A, B, max(64, cutoff)).equal(want)
+    assert m4ri_amd._mzd_mul_m4rm(C0.copy(), A, B, k, 0).equal(want)
+    assert m4ri_amd.mzd_addmul_mp(C0.copy(), A, B, cutoff).equal(want)
+
+
+@pytest.mark.parametrize("n,k,cutoff", shapes.SQR)
+def test_sqr_aliasing(oracle, n, k, cutoff):
+    A = Mzd.random(n, n, shapes.seed_of(33, n))
+    want = oracle.mul(None, A, A, cutoff)
+    assert m4ri_amd.mzd_mul(None, A, A, cutoff).equal(want)  # A == B, same pointer (strassen.c:363)
+    L = m4ri_amd.lib()
+    C = Mzd.init(n, n)
+    L._mzd_sqr_even(C.ptr, A.ptr, max(64, cutoff))
+    assert C.equal(want)
+
+
+@pytest.mark.parametrize("n,k,cutoff", shapes.ADDSQR)
+def test_addsqr_aliasing(oracle, n, k, cutoff):
+    A = Mzd.random(n, n, shapes.seed_of(34, n))
+    C0 = Mzd.random(n, n, shapes.seed_of(34, n, 3))
+    want = oracle.addmul(C0.copy(), A, A, cutoff)
+    assert m4ri_amd.mzd_addmul(C0.copy(), A, A, cutoff).equal(want)
+    C = C0.copy()
+    m4ri_amd.lib()._mzd_addsqr_even(C.ptr, A.ptr, max(64, cutoff))
+    assert C.equal(want)
+
+
+@pytest.mark.parametrize("m,l,n", shapes.EMPTY_INNER)
+def test_empty_inner_dimension(m, l, n):
+    A, B = Mzd.init(m, l), Mzd.init(l, n)
+    C = Mzd.random(m, n, 9)
+    keep = C.copy()
+    assert m4ri_amd.mzd_addmul(C, A, B, 0).equal(keep)      # C += 0
+    assert m4ri_amd.mzd_mul(C, A, B, 0).equal(Mzd.init(m, n))  # C = 0
+
+
+# ---- windows with non-zero excess inside a pattern-filled parent (test_smallops.c) --------------
+@pytest.mark.parametrize("M,N,m,n", shapes.SMALLOPS)
+@pytest.mark.parametrize("cutoff", [0, 64])
+def test_windows_preserve_parent(oracle, M, N, m, n, cutoff):
+    pat = np.uint64(shapes.SMALLOPS_PATTERN)
+
+    def parent():
+        P = Mzd.init(M, N)
+        P.rows()[:, :] = pat
+        return P
+
+    PA, PB, PCg, PCo = parent(), parent(), parent(), parent()
+    k = min(m, n)
+    a, b = PA.window(0, 0, m, k), PB.window(0, 0, k, n)
+    a.fill_splitmix(shapes.seed_of(35, M, N, 1))
+    b.fill_splitmix(shapes.seed_of(35, M, N, 2))
+    cg, co = PCg.window(0, 0, m, n), PCo.window(0, 0, m, n)
+    cg.fill_splitmix(78)
+    co.fill_splitmix(78)
+    m4ri_amd.mzd_mul(cg, a, b, cutoff)
+    oracle.mul(co, a, b, cutoff)
+    assert np.array_equal(PCg.buf, PCo.buf)  # every word of the parent, pattern and excess bits included
+    m4ri_amd.mzd_addmul(cg, a, b, cutoff)
+    oracle.addmul(co, a, b, cutoff)
+    assert np.array_equal(PCg.buf, PCo.buf)
+    m4ri_amd.mzd_addmul_m4rm(cg, a, b, 0)
+    oracle.mul_m4rm(co, a, b, 0, 0)
+    assert np.array_equal(PCg.buf, PCo.buf)
+    # a window that does not start at (0,0): rows and word-aligned columns offset
+    if M >= 2 * m and N >= 64 + n:
+        cg2, co2 = PCg.window(M - m, 64, M, 64 + n), PCo.window(M - m, 64, M, 64 + n)
+        m4ri_amd.mzd_mul(cg2, a, b, cutoff)
+        oracle.mul(co2, a, b, cutoff)
+        assert np.array_equal(PCg.buf, PCo.buf)
+    assert np.all(PA.rows()[m:, :] == pat) and np.all(PB.rows()[k:, :] == pat)  # operands only read
+
+
+def test_smallops_identity():
+    """(A+B)^2 == A^2 + BA + AB + B^2 through mzd_mul / mzd_addmul (test_smallops.c:70-85)."""
+    for n in (64, 513, 1024):
+        A, B = Mzd.random(n, n, 41), Mzd.random(n, n, 42)
+        S = Mzd.init(n, n)
+        S.valid_words()[:, :] = A.valid_words() ^ B.valid_words()
+        D = m4ri_amd.mzd_mul(None, S, S, 0)
+        C = m4ri_amd.mzd_mul(None, A, A, 0)
+        m4ri_amd.mzd_addmul(C, B, A, 0)
+        m4ri_amd.mzd_addmul(C, A, B, 0)
+        m4ri_amd.mzd_addmul(C, B, B, 0)
+        assert C.equal(D)
+
+
+# ---- golden fixtures from the real reference -----------------------------------------------------
+@pytest.mark.parametrize("case", list(load_kats()), ids=lambda c: f"{c[1]}-{c[2]}x{c[3]}x{c[4]}-{c[5]}")
+def test_golden_kat(case):
+    i, op, m, l, n, par, seeds, Aw, Bw, Cw = case
+    got = run_kat(m4ri_amd.mzd_mul, m4ri_amd.mzd_addmul, lambda C, A, B, k: m4ri_amd.mzd_mul_m4rm(C, A, B, k),
+                  op, m, l, n, par, seeds, Aw, Bw)
+    assert np.array_equal(got.masked(), Cw)
+
+
+def test_golden_window_parents():
+    z = np.load(os.path.join(GOLD, "kat_small.npz"))
+    for (M, N, m, n) in shapes.SMALLOPS[:2]:
+        pat = np.uint64(shapes.SMALLOPS_PATTERN)
+        PA, PB, PC = Mzd.init(M, N), Mzd.init(M, N), Mzd.init(M, N)
+        for P in (PA, PB, PC):
+            P.rows()[:, :] = pat
+        k = min(m, n)
+        a, b, c = PA.window(0, 0, m, k), PB.window(0, 0, k, n), PC.window(0, 0, m, n)
+        a.fill_splitmix(shapes.seed_of(22, M, N, 1))
+        b.fill_splitmix(shapes.seed_of(22, M, N, 2))
+        c.fill_splitmix(shapes.seed_of(22, M, N, 3))
+        m4ri_amd.mzd_addmul(c, a, b, 0)
+        assert np.array_equal(PC.buf, z[f"win{M}_{N}_{m}_{n}_parentC"])
+
+
+def test_golden_fingerprints_host_api(oracle):
+    """Large products of the reference, inputs regenerated from seeds (incl. the 4096x3528x4096
+    regression shape named in strassen.c:127-134, 8192^3, a ragged 3000x5000x7001 and 16384^3)."""
+    z = np.load(os.path.join(GOLD, "fingerprints.npz"))
+    for op, (m, l, n, par), (sa, sb, sc), fp in zip(z["ops"], z["meta"], z["seeds"], z["fp"]):
+        m, l, n, par = int(m), int(l), int(n), int(par)
+        A, B = Mzd.random(m, l, int(sa)), Mzd.random(l, n, int(sb))
+        if op == "mul":
+            C = m4ri_amd.mzd_mul(None, A, B, par)
+        elif op == "m4rm":
+            C = m4ri_amd.mzd_mul_m4rm(None, A, B, par)
+        else:
+            C = m4ri_amd.mzd_addmul(Mzd.random(m, n, int(sc)), A, B, par)
+        assert oracle.fingerprint(C) == int(fp), (op, m, l, n, par)
+        # cutoff / k are hints: other values give the same bits
+        if op == "mul" and m * l * n <= 4096 ** 3:
+            for other in (64, 512, 1 << 20):
+                assert oracle.fingerprint(m4ri_amd.mzd_mul(None, A, B, other)) == int(fp)
+
+
+# ---- device-resident API at BASELINE sizes ----------------------------------------------------
+torch = pytest.importorskip("torch")
+
+
+def dev_random(rows, cols, seed):
+    w = (cols + 63) // 64
+    t = torch.empty((rows, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.fill_dev(t.data_ptr(), w, rows, cols, seed)
+    return t
+
+
+def to_host(t, rows, cols):
+    M = Mzd(rows, cols, rowstride=t.shape[1])
+    torch.cuda.synchronize()
+    M.rows()[:, :] = t.cpu().numpy().view(np.uint64)
+    return M
+
+
+def test_device_fill_matches_host_fill():
+    for (r, c) in [(3, 1), (5, 65), (100, 4096), (7, 200)]:
+        t = dev_random(r, c, 1234)
+        assert np.array_equal(to_host(t, r, c).masked(), Mzd.random(r, c, 1234).masked())
+
+
+def test_config2_leaf_16384_vs_reference_fingerprint(oracle):
+    """BASELINE.json configs[1]: 16384^3 through the M4RM leaf only, all 32 MiB of C compared with the
+    reference's product by fingerprint (golden), seeds as in the fixture."""
+    z = np.load(os.path.join(GOLD, "fingerprints.npz"))
+    i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (16384, 16384, 16384)]
+    if not i:
+        pytest.skip("16384^3 fixture not generated")
+    sa, sb, _ = (int(x) for x in z["seeds"][i[0]])
+    n = 16384
+    A, B = dev_random(n, n, sa), dev_random(n, n, sb)
+    C = torch.empty((n, n // 64), dtype=torch.int64, device="cuda")
+    m4ri_amd.m4rm_dev(C.data_ptr(), n // 64, A.data_ptr(), n // 64, B.data_ptr(), n // 64, n, n, n)
+    assert oracle.fingerprint(to_host(C, n, n)) == int(z["fp"][i[0]])
+    # and the Strassen engine gives the same bits
+    C2 = torch.empty_like(C)
+    m4ri_amd.mul_dev(C2.data_ptr(), n // 64, A.data_ptr(), n // 64, B.data_ptr(), n // 64, n, n, n)
+    assert torch.equal(C, C2)
+    st = m4ri_amd.get_stats()
+    assert st.levels == 1 and st.leaf_products == 7
+
+
+def freivalds(oracle, A, B, C, m, l, n, seed):
+    """C == A*B  <=>  C*x == A*(B*x) for a random n x 64 block x (error probability 2^-64), with the
+    thin products done on the CPU by the oracle."""
+    x = Mzd.random(n, 64, seed)
+    Bx = oracle.mul_m4rm(Mzd.init(l, 64), B, x, 8, 1)
+    ABx = oracle.mul_m4rm(Mzd.init(m, 64), A, Bx, 8, 1)
+    Cx = oracle.mul_m4rm(Mzd.init(m, 64), C, x, 8, 1)
+    return ABx.equal(Cx)
+
+
+def test_config3_65536_strassen_properties(oracle):
+    """BASELINE.json configs[2]: 65536^3 mzd_mul on one GPU (seeds 3, 4).  Checked by (i) the
+    reference's fingerprint when the XL fixture exists, (ii) Freivalds' identity on the CPU,
+    (iii) linearity C(A1+A2, B) == C(A1, B) + C(A2, B), (iv) agreement of two different schedules."""
+    n = 65536
+    w = n // 64
+    A, B = dev_random(n, n, 3), dev_random(n, n, 4)
+    C = torch.empty((n, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
+    st = m4ri_amd.get_stats()
+    assert st.levels == 3 and st.leaf_products == 343 and (st.leaf_m, st.leaf_l, st.leaf_n) == (8192, 8192, 8192)
+    hC = to_host(C, n, n)
+    xl = os.path.join(GOLD, "fingerprints_xl.npz")
+    if os.path.exists(xl):
+        z = np.load(xl)
+        i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (n, n, n)][0]
+        assert oracle.fingerprint(hC) == int(z["fp"][i])
+    assert freivalds(oracle, to_host(A, n, n), to_host(B, n, n), hC, n, n, n, 77)
+    # different schedule (2 levels, 16384^3 leaves), same bits
+    C2 = torch.empty_like(C)
+    m4ri_amd.mul_dev(C2.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, cutoff=16384)
+    assert m4ri_amd.get_stats().levels == 2
+    assert torch.equal(C, C2)
+    # linearity, with the accumulate path: C ^= A2*B must equal (A ^ A2)*B
+    A2 = dev_random(n, n, 33)
+    m4ri_amd.mul_dev(C.data_ptr(), w, A2.data_ptr(), w, B.data_ptr(), w, n, n, n, add=True)
+    m4ri_amd.xor_dev(A2.data_ptr(), w, A2.data_ptr(), w, A.data_ptr(), w, n, n)
+    m4ri_amd.mul_dev(C2.data_ptr(), w, A2.data_ptr(), w, B.data_ptr(), w, n, n, n)
+    assert torch.equal(C, C2)
+
+
+def test_config5_rectangular_131072(oracle):
+    """BASELINE.json configs[4] shape on one GPU: 131072 x 8192 x 131072 (C = 2 GiB), seeds 5, 6."""
+    m, l, n = 131072, 8192, 131072
+    A, B = dev_random(m, l, 5), dev_random(l, n, 6)
+    C = torch.empty((m, n // 64), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
+    hC = to_host(C, m, n)
+    xl = os.path.join(GOLD, "fingerprints_xl.npz")
+    if os.path.exists(xl):
+        z = np.load(xl)
+        i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (m, l, n)]
+        if i:
+            assert oracle.fingerprint(hC) == int(z["fp"][i[0]])
+    assert freivalds(oracle, to_host(A, m, l), to_host(B, l, n), hC, m, l, n, 78)
+
+
+def test_device_views_and_ragged_strassen(oracle):
+    """Strided device views + dimensions that leave all three remainder strips (strassen.c:170-204)."""
+    m, l, n = 2 * 8192 + 37, 2 * 8192 + 64 + 5, 2 * 8192 + 128 + 11
+    hA, hB = Mzd.random(m, l, 51), Mzd.random(l, n, 52)
+    wa, wn = hA.rowstride, hB.rowstride
+    A = torch.from_numpy(hA.rows().view(np.int64).copy()).cuda()
+    B = torch.from_numpy(hB.rows().view(np.int64).copy()).cuda()
+    C = torch.zeros((m, wn + 3), dtype=torch.int64, device="cuda")  # padded stride
+    m4ri_amd.mul_dev(C.data_ptr(), wn + 3, A.data_ptr(), wa, B.data_ptr(), wn, m, l, n)
+    assert m4ri_amd.get_stats().levels == 1
+    got = to_host(C, m, n)
+    want = oracle.mul(None, hA, hB, 8192)
+    assert got.equal(want)
+    assert np.all(got.rows()[:, got.width:] == 0)  # padding words never written
