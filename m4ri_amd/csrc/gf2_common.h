@@ -48,7 +48,8 @@ struct LeafArgs {
   int32_t wn;                             // words_of(n)
   int32_t tiles_m, tiles_n;               // tile grid per product
   int32_t ksplit;                         // inner-dimension splits (>=1); >1 => atomic XOR output
-  int32_t stages_per_split;               // LEAF_STAGE-bit stages per split
+  int32_t stages_per_split;               // two-phase kernel: LEAF_STAGE-bit stages per split
+  int32_t chunks_per_split;               // double-buffered kernel: 32-bit A chunks per split
   int32_t batch;
   int32_t mode;                           // 0: C = A*B (plain store), 1: C ^= A*B (no-return atomic xor)
 };

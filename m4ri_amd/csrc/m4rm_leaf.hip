@@ -25,6 +25,14 @@
 #include <hip/hip_runtime.h>
 #include "gf2_common.h"
 
+// (rg, ug, pipe) instantiations.  Product defaults first; the others exist for tools/leaf_check.
+#ifndef LEAF_VARIANTS
+#define LEAF_VARIANTS(X) \
+  X(32, 2, 0) X(24, 4, 0) X(16, 4, 0) X(32, 2, 1) X(32, 4, 0) X(32, 4, 1) X(24, 4, 1) X(24, 2, 1) X(16, 4, 1) X(16, 8, 0) X(16, 8, 1)
+#endif
+#define LEAF_DEFAULT_UG(rg) 4
+#define LEAF_DEFAULT_PIPE(rg) 0
+
 namespace {
 
 __device__ __forceinline__ int64_t words_of_dev(int64_t ncols) { return (ncols + 63) >> 6; }
@@ -50,7 +58,7 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int z) {
   return 0x0c000000u | ((z ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
-template <int RG, bool XOR_OUT>
+template <int RG, int UG, bool PIPE, bool XOR_OUT>
 __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LEAF_NT * 65536];
   constexpr int R = 32 * RG;  // tile rows: 32 row groups (8 waves x 4) x RG rows
@@ -142,6 +150,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
       const int s = 2 * q + half;
       // ---------------- build: 16 entries of table bz, high nibble bhi ----------------------
       {
+        // the B rows become visible to the optimiser only HERE (volatile asm stays behind the
+        // preceding barrier): otherwise hipcc hoists this build's first XORs up to where the rows
+        // were requested, one use phase earlier, and waits out the whole load latency there.
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          asm volatile("" : "+v"(brow[j].x), "+v"(brow[j].y), "+v"(brow[j].z), "+v"(brow[j].w));
         uint32_t cur[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -167,39 +181,68 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
           *reinterpret_cast<uint4 *>(tbl_wr + gcode * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
         }
       }
-      // next stage's B rows: issued now, consumed after the use phase
-      if (s + 1 < s_end) load_b(s + 1);
+      // next stage's B rows: requested now, consumed by the next build, one use phase later.
+      // (Measured: issuing them inside the use phase instead is SLOWER -- the use phase is bound by
+      // each wave's serial issue, and 8 x buffer_load_dwordx4 cost a wave ~270 clk of issue time.)
+      // Unconditional on purpose (rows past the end read as 0 through the descriptor's range
+      // check): a branch makes hipcc resolve the merge with v_movs of the loaded registers, i.e.
+      // an immediate vmcnt(0).  The sched_barriers keep the next build's XORs from being hoisted up
+      // to the loads.
+      load_b(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
       // ---------------- use: RG rows x 2 lookups ------------------------------------------
-      // rows are processed in groups of UG: 2*UG ds_read_b128 in flight, then folded into the
-      // accumulators.  The sched_barrier pins that shape (without it hipcc hoists every read of
-      // the phase above the XORs and spills the tile).
-      constexpr int UG = (RG >= 32) ? 2 : 4;
+      // Rows go through in groups of UG: 2*UG ds_read_b128 per group.  PIPE issues group g+1's
+      // reads before folding group g into the accumulators (two register sets), so the LDS queue
+      // never drains while a wave does its XORs.  The sched_barriers pin that shape: un-pinned,
+      // hipcc hoists every read of the phase above the XORs and spills the tile.
       static_assert(RG % UG == 0, "RG must be a multiple of UG");
-#pragma unroll
-      for (int tb = 0; tb < RG; tb += UG) {
-        uint4 t0[UG], t1[UG];
+      constexpr int NG = RG / UG;
+      uint4 t0[PIPE ? 2 : 1][UG], t1[PIPE ? 2 : 1][UG];
+      auto issue = [&](int g, int slot) {
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
-          const uint32_t a0 = __builtin_amdgcn_perm(areg[tb + u], coloff, perm_sel(2 * half + 0, 0));
-          const uint32_t a1 = __builtin_amdgcn_perm(areg[tb + u], coloff, perm_sel(2 * half + 1, 1));
-          t0[u]             = *reinterpret_cast<const uint4 *>(lds + a0);
-          t1[u]             = *reinterpret_cast<const uint4 *>(lds + a1);
+          const uint32_t a0 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, perm_sel(2 * half + 0, 0));
+          const uint32_t a1 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, perm_sel(2 * half + 1, 1));
+          t0[slot][u]       = *reinterpret_cast<const uint4 *>(lds + a0);
+          t1[slot][u]       = *reinterpret_cast<const uint4 *>(lds + a1);
         }
+      };
+      auto fold = [&](int g, int slot) {
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
-          acc[tb + u][0] = xor3(acc[tb + u][0], t0[u].x, t1[u].x);
-          acc[tb + u][1] = xor3(acc[tb + u][1], t0[u].y, t1[u].y);
-          acc[tb + u][2] = xor3(acc[tb + u][2], t0[u].z, t1[u].z);
-          acc[tb + u][3] = xor3(acc[tb + u][3], t0[u].w, t1[u].w);
+          uint32_t *a = acc[g * UG + u];
+          a[0] = xor3(a[0], t0[slot][u].x, t1[slot][u].x);
+          a[1] = xor3(a[1], t0[slot][u].y, t1[slot][u].y);
+          a[2] = xor3(a[2], t0[slot][u].z, t1[slot][u].z);
+          a[3] = xor3(a[3], t0[slot][u].w, t1[slot][u].w);
           // pin the accumulation here: XOR is associative, and without this hipcc re-associates
           // the whole phase into one late XOR tree and keeps every loaded table row live.
-          asm volatile("" : "+v"(acc[tb + u][0]), "+v"(acc[tb + u][1]), "+v"(acc[tb + u][2]),
-                       "+v"(acc[tb + u][3]));
+          asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
         }
+      };
+      if constexpr (PIPE) {
+        issue(0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) issue(g + 1, (g + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          fold(g, g & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          issue(g, 0);
+          fold(g, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -232,8 +275,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
 
 }  // namespace
 
-// Host launcher.  `rg` selects the tile height (rows = 32*rg).
-extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg) {
+// Host launcher.  rg: tile height / 32 (rows = 32*rg); ug: rows per read group; pipe: software-
+// pipelined use phase.  ug == 0 picks the tuned default for rg.
+extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs a, int rg, int ug, int pipe) {
   const int R = 32 * rg;
   a.wn        = (int32_t)words_of(a.n);
   a.tiles_m   = (a.m + R - 1) / R;
@@ -251,17 +295,18 @@ extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int r
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
-#define LEAF_CASE(RGV)                                                                             \
-  case RGV:                                                                                        \
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, false>), grid, block, 0, stream, a); \
-    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, true>), grid, block, 0, stream, a);  \
-    break;
-  switch (rg) {
-    LEAF_CASE(16)
-    LEAF_CASE(24)
-    LEAF_CASE(32)
-  default: return hipErrorInvalidValue;
+  if (ug == 0) { ug = LEAF_DEFAULT_UG(rg); pipe = LEAF_DEFAULT_PIPE(rg); }
+#define LEAF_CASE(RGV, UGV, PV)                                                                        \
+  if (rg == RGV && ug == UGV && pipe == PV) {                                                          \
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV != 0, false>), grid, block, 0, stream, a); \
+    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV != 0, true>), grid, block, 0, stream, a);  \
+    return hipGetLastError();                                                                          \
   }
+  LEAF_VARIANTS(LEAF_CASE)
 #undef LEAF_CASE
-  return hipGetLastError();
+  return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg) {
+  return gf2_launch_m4rm_leaf_variant(stream, a, rg, 0, 0);
 }

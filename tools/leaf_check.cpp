@@ -2,7 +2,7 @@
 // not a test the driver runs): checks gf2_launch_m4rm_leaf against a definitional CPU multiply on
 // ragged/batched/strided shapes, then times the bench-sized launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp \
-//         m4ri_amd/csrc/m4rm_leaf.hip -o build/leaf_check
+//         m4ri_amd/csrc/m4rm_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +11,14 @@
 #include "gf2_common.h"
 
 extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
+extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs a, int rg, int ug, int pipe);
+extern "C" hipError_t gf2_launch_m4rm_leaf_db(hipStream_t stream, LeafArgs a, int rg, int ug);
+
+// pipe: 0/1 = two-phase kernel (plain / software-pipelined use phase), 2 = double-buffered kernel
+static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
+  if (pipe == 2) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  return gf2_launch_m4rm_leaf_variant(0, a, rg, ug, pipe);
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -48,7 +56,7 @@ static void fill(std::vector<word> &M, int64_t stride, int rows, int cols, bool 
     }
 }
 
-static int check(int m, int l, int n, int batch, int ksplit, int mode, int rg, int pad) {
+static int check(int m, int l, int n, int batch, int ksplit, int mode, int rg, int pad, int ug = 0, int pipe = 0) {
   const int wa = (l + 63) / 64, wn = (n + 63) / 64;
   const int64_t as = wa + pad, bs = wn + pad, cs = wn + pad;
   const int64_t abs_ = (int64_t)m * as + 3, bbs = (int64_t)l * bs + 5, cbs = (int64_t)m * cs + 7;
@@ -80,18 +88,18 @@ static int check(int m, int l, int n, int batch, int ksplit, int mode, int rg, i
   a.a_stride = as; a.b_stride = bs; a.c_stride = cs;
   a.a_bs = abs_; a.b_bs = bbs; a.c_bs = cbs;
   a.m = m; a.l = l; a.n = n; a.batch = batch; a.ksplit = ksplit; a.mode = mode;
-  CK(gf2_launch_m4rm_leaf(0, a, rg));
+  CK(launch(a, rg, ug, pipe));
   CK(hipDeviceSynchronize());
   std::vector<word> Cg(C.size());
   CK(hipMemcpy(Cg.data(), dC, C.size() * 8, hipMemcpyDeviceToHost));
   CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   size_t bad = 0;
   for (size_t i = 0; i < Cg.size(); ++i) if (Cg[i] != Cref[i]) { if (!bad) fprintf(stderr, "  first mismatch at word %zu: got %016llx want %016llx\n", i, (unsigned long long)Cg[i], (unsigned long long)Cref[i]); ++bad; }
-  printf("check m=%d l=%d n=%d batch=%d ksplit=%d mode=%d rg=%d pad=%d : %s (%zu bad words)\n", m, l, n, batch, ksplit, mode, rg, pad, bad ? "FAIL" : "ok", bad);
+  printf("check m=%d l=%d n=%d batch=%d ksplit=%d mode=%d rg=%d ug=%d pipe=%d pad=%d : %s (%zu bad words)\n", m, l, n, batch, ksplit, mode, rg, ug, pipe, pad, bad ? "FAIL" : "ok", bad);
   return bad != 0;
 }
 
-static void timeit(int m, int l, int n, int batch, int ksplit, int rg, int reps) {
+static void timeit(int m, int l, int n, int batch, int ksplit, int rg, int reps, int ug = 0, int pipe = 0) {
   const int wa = (l + 63) / 64, wn = (n + 63) / 64;
   const size_t asz = (size_t)m * wa * batch, bsz = (size_t)l * wn * batch, csz = (size_t)m * wn * batch;
   word *dA, *dB, *dC;
@@ -108,18 +116,18 @@ static void timeit(int m, int l, int n, int batch, int ksplit, int rg, int reps)
   a.a_bs = (int64_t)m * wa; a.b_bs = (int64_t)l * wn; a.c_bs = (int64_t)m * wn;
   a.m = m; a.l = l; a.n = n; a.batch = batch; a.ksplit = ksplit; a.mode = ksplit > 1 ? 1 : 0;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  CK(gf2_launch_m4rm_leaf(0, a, rg)); CK(hipDeviceSynchronize());
+  CK(launch(a, rg, ug, pipe)); CK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0;
   for (int r = 0; r < reps; ++r) {
     CK(hipEventRecord(e0, 0));
-    CK(gf2_launch_m4rm_leaf(0, a, rg));
+    CK(launch(a, rg, ug, pipe));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms; sum += ms;
   }
   const double ops = (double)m * l * n * batch;
-  printf("time m=%d l=%d n=%d batch=%d ksplit=%d rg=%d : best %.3f ms avg %.3f ms  -> %.3e bit-MAC/s (best)\n",
-         m, l, n, batch, ksplit, rg, best, sum / reps, ops / (best * 1e-3));
+  printf("time m=%d l=%d n=%d batch=%d ksplit=%d rg=%d ug=%d pipe=%d : best %.3f ms avg %.3f ms  -> %.3e bit-MAC/s (best)\n",
+         m, l, n, batch, ksplit, rg, ug, pipe, best, sum / reps, ops / (best * 1e-3));
   CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
 }
 
@@ -127,6 +135,7 @@ int main(int argc, char **argv) {
   sm_state = 12345;
   int fails = 0;
   const int rgs[3] = {32, 24, 16};
+  if (!(argc > 1 && !strcmp(argv[1], "--one")))
   for (int rg : rgs) {
     fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0);
     fails += check(1000, 777, 1234, 1, 1, 0, rg, 1);
@@ -138,6 +147,22 @@ int main(int argc, char **argv) {
     fails += check(193, 65, 65, 1, 2, 1, rg, 0);
   }
   if (argc > 1 && !strcmp(argv[1], "--check-only")) return fails != 0;
+  if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch : profile a single variant
+    timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), 3, atoi(argv[3]), atoi(argv[4]));
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--variants")) {
+    const int v[][3] = {{32, 2, 0}, {32, 2, 1}, {32, 4, 0}, {24, 4, 0}, {24, 4, 1}, {16, 4, 0}, {16, 8, 0}, {24, 8, 2}};
+    for (auto &x : v) {
+      fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
+      fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
+      fails += check(193, 65, 65, 1, 1, 0, x[0], 0, x[1], x[2]);
+      fails += check(1024, 1024, 2048, 1, 1, 0, x[0], 0, x[1], x[2]);
+      timeit(8192, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
+    }
+    printf("%s\n", fails ? "LEAF_CHECK FAILED" : "LEAF_CHECK ALL OK");
+    return fails != 0;
+  }
   for (int rg : rgs) {
     timeit(8192, 8192, 8192, 8, 1, rg, 5);
     timeit(16384, 16384, 16384, 1, 1, rg, 5);
