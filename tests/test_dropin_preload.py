@@ -1,0 +1,31 @@
+"""Drop-in check: an ordinary M4RI client binary (tests/dropin_driver.c, linked against the reference
+build) run with LD_PRELOAD=libm4ri_amd.so -- its mzd_mul / mzd_addmul / *_m4rm calls land on the GPU,
+everything else (mzd_init, mzd_randomize, mzd_mul_naive, mzd_equal, mzd_free) stays the reference's.
+The binary is built in the build container by oracle/Makefile and travels under oracle/_ref/."""
+import os
+import subprocess
+
+import pytest
+
+import m4ri_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+
+
+def test_driver_alone_is_a_valid_reference_self_test():
+    if not os.path.exists(DRIVER):
+        pytest.skip("oracle/_ref/dropin_driver not built (needs /root/reference)")
+    r = subprocess.run([DRIVER], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "interposed: no" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_ld_preload_drop_in():
+    if not os.path.exists(DRIVER):
+        pytest.skip("oracle/_ref/dropin_driver not built (needs /root/reference)")
+    env = dict(os.environ, LD_PRELOAD=m4ri_amd.LIB_PATH)
+    r = subprocess.run([DRIVER], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "interposed: yes" in r.stdout and "ALL OK" in r.stdout and "FAILED" not in r.stdout
+    assert "leaf launch" in r.stdout

@@ -1,0 +1,106 @@
+"""The N > 1 path on CPU: m4ri_amd/sharding.py under torch.distributed with the gloo backend, two
+processes.  The block products are done by the CPU oracle here (tests may use it as the checker's
+stand-in for the device multiply); the partitioning, the pairwise XOR exchange and the ownership of the
+reduced rows are exactly the code bench.py runs under RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from m4ri_amd import sharding  # noqa: E402
+from m4ri_amd.mzd import Mzd  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, grid, m, l, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_libs
+    orc = cpu_libs.oracle()
+    A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)  # every rank regenerates the operands, as bench.py does
+    plan = sharding.make_plan(world, rank, m, l, n, grid=grid)
+    state = {}
+
+    def multiply(r0, r1, k0, k1, c0, c1):
+        a = A.window(r0, k0, r1, k1).copy()
+        b = B.window(k0, c0, k1, c1).copy()
+        P = orc.mul(None, a, b, 0)
+        state["P"] = torch.from_numpy(P.rows().view(np.int64).copy())  # (rows x stride) words
+
+    def send_recv(partner, send_rows, recv_rows):
+        P = state["P"]
+        recv = torch.empty((recv_rows[1] - recv_rows[0], P.shape[1]), dtype=torch.int64)
+        ops = [dist.P2POp(dist.isend, P[send_rows[0]:send_rows[1]].contiguous(), partner),
+               dist.P2POp(dist.irecv, recv, partner)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return recv
+
+    def xor_rows(rows, got):
+        state["P"][rows[0]:rows[1]] ^= got
+
+    r0, r1, c0, c1 = sharding.run_sharded(plan, multiply, xor_rows, send_recv)
+    b0, _ = plan.row_range()
+    owned = state["P"][r0 - b0:r1 - b0].numpy().view(np.uint64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), region=np.array([r0, r1, c0, c1]), words=owned)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,m,l,n", [((2, 1, 1), 300, 200, 260),      # rows of C, no exchange
+                                        ((1, 2, 1), 130, 257, 512),      # columns of C
+                                        ((1, 1, 2), 200, 512, 200),      # inner dimension split + pairwise XOR exchange
+                                        ((1, 1, 2), 77, 129, 65)])       # ragged: last slices take the remainders
+def test_two_rank_sharded_product_matches_oracle(tmp_path, oracle, grid, m, l, n):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, grid, m, l, n, str(tmp_path)), nprocs=world, join=True)
+    want = oracle.mul(None, Mzd.random(m, l, 3), Mzd.random(l, n, 4), 0)
+    covered = np.zeros((m, want.width), dtype=bool)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        r0, r1, c0, c1 = (int(x) for x in z["region"])
+        w0, w1 = c0 // 64, (c1 + 63) // 64
+        got = z["words"][:, : w1 - w0]
+        exp = want.masked()[r0:r1, w0:w1]
+        assert np.array_equal(got, exp), (grid, r, (r0, r1, c0, c1))
+        covered[r0:r1, w0:w1] = True
+    assert covered.all(), "the ranks' reduced regions must tile C exactly"
+
+
+def test_plans_tile_the_product():
+    """Every default grid covers C exactly once and splits the inner dimension without gaps."""
+    for world in (1, 2, 4, 8):
+        m = l = n = 65536
+        seen = {}
+        for rank in range(world):
+            p = sharding.make_plan(world, rank, m, l, n)
+            r0, r1 = p.row_range(); c0, c1 = p.col_range(); k0, k1 = p.inner_range()
+            assert c0 % 64 == 0 and k0 % 64 == 0
+            seen.setdefault((r0, r1, c0, c1), []).append((k0, k1))
+            o0, o1 = p.owned_rows_after_reduce()
+            assert r0 <= o0 < o1 <= r1
+        area = 0
+        for (r0, r1, c0, c1), ks in seen.items():
+            area += (r1 - r0) * (c1 - c0)
+            ks.sort()
+            assert ks[0][0] == 0 and ks[-1][1] == l and all(a[1] == b[0] for a, b in zip(ks, ks[1:]))
+        assert area == m * n
+    assert sharding.default_grid(8) == (2, 2, 2) and sharding.default_grid(4) == (2, 2, 1)
