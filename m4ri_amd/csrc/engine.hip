@@ -25,6 +25,8 @@
 
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
+hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
+int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
                                     int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word *prod, word *parent, int64_t o_stride,
@@ -52,6 +54,8 @@ struct Engine {
   word *ws              = nullptr;  // grow-only workspace
   size_t ws_cap         = 0;
   size_t ws_used        = 0;
+  word *a7              = nullptr;  // packed-A scratch of the current call (inside ws)
+  size_t a7_words       = 0;
   bool profiling        = false;
   m4ri_amd_stats stats  = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
@@ -150,7 +154,15 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
+  // 1024-row tiles run the double-buffered 7-bit kernel (it packs A into the call's scratch first);
+  // shorter tiles (small or ragged m) stay on the two-phase kernel, which has 768/512-row variants
+  const size_t a7_need = (size_t)gf2_m4rm7_a7_words(m, l, batch);
+  if (rg == 32 && e->a7 != nullptr && a7_need <= e->a7_words) {
+    HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
+    e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)a7_need;
+  } else {
+    HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
+  }
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
     e->pending.emplace_back(e0, e1);
@@ -160,6 +172,14 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   e->stats.leaf_products += batch;
   e->stats.leaf_m = (int32_t)m; e->stats.leaf_l = (int32_t)l; e->stats.leaf_n = (int32_t)n;
   e->stats.leaf_bytes += 8.0 * (double)batch * ((double)m * words_of(l) + (double)l * wn + (double)m * wn * (add ? 2 : 1));
+  return 0;
+}
+
+int reserve_a7(Engine *e, size_t words) {
+  words = (words + 31) & ~(size_t)31;
+  if (int rc = ws_reserve(e, words)) return rc;
+  e->a7 = ws_take(e, words);
+  e->a7_words = words;
   return 0;
 }
 
@@ -185,7 +205,7 @@ int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 
 // breadth-first Strassen-Winograd on the even block: C (m x n) (+)= A (m x l) * B (l x n), with
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
-int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) {
+int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
   // workspace plan
   size_t need = 0;
@@ -194,7 +214,14 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     need += pad((size_t)cnt * md * wl) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
-  if (int rc = ws_reserve(e, need)) return rc;
+  {
+    const size_t a7_bfs = (size_t)gf2_m4rm7_a7_words(m >> L, l >> L, ipow7(L));
+    if (a7_bfs > a7_extra) a7_extra = a7_bfs;
+  }
+  a7_extra = pad(a7_extra);
+  if (int rc = ws_reserve(e, need + a7_extra)) return rc;
+  e->a7 = ws_take(e, a7_extra);
+  e->a7_words = a7_extra;
   std::vector<word *> Al(L + 1), Bl(L + 1), Pl(L + 1);
   for (int d = 1; d <= L; ++d) {
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
@@ -240,9 +267,21 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
   if (m == 0 || n == 0) return 0;
   int L = plan_levels(m, l, n, cutoff);
   e->stats.levels = L;
-  if (L == 0) return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
+  if (L == 0) {
+    if (int rc = reserve_a7(e, (size_t)gf2_m4rm7_a7_words(m, l, 1))) return rc;
+    return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
+  }
   const int64_t me = m - m % (1ll << L), le = l - l % (64ll << L), ne = n - n % (64ll << L);
-  if (int rc = bfs_product(e, st, dview(C, 0, 0, me, ne), dview(A, 0, 0, me, le), dview(B, 0, 0, le, ne), add, L)) return rc;
+  // packed-A scratch big enough for the batched leaves and for every remainder strip
+  size_t a7_strips = 0;
+  {
+    const size_t s1 = n > ne ? (size_t)gf2_m4rm7_a7_words(m, l, 1) : 0;
+    const size_t s2 = m > me ? (size_t)gf2_m4rm7_a7_words(m - me, l, 1) : 0;
+    const size_t s3 = l > le ? (size_t)gf2_m4rm7_a7_words(me, l - le, 1) : 0;
+    a7_strips = s1 > s2 ? s1 : s2;
+    if (s3 > a7_strips) a7_strips = s3;
+  }
+  if (int rc = bfs_product(e, st, dview(C, 0, 0, me, ne), dview(A, 0, 0, me, le), dview(B, 0, 0, le, ne), add, L, a7_strips)) return rc;
   // remainder strips (strassen.c:170-204): right columns, bottom rows, trailing inner slab
   if (n > ne)
     if (int rc = launch_leaf(e, st, C.p + ne / 64, C.stride, 0, A.p, A.stride, 0, B.p + ne / 64, B.stride, 0, m, l, n - ne, 1, add, 0)) return rc;
@@ -297,6 +336,7 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
   Engine *e = engine_for_current_device();
   if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
+  if (int rc = reserve_a7(e, (size_t)gf2_m4rm7_a7_words(m, l, 1))) return rc;
   return launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit);
 }
 

@@ -28,7 +28,7 @@
 // (rg, ug, pipe) instantiations.  Product defaults first; the others exist for tools/leaf_check.
 #ifndef LEAF_VARIANTS
 #define LEAF_VARIANTS(X) \
-  X(32, 2, 0) X(24, 4, 0) X(16, 4, 0) X(32, 2, 1) X(32, 4, 0) X(32, 4, 1) X(24, 4, 1) X(24, 2, 1) X(16, 4, 1) X(16, 8, 0) X(16, 8, 1)
+  X(32, 4, 0) X(24, 4, 0) X(16, 4, 0) X(32, 2, 0) X(32, 2, 2) X(32, 4, 2) X(32, 4, 3) X(32, 8, 2) X(40, 2, 2) X(40, 4, 2) X(40, 4, 3) X(24, 4, 2) X(16, 4, 2)
 #endif
 #define LEAF_DEFAULT_UG(rg) 4
 #define LEAF_DEFAULT_PIPE(rg) 0
@@ -58,9 +58,12 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int z) {
   return 0x0c000000u | ((z ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
-template <int RG, int UG, bool PIPE, bool XOR_OUT>
+template <int RG, int UG, int VAR, bool XOR_OUT>
 __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LEAF_NT * 65536];
+  constexpr bool PIPE    = (VAR & 1) != 0;  // software-pipelined use phase
+  constexpr bool STAGE_B = (VAR & 2) != 0;  // B rows staged once per workgroup through LDS
+  constexpr int STG_OFF  = LEAF_NT * 65536; // staging area behind the tables: 2 buffers x 4 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LEAF_NT * 65536 + (STAGE_B ? 2 * 4096 : 0)];
   constexpr int R = 32 * RG;  // tile rows: 32 row groups (8 waves x 4) x RG rows
 
   const int tid  = threadIdx.x;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
   // stored).
   uint4 brow[8];
   const uint32_t b_lane = (uint32_t)bz * 8u * b_rs + (uint32_t)w0 * 8u;
-  auto load_b = [&](int s) {
+  auto load_b = [&](int s) {  // direct variant: every thread fetches its 8 rows itself (16x redundant)
     // one running offset VGPR (the empty asm keeps hipcc from materialising 8 hoisted offsets)
     uint32_t off = b_lane + (uint32_t)s * LEAF_STAGE * b_rs;
 #pragma unroll
@@ -127,6 +130,24 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
       off += b_rs;
       asm volatile("" : "+v"(off));
     }
+  };
+  // staged variant: the 16 rows x 256 B of a stage are fetched ONCE per workgroup -- 8 bytes per
+  // thread, row tid>>5, word tid&31 -- parked in a 2-deep LDS ring one stage ahead, and every
+  // thread picks its 8 rows up from there at build time.  Costs 64 extra ds_read_b128 per stage
+  // (+8 % LDS work) and buys back 1024 clk/stage of texture-addresser time, ~270 clk of VMEM issue
+  // per wave in the build phase, and 28 VGPRs during the use phase.
+  uint2 bpiece = make_uint2(0u, 0u);
+  const uint32_t s_lane = (uint32_t)(tid >> 5) * b_rs + (uint32_t)(tile_n * LEAF_TW + (tid & 31)) * 8u;
+  unsigned char *const stg_wr = lds + STG_OFF + (tid >> 5) * 256 + (tid & 31) * 8;
+  const unsigned char *const stg_rd = lds + STG_OFF + bz * 8 * 256 + c * 16;
+  auto fetch_piece = [&](int s) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(b_rsrc, (int)(s_lane + (uint32_t)s * LEAF_STAGE * b_rs), 0, 0);
+    bpiece = __builtin_bit_cast(uint2, v);
+  };
+  auto park_piece = [&](int s) { *reinterpret_cast<uint2 *>(stg_wr + (s & 1) * 4096) = bpiece; };
+  auto pick_rows = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) brow[j] = *reinterpret_cast<const uint4 *>(stg_rd + (s & 1) * 4096 + j * 256);
   };
 
   uint32_t areg[RG];
@@ -141,7 +162,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
     }
   };
 
-  if (s_begin < s_end) load_b(s_begin);
+  if constexpr (STAGE_B) {
+    fetch_piece(s_begin);
+    park_piece(s_begin);
+    fetch_piece(s_begin + 1);
+    __syncthreads();
+  } else {
+    if (s_begin < s_end) load_b(s_begin);
+  }
 
   for (int q = s_begin >> 1; 2 * q < s_end; ++q) {
     load_a(q);
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
         // the B rows become visible to the optimiser only HERE (volatile asm stays behind the
         // preceding barrier): otherwise hipcc hoists this build's first XORs up to where the rows
         // were requested, one use phase earlier, and waits out the whole load latency there.
+        if constexpr (STAGE_B) pick_rows(s);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           asm volatile("" : "+v"(brow[j].x), "+v"(brow[j].y), "+v"(brow[j].z), "+v"(brow[j].w));
@@ -188,10 +217,18 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
       // check): a branch makes hipcc resolve the merge with v_movs of the loaded registers, i.e.
       // an immediate vmcnt(0).  The sched_barriers keep the next build's XORs from being hoisted up
       // to the loads.
-      load_b(s + 1);
+      if constexpr (!STAGE_B) load_b(s + 1);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (STAGE_B) {
+        // rows of stage s+1 (requested one stage ago) go into the ring slot the build of stage
+        // s-1 has finished with; then request stage s+2.  One ds_write_b64 + one buffer_load per
+        // thread, overlapping the gathers below.
+        park_piece(s + 1);
+        fetch_piece(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---------------- use: RG rows x 2 lookups ------------------------------------------
       // Rows go through in groups of UG: 2*UG ds_read_b128 per group.  PIPE issues group g+1's
       // reads before folding group g into the accumulators (two register sets), so the LDS queue
@@ -298,8 +335,8 @@ extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs 
   if (ug == 0) { ug = LEAF_DEFAULT_UG(rg); pipe = LEAF_DEFAULT_PIPE(rg); }
 #define LEAF_CASE(RGV, UGV, PV)                                                                        \
   if (rg == RGV && ug == UGV && pipe == PV) {                                                          \
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV != 0, false>), grid, block, 0, stream, a); \
-    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV != 0, true>), grid, block, 0, stream, a);  \
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV, false>), grid, block, 0, stream, a); \
+    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV, true>), grid, block, 0, stream, a);  \
     return hipGetLastError();                                                                          \
   }
   LEAF_VARIANTS(LEAF_CASE)

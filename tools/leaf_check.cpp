@@ -2,7 +2,7 @@
 // not a test the driver runs): checks gf2_launch_m4rm_leaf against a definitional CPU multiply on
 // ragged/batched/strided shapes, then times the bench-sized launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp \
-//         m4ri_amd/csrc/m4rm_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
+//         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/m4rm7_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,14 +13,23 @@
 extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs a, int rg, int ug, int pipe);
 extern "C" hipError_t gf2_launch_m4rm_leaf_db(hipStream_t stream, LeafArgs a, int rg, int ug);
+extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
+extern "C" int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
+static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
-// pipe: 0/1 = two-phase kernel (plain / software-pipelined use phase), 2 = double-buffered kernel
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+// pipe: variant bits of the two-phase kernel (1 = software-pipelined use phase, 2 = B rows staged
+// through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
-  if (pipe == 2) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 7 || pipe == 8) {  // 7-bit double-buffered kernel (packs A first); 8 = software-pipelined
+    const int64_t need = gf2_m4rm7_a7_words(a.m, a.l, a.batch);
+    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    return gf2_launch_m4rm7(0, a, g_a7, rg, ug, pipe == 8);
+  }
   return gf2_launch_m4rm_leaf_variant(0, a, rg, ug, pipe);
 }
 
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 static uint64_t sm_state;
 static uint64_t splitmix() {
@@ -152,13 +161,14 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 2, 0}, {32, 2, 1}, {32, 4, 0}, {24, 4, 0}, {24, 4, 1}, {16, 4, 0}, {16, 8, 0}, {24, 8, 2}};
+    const int v[][3] = {{32, 4, 0}, {32, 4, 7}, {40, 4, 7}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
       fails += check(193, 65, 65, 1, 1, 0, x[0], 0, x[1], x[2]);
       fails += check(1024, 1024, 2048, 1, 1, 0, x[0], 0, x[1], x[2]);
       timeit(8192, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
+      if (x[0] == 40) timeit(10240, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
     }
     printf("%s\n", fails ? "LEAF_CHECK FAILED" : "LEAF_CHECK ALL OK");
     return fails != 0;

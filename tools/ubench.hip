@@ -129,6 +129,103 @@ __global__ __launch_bounds__(512) void lds_read2_kernel(uint32_t *out, uint64_t 
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// ---- use-phase replica of the 7-bit kernel: per group 2*UG perm + 2*UG ds_read_b128 + (WR: 4 xor +
+// one ds_write_b128) + 4*UG bitop3; barrier every 8 groups.  PIPE: next group's reads issued before the fold.
+template <int UG, bool WR, bool PIPE, bool BAR>
+__global__ __launch_bounds__(512) void group_replica_kernel(uint32_t *out, uint64_t *cyc, uint32_t seed) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[131072];
+  for (int i = threadIdx.x; i < 131072 / 4; i += 512) reinterpret_cast<uint32_t *>(lds)[i] = i * seed;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t col = (lane & 15) * 16, coloff = col | 0x0100u;
+  uint32_t areg[8 * UG];
+  uint32_t idx = (threadIdx.x >> 4) * 2654435761u + seed;
+#pragma unroll
+  for (int t = 0; t < 8 * UG; ++t) { idx = idx * 1664525u + 1013904223u; areg[t] = idx; }
+  uint32_t acc[8 * UG][4];
+#pragma unroll
+  for (int t = 0; t < 8 * UG; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0;
+  uint32_t cur[4] = {seed, seed * 3, seed * 5, seed * 7};
+  unsigned char *wr = lds + (threadIdx.x >> 4) * 2048 + col;
+  const uint64_t t0 = now();
+  for (int it = 0; it < ITERS / 8; ++it) {
+    uint4 t0v[PIPE ? 2 : 1][UG], t1v[PIPE ? 2 : 1][UG];
+    auto issue = [&](int g, int slot) {
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const uint32_t a0 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, 0x0c0c0400u);
+        const uint32_t a1 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, 0x0c0c0500u);
+        t0v[slot][u] = *reinterpret_cast<const uint4 *>(lds + a0);
+        t1v[slot][u] = *reinterpret_cast<const uint4 *>(lds + a1);
+      }
+    };
+    auto fold = [&](int g, int slot) {
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        uint32_t *a = acc[g * UG + u];
+        a[0] = __builtin_amdgcn_bitop3_b32(a[0], t0v[slot][u].x, t1v[slot][u].x, 0x96);
+        a[1] = __builtin_amdgcn_bitop3_b32(a[1], t0v[slot][u].y, t1v[slot][u].y, 0x96);
+        a[2] = __builtin_amdgcn_bitop3_b32(a[2], t0v[slot][u].z, t1v[slot][u].z, 0x96);
+        a[3] = __builtin_amdgcn_bitop3_b32(a[3], t0v[slot][u].w, t1v[slot][u].w, 0x96);
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+      }
+    };
+    if (PIPE) { issue(0, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (PIPE) { if (g + 1 < 8) issue(g + 1, (g + 1) & 1); } else issue(g, 0);
+      if (WR) {
+        cur[0] ^= areg[g]; cur[1] ^= areg[g]; cur[2] ^= areg[g]; cur[3] ^= areg[g];
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+        *reinterpret_cast<uint4 *>(wr + 65536 + (g ^ (g >> 1)) * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fold(g, PIPE ? (g & 1) : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (BAR) __syncthreads();
+  }
+  const uint64_t t1 = now();
+  uint32_t x = cur[0];
+#pragma unroll
+  for (int t = 0; t < 8 * UG; ++t) x ^= acc[t][0] ^ acc[t][1] ^ acc[t][2] ^ acc[t][3];
+  __syncthreads();
+  out[blockIdx.x * 512 + threadIdx.x] = x ^ reinterpret_cast<uint32_t *>(lds)[threadIdx.x + 20000];
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// ---- table-build replica: per iteration every thread does the leaf's Gray chain (16 x {4 dependent
+// XORs + ds_write_b128 at Gray-ordered rows}) followed by a workgroup barrier
+template <int MODE>  // 0: chain + writes + barrier, 1: same without the barrier, 2: writes of constant data (no chain)
+__global__ __launch_bounds__(512) void build_replica_kernel(uint32_t *out, uint64_t *cyc, uint32_t seed) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[131072];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  uint32_t r[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j][0] = seed * (j + 3) + threadIdx.x; r[j][1] = r[j][0] * 3; r[j][2] = r[j][0] * 5; r[j][3] = r[j][0] * 7; }
+  uint32_t cur[4] = {seed, seed + 1, seed + 2, seed + 3};
+  unsigned char *base = lds + g * 4096 + c * 16;
+  __syncthreads();
+  const uint64_t t0 = now();
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MODE != 2 && i > 0) {
+        const int j = __builtin_ctz(i);
+        cur[0] ^= r[j][0]; cur[1] ^= r[j][1]; cur[2] ^= r[j][2]; cur[3] ^= r[j][3];
+      }
+      asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+      const int gc = i ^ (i >> 1);
+      *reinterpret_cast<uint4 *>(base + gc * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+    }
+    if (MODE != 1) __syncthreads();
+  }
+  const uint64_t t1 = now();
+  __syncthreads();
+  out[blockIdx.x * 512 + threadIdx.x] = reinterpret_cast<uint32_t *>(lds)[threadIdx.x] ^ cur[0];
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 // ---- LDS writes: NF ds_write per iteration, rows as in the table build ---------------------------
 template <int WIDTH>
 __global__ __launch_bounds__(512) void lds_write_kernel(uint32_t *out, uint64_t *cyc, uint32_t seed) {
@@ -238,6 +335,18 @@ int main(int argc, char **argv) {
   run("clean ds_read_b128 x16 + bitop3 pairs", [&] { hipLaunchKernelGGL((lds_read2_kernel<16, 1>), g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
   run("clean ds_read_b128 x4  + perm + 4 xor", [&] { hipLaunchKernelGGL((lds_read2_kernel<4, 2>), g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 4 * 1024, "bytes", dout, dcyc);
   run("clean ds_read_b128 x8  + perm + 4 xor", [&] { hipLaunchKernelGGL((lds_read2_kernel<8, 2>), g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 8 * 1024, "bytes", dout, dcyc);
+  // bytes read per block-iteration (ITERS/8 outer trips x 8 groups): 8 waves x 2*UG reads x 1 KiB per group
+#define GR(UGV, WRV, PV, BV, label) run(label, [&] { hipLaunchKernelGGL((group_replica_kernel<UGV, WRV, PV, BV>), g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 2 * UGV * 1024, "read-bytes", dout, dcyc)
+  GR(4, false, false, false, "group replica UG4 reads only");
+  GR(4, true, false, false, "group replica UG4 +write");
+  GR(4, true, false, true, "group replica UG4 +write +barrier/8");
+  GR(2, true, false, true, "group replica UG2 +write +barrier/8");
+  GR(2, true, true, true, "group replica UG2 +write +barrier PIPE");
+  GR(4, true, true, true, "group replica UG4 +write +barrier PIPE");
+  GR(4, false, true, false, "group replica UG4 reads only PIPE");
+  run("build replica: chain+write+barrier", [&] { hipLaunchKernelGGL(build_replica_kernel<0>, g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
+  run("build replica: chain+write, no barrier", [&] { hipLaunchKernelGGL(build_replica_kernel<1>, g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
+  run("build replica: const data + barrier", [&] { hipLaunchKernelGGL(build_replica_kernel<2>, g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
   run("ds_write_b128 (16 per wave per iter)", [&] { hipLaunchKernelGGL(lds_write_kernel<16>, g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
   run("ds_write_b64 x2 (16 pairs per wave per iter)", [&] { hipLaunchKernelGGL(lds_write_kernel<8>, g, b, 0, 0, dout, dcyc, 7u); }, 8.0 * 16 * 1024, "bytes", dout, dcyc);
   // register-table lookups: 8 lookups x 4 v_xor per loop trip per wave
