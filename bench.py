@@ -9,7 +9,7 @@ operands: Strassen-Winograd levels over batched M4RM leaves, everything through 
 C ABI.  Inputs are in HBM before the timed region starts; C stays in HBM (distributed over the ranks
 that own its blocks when N > 1).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 65536] [--workload mul|leaf16384]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 65536] [--workload mul|leaf16384]
 
 For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL); the product is
 decomposed by m4ri_amd/sharding.py (block products, one pairwise XOR exchange at N = 8).
@@ -89,10 +89,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--size", type=int, default=65536, help="n of the n x n x n product")
     ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384"])
     ap.add_argument("--cutoff", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: development aid -- several ranks may share one GPU, P2P is staged through the host")
+    ap.add_argument("--check", action="store_true",
+                    help="after timing, every rank recomputes the full product on its own GPU and compares its owned block")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,8 +109,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -116,7 +123,7 @@ def main():
     if args.workload == "leaf16384":
         n = 16384
     else:
-        n = args.n
+        n = args.size
     w = n // 64
     assert n % 64 == 0
 
@@ -144,6 +151,14 @@ def main():
             m4ri_amd.mul_dev(P.data_ptr(), pw, a_ptr, w, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, args.cutoff, stream)
 
     def send_recv(partner, send_rows, recv_rows):
+        if args.backend == "gloo":  # host-staged (development only)
+            out = P[send_rows[0]:send_rows[1]].cpu()
+            inp = torch.empty(recv_buf.shape, dtype=torch.int64)
+            reqs = [dist.isend(out, partner), dist.irecv(inp, partner)]
+            for r in reqs:
+                r.wait()
+            recv_buf.copy_(inp)
+            return recv_buf
         ops = [dist.P2POp(dist.isend, P[send_rows[0]:send_rows[1]], partner),
                dist.P2POp(dist.irecv, recv_buf, partner)]
         for req in dist.batch_isend_irecv(ops):
@@ -182,6 +197,25 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     ops = float(n) ** 3  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
     value = ops * args.steps / elapsed
+
+    if args.check:
+        # recompute the whole product on this rank's GPU and compare the region this rank owns
+        region = sharding.run_sharded(plan, multiply, xor_rows, send_recv)
+        torch.cuda.synchronize()
+        full = torch.empty((n, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.mul_dev(full.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, False, 0, stream)
+        torch.cuda.synchronize()
+        rr0, rr1, cc0, cc1 = region
+        mine = P[rr0 - r0:rr1 - r0, :]
+        ok = bool(torch.equal(mine, full[rr0:rr1, cc0 // 64:cc1 // 64]))
+        print(f"[check] rank {rank} grid {plan.grid} owns rows {rr0}:{rr1} cols {cc0}:{cc1} -> {'OK' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            raise SystemExit(3)
+        m4ri_amd.set_profiling(True)
+        step()
+        torch.cuda.synchronize()
+        stats = m4ri_amd.get_stats()
+        m4ri_amd.set_profiling(False)
 
     if rank == 0:
         leaf_launch_ms = stats.leaf_ms / max(1, stats.leaf_launches)
