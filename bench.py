@@ -84,6 +84,18 @@ def cpu_baseline(n_workload: int):
     return out
 
 
+def leaf_traffic(n, world):
+    """HBM bytes of one leaf launch from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE, MI355X_MICROARCH.md HBM section) -- counters cannot be read from inside
+    this process, so the number is the one tools/prof_bench.sh measured for this exact command
+    (profiles/leaf_traffic.json); null for any other configuration."""
+    p = os.path.join(ROOT, "profiles", "leaf_traffic.json")
+    if world != 1 or not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    return d.get("bytes_per_launch") if d.get("n") == n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,12 +262,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "m4rm_leaf_kernel (one batched launch per step)",
+                "kernel": "m4rm7_kernel (the M4RM leaf; one batched launch per step, HIP events around that launch alone)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": leaf_traffic(n, world),
                 "launch_ms": leaf_launch_ms,
                 "launches_per_step": int(stats.leaf_launches),
                 "algorithmic_bytes_per_launch": leaf_launch_bytes,

@@ -26,6 +26,7 @@
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
+hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
                                     int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
@@ -149,20 +150,23 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   a.m = (int32_t)m; a.l = (int32_t)l; a.n = (int32_t)n;
   a.batch = (int32_t)batch; a.ksplit = ksplit;
   a.mode  = (add || ksplit > 1) ? 1 : 0;
+  // 1024-row tiles run the double-buffered 7-bit kernel, which consumes A in a packed form (one
+  // streaming pass into the call's scratch first); shorter tiles (small or ragged m) stay on the
+  // two-phase kernel, which has 768/512-row variants
+  const size_t a7_need = (size_t)gf2_m4rm7_a7_words(m, l, batch);
+  const bool use_k7    = rg == 32 && e->a7 != nullptr && a7_need <= e->a7_words &&
+                      (uint64_t)a7_need * 8 / (uint64_t)batch < (1ull << 32);  // 32-bit offsets inside one packed operand
+  if (use_k7) {
+    HIPTRY(gf2_launch_a7_pack(st, a, e->a7));
+    e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)a7_need;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (e->profiling) {
+  if (e->profiling) {  // the events bracket the leaf kernel alone
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  // 1024-row tiles run the double-buffered 7-bit kernel (it packs A into the call's scratch first);
-  // shorter tiles (small or ragged m) stay on the two-phase kernel, which has 768/512-row variants
-  const size_t a7_need = (size_t)gf2_m4rm7_a7_words(m, l, batch);
-  if (rg == 32 && e->a7 != nullptr && a7_need <= e->a7_words) {
-    HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
-    e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)a7_need;
-  } else {
-    HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
-  }
+  if (use_k7) HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
+  else HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
     e->pending.emplace_back(e0, e1);

@@ -329,27 +329,38 @@ extern "C" int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch) {
   return (batch * ((m + 3) & ~(int64_t)3) * nq + 1) / 2;
 }
 
-// Host launcher: packs A into `a7_ws` (gf2_m4rm7_a7_words words) and runs the leaf.  rg: tile
-// height / 32 (rows = 32*rg).
-extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe) {
+// Host launchers.  gf2_launch_a7_pack fills `a7_ws` (gf2_m4rm7_a7_words words) with the packed copy of
+// A; gf2_launch_m4rm7 runs the leaf on it.  rg: tile height / 32 (rows = 32*rg).
+static bool k7_geometry(LeafArgs &a, word *a7_ws, int rg, int64_t &nq, int64_t &m_pad) {
   const int R = 32 * rg;
   a.wn        = (int32_t)words_of(a.n);
   a.tiles_m   = (a.m + R - 1) / R;
   a.tiles_n   = (a.wn + LEAF_TW - 1) / LEAF_TW;
-  if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return hipSuccess;
-  const int64_t nq = (a.l + K7_CHUNK - 1) / K7_CHUNK;
+  if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return false;
+  nq          = (a.l + K7_CHUNK - 1) / K7_CHUNK;
+  m_pad       = ((int64_t)a.m + 3) & ~(int64_t)3;
   a.A7        = reinterpret_cast<const uint32_t *>(a7_ws);
-  const int64_t m_pad = ((int64_t)a.m + 3) & ~(int64_t)3;
   a.a7_stride = m_pad;
   a.a7_bs     = m_pad * nq;
+  return true;
+}
+
+extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws) {
+  int64_t nq, m_pad;
+  if (!k7_geometry(a, a7_ws, 32, nq, m_pad)) return hipSuccess;
   if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
-  {
-    const int64_t row_tiles = (m_pad + PK_ROWS - 1) / PK_ROWS, chunk_tiles = (nq + PK_CHUNKS - 1) / PK_CHUNKS;
-    const int64_t g = row_tiles * chunk_tiles * a.batch;
-    if (g > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(a7_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, a.A, a.a_stride, a.a_bs,
-                       reinterpret_cast<uint32_t *>(a7_ws), m_pad, a.a7_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles);
-  }
+  const int64_t row_tiles = (m_pad + PK_ROWS - 1) / PK_ROWS, chunk_tiles = (nq + PK_CHUNKS - 1) / PK_CHUNKS;
+  const int64_t g = row_tiles * chunk_tiles * a.batch;
+  if (g > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(a7_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, a.A, a.a_stride, a.a_bs,
+                     reinterpret_cast<uint32_t *>(a7_ws), m_pad, a.a7_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe) {
+  int64_t nq, m_pad;
+  if (!k7_geometry(a, a7_ws, rg, nq, m_pad)) return hipSuccess;
+  if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
   if (a.ksplit < 1) a.ksplit = 1;
   int cps = (int)((nq + a.ksplit - 1) / a.ksplit);
   if (cps < 1) cps = 1;
@@ -365,7 +376,7 @@ extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_
     else             hipLaunchKernelGGL((m4rm7_kernel<RGV, UGV, PV != 0, true>), grid, block, 0, stream, a);  \
     return hipGetLastError();                                                                        \
   }
-  K7_CASE(32, 4, 0) K7_CASE(40, 4, 0)
+  K7_CASE(32, 4, 0)
 #undef K7_CASE
   return hipErrorInvalidValue;
 }

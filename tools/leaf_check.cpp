@@ -15,6 +15,7 @@ extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs 
 extern "C" hipError_t gf2_launch_m4rm_leaf_db(hipStream_t stream, LeafArgs a, int rg, int ug);
 extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
+extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -25,6 +26,7 @@ static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 7 || pipe == 8) {  // 7-bit double-buffered kernel (packs A first); 8 = software-pipelined
     const int64_t need = gf2_m4rm7_a7_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    CK(gf2_launch_a7_pack(0, a, g_a7));
     return gf2_launch_m4rm7(0, a, g_a7, rg, ug, pipe == 8);
   }
   return gf2_launch_m4rm_leaf_variant(0, a, rg, ug, pipe);
@@ -161,7 +163,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 0}, {32, 4, 7}, {40, 4, 7}};
+    const int v[][3] = {{32, 4, 0}, {32, 4, 7}, {24, 4, 0}, {16, 4, 0}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
