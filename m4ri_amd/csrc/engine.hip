@@ -27,6 +27,9 @@ extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
+hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
+hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
+int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
                                     int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
@@ -101,15 +104,27 @@ hipEvent_t take_event(Engine *e) {
 }
 
 // ---- leaf launch ------------------------------------------------------------------------------
-int pick_rg(int64_t m) {
-  // tile heights 1024 / 768 / 512 rows: least padded rows wins, taller tile on ties
-  const int cand[3] = {32, 24, 16};
-  int best = 32; int64_t best_pad = INT64_MAX;
-  for (int rg : cand) {
-    const int64_t R = 32 * rg, pad = ((m + R - 1) / R) * R;
-    if (pad < best_pad) { best_pad = pad; best = rg; }
+// Three generations of the leaf kernel exist (m4rm8 / m4rm7 / m4rm_leaf); they differ in tile height
+// and in measured throughput on full tiles (8192^3 batches: 5.2 / 4.8 / 4.1 / 3.4 / 2.8 e15).  Pick
+// the one that wastes the least time on padded rows.
+struct LeafKind { int gen; int rg; int rows; double rate; };
+const LeafKind LEAF_KINDS[5] = {{3, 32, 2048, 5.2}, {2, 32, 1024, 4.8}, {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
+
+LeafKind pick_leaf(int64_t m) {
+  LeafKind best = LEAF_KINDS[2];
+  double best_cost = 1e300;
+  for (const LeafKind &k : LEAF_KINDS) {
+    const double padded = (double)(((m + k.rows - 1) / k.rows) * k.rows);
+    const double cost   = padded / k.rate;
+    if (cost < best_cost) { best_cost = cost; best = k; }
   }
   return best;
+}
+
+// words of packed-A scratch a leaf launch of this shape may need (max over the packed kernels)
+size_t packed_a_words(int64_t m, int64_t l, int64_t batch) {
+  const size_t a = (size_t)gf2_m4rm7_a7_words(m, l, batch), b = (size_t)gf2_m4rm8_a4_words(m, l, batch);
+  return a > b ? a : b;
 }
 
 int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
@@ -120,10 +135,10 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   // 32-bit byte offsets inside one operand (raw buffer addressing)
   if ((uint64_t)m * (uint64_t)as * 8 >= (1ull << 32) || (uint64_t)l * (uint64_t)bs * 8 >= (1ull << 32))
     return (int)hipErrorInvalidValue;
-  const int rg       = pick_rg(m);
-  const int64_t R    = 32 * rg;
+  LeafKind kind      = pick_leaf(m);
   const int64_t wn   = words_of(n);
-  const int64_t tiles = ((m + R - 1) / R) * ((wn + LEAF_TW - 1) / LEAF_TW) * batch;
+  const int64_t tw   = kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
+  const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
   const int64_t stages = (l + LEAF_STAGE - 1) / LEAF_STAGE;
   int ksplit = ksplit_req;
   if (ksplit <= 0) {
@@ -150,23 +165,25 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   a.m = (int32_t)m; a.l = (int32_t)l; a.n = (int32_t)n;
   a.batch = (int32_t)batch; a.ksplit = ksplit;
   a.mode  = (add || ksplit > 1) ? 1 : 0;
-  // 1024-row tiles run the double-buffered 7-bit kernel, which consumes A in a packed form (one
-  // streaming pass into the call's scratch first); shorter tiles (small or ragged m) stay on the
-  // two-phase kernel, which has 768/512-row variants
-  const size_t a7_need = (size_t)gf2_m4rm7_a7_words(m, l, batch);
-  const bool use_k7    = rg == 32 && e->a7 != nullptr && a7_need <= e->a7_words &&
-                      (uint64_t)a7_need * 8 / (uint64_t)batch < (1ull << 32);  // 32-bit offsets inside one packed operand
-  if (use_k7) {
-    HIPTRY(gf2_launch_a7_pack(st, a, e->a7));
-    e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)a7_need;
+  // generations 2 and 3 consume A in a packed, chunk-major form (one streaming pass into the call's
+  // scratch first); they need that scratch and 32-bit offsets inside one packed operand
+  if (kind.gen >= 2) {
+    const size_t need = kind.gen == 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
+    if (e->a7 == nullptr || need > e->a7_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[2];
+    else {
+      if (kind.gen == 3) HIPTRY(gf2_launch_a4_pack(st, a, e->a7));
+      else HIPTRY(gf2_launch_a7_pack(st, a, e->a7));
+      e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
+    }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {  // the events bracket the leaf kernel alone
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (use_k7) HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
-  else HIPTRY(gf2_launch_m4rm_leaf(st, a, rg));
+  if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->a7, 32, 4, 0));
+  else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
+  else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
     e->pending.emplace_back(e0, e1);
@@ -219,7 +236,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     need += pad((size_t)cnt * md * wl) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
   {
-    const size_t a7_bfs = (size_t)gf2_m4rm7_a7_words(m >> L, l >> L, ipow7(L));
+    const size_t a7_bfs = packed_a_words(m >> L, l >> L, ipow7(L));
     if (a7_bfs > a7_extra) a7_extra = a7_bfs;
   }
   a7_extra = pad(a7_extra);
@@ -272,16 +289,16 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
   int L = plan_levels(m, l, n, cutoff);
   e->stats.levels = L;
   if (L == 0) {
-    if (int rc = reserve_a7(e, (size_t)gf2_m4rm7_a7_words(m, l, 1))) return rc;
+    if (int rc = reserve_a7(e, packed_a_words(m, l, 1))) return rc;
     return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
   }
   const int64_t me = m - m % (1ll << L), le = l - l % (64ll << L), ne = n - n % (64ll << L);
   // packed-A scratch big enough for the batched leaves and for every remainder strip
   size_t a7_strips = 0;
   {
-    const size_t s1 = n > ne ? (size_t)gf2_m4rm7_a7_words(m, l, 1) : 0;
-    const size_t s2 = m > me ? (size_t)gf2_m4rm7_a7_words(m - me, l, 1) : 0;
-    const size_t s3 = l > le ? (size_t)gf2_m4rm7_a7_words(me, l - le, 1) : 0;
+    const size_t s1 = n > ne ? packed_a_words(m, l, 1) : 0;
+    const size_t s2 = m > me ? packed_a_words(m - me, l, 1) : 0;
+    const size_t s3 = l > le ? packed_a_words(me, l - le, 1) : 0;
     a7_strips = s1 > s2 ? s1 : s2;
     if (s3 > a7_strips) a7_strips = s3;
   }
@@ -340,7 +357,7 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
   Engine *e = engine_for_current_device();
   if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
-  if (int rc = reserve_a7(e, (size_t)gf2_m4rm7_a7_words(m, l, 1))) return rc;
+  if (int rc = reserve_a7(e, packed_a_words(m, l, 1))) return rc;
   return launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit);
 }
 

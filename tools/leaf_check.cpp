@@ -16,6 +16,9 @@ extern "C" hipError_t gf2_launch_m4rm_leaf_db(hipStream_t stream, LeafArgs a, in
 extern "C" hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
+extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
+extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
+extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -23,6 +26,12 @@ static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 // through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 10) {  // generation 3: 8-bit tables, 128-byte entries, 2048 x 1024 tiles
+    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
+    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    CK(gf2_launch_a4_pack(0, a, g_a7));
+    return gf2_launch_m4rm8(0, a, g_a7, rg, ug, 0);
+  }
   if (pipe == 7 || pipe == 8) {  // 7-bit double-buffered kernel (packs A first); 8 = software-pipelined
     const int64_t need = gf2_m4rm7_a7_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
@@ -163,12 +172,16 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 0}, {32, 4, 7}, {24, 4, 0}, {16, 4, 0}};
+    const int v[][3] = {{32, 4, 7}, {32, 4, 10}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
       fails += check(193, 65, 65, 1, 1, 0, x[0], 0, x[1], x[2]);
       fails += check(1024, 1024, 2048, 1, 1, 0, x[0], 0, x[1], x[2]);
+      fails += check(2048, 512, 1024, 1, 1, 0, x[0], 0, x[1], x[2]);
+      fails += check(3000, 1000, 3000, 1, 1, 0, x[0], 1, x[1], x[2]);
+      fails += check(1, 1, 1, 1, 1, 0, x[0], 0, x[1], x[2]);
+      fails += check(64, 64, 64, 5, 1, 0, x[0], 0, x[1], x[2]);
       timeit(8192, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
       if (x[0] == 40) timeit(10240, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
     }
