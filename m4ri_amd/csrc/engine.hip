@@ -29,6 +29,7 @@ hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg,
 hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
+hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
@@ -104,14 +105,17 @@ hipEvent_t take_event(Engine *e) {
 }
 
 // ---- leaf launch ------------------------------------------------------------------------------
-// Three generations of the leaf kernel exist (m4rm8 / m4rm7 / m4rm_leaf); they differ in tile height
-// and in measured throughput on full tiles (8192^3 batches: 5.2 / 4.8 / 4.1 / 3.4 / 2.8 e15).  Pick
-// the one that wastes the least time on padded rows.
+// Four generations of the leaf kernel exist (m4rm8q / m4rm8 / m4rm7 / m4rm_leaf); they differ in tile
+// shape (4096x512, 2048x1024, 1024x2048 and shorter) and in measured throughput on full tiles
+// (8192^3 batches: 5.7 / 5.3 / 4.8 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time
+// on padded rows.
 struct LeafKind { int gen; int rg; int rows; double rate; };
-const LeafKind LEAF_KINDS[5] = {{3, 32, 2048, 5.2}, {2, 32, 1024, 4.8}, {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
+const LeafKind LEAF_KINDS[6] = {{4, 32, 4096, 5.7}, {3, 32, 2048, 5.3}, {2, 32, 1024, 4.8},
+                                {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
+constexpr int LEAF_KIND_FALLBACK = 3;  // generation 1, 1024 rows: needs no packed A
 
 LeafKind pick_leaf(int64_t m) {
-  LeafKind best = LEAF_KINDS[2];
+  LeafKind best = LEAF_KINDS[LEAF_KIND_FALLBACK];
   double best_cost = 1e300;
   for (const LeafKind &k : LEAF_KINDS) {
     const double padded = (double)(((m + k.rows - 1) / k.rows) * k.rows);
@@ -137,7 +141,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     return (int)hipErrorInvalidValue;
   LeafKind kind      = pick_leaf(m);
   const int64_t wn   = words_of(n);
-  const int64_t tw   = kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
+  const int64_t tw   = kind.gen == 4 ? 8 : kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
   const int64_t stages = (l + LEAF_STAGE - 1) / LEAF_STAGE;
   int ksplit = ksplit_req;
@@ -168,10 +172,10 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   // generations 2 and 3 consume A in a packed, chunk-major form (one streaming pass into the call's
   // scratch first); they need that scratch and 32-bit offsets inside one packed operand
   if (kind.gen >= 2) {
-    const size_t need = kind.gen == 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
-    if (e->a7 == nullptr || need > e->a7_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[2];
+    const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
+    if (e->a7 == nullptr || need > e->a7_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
-      if (kind.gen == 3) HIPTRY(gf2_launch_a4_pack(st, a, e->a7));
+      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack(st, a, e->a7));
       else HIPTRY(gf2_launch_a7_pack(st, a, e->a7));
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
@@ -181,7 +185,8 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->a7, 32, 4, 0));
+  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->a7, 32, 2));
+  else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->a7, 32, 4, 0));
   else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {

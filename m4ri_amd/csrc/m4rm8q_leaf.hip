@@ -1,0 +1,326 @@
+// m4rm8q_leaf.hip -- M4RM leaf, generation 4: 8-bit tables with 64-byte entries, FOUR tables
+// interleaved per LDS bank row, double-buffered, every wave symmetric.
+//
+// One more turn of generation 3's screw (m4rm8_leaf.hip).  The leaf is bound by LDS-array cycles,
+// and for a tile of fixed area the gathers cost the same while the table writes shrink with the
+// entry size, because more rows share every entry:
+//
+//     entry 256 B (gen 2): 1024 x 2048 tile, 2560 clk per 14 inner bits  -> 183 clk/bit
+//     entry 128 B (gen 3): 2048 x 1024 tile, 2560 clk per 16 inner bits  -> 160 clk/bit
+//     entry  64 B (here) : 4096 x  512 tile, 4608 clk per 32 inner bits  -> 144 clk/bit
+//
+// A stage is now a whole 32-bit word of A = four 256-entry tables (4 x 16 KiB), two stages resident.
+//   * LDS bank row x holds [T0[x] | T1[x] | T2[x] | T3[x]], 64 bytes each.
+//   * lane = (row group lane>>2, 16-byte slot lane&3).  A row takes four gathers per stage; in
+//     gather i the row group reads table (rot + i) & 3 with rot = (row group >> 1) & 3.  Each of
+//     ds_read_b128's four 16-lane service groups holds four row groups -- {0,3,5,6}, {1,2,4,7},
+//     {8,11,13,14}, {9,10,12,15} -- whose `rot` values are 0,1,2,3 in every case, so the four row
+//     groups always sit in four different quarters of the bank row: conflict-free for ANY indices.
+//   * per stage a thread still builds 8 entries of one table from 8 rows of B, so B traffic per
+//     inner bit HALVES; barriers per inner bit halve too.
+//
+// Everything else is generation 3's: C-stationary tile in VGPRs (128 dwords per lane), one
+// v_perm_b32 per lookup address (per-lane selector), one v_bitop3_b32 per dword folds two lookups,
+// Gray-code table build, chunk-major A (a4_pack_kernel of m4rm8_leaf.hip), range-checked buffer
+// descriptors, one barrier per stage.
+//
+// Replaces (result-identical) _mzd_mul_m4rm, mzd_make_table and _mzd_combine_N of the reference
+// (/root/reference m4ri/brilliantrussian.c:1032-1190, :163-211, m4ri/xor_template.h:12-227).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "gf2_common.h"
+
+namespace {
+
+constexpr int K8_BITS  = 8;             // bits per table index
+constexpr int K8_STAGE = 4 * K8_BITS;   // inner bits per stage (four tables) = one dword of A
+constexpr int K8_CHUNK = K8_STAGE;      // inner bits per A dword
+constexpr int K8_TW    = 8;             // tile width in words (512 columns, 64 B per entry)
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// Raw buffer descriptor from wave-uniform inputs (readfirstlane makes the uniformity provable to
+// hipcc; otherwise it may wrap every buffer_load in a waterfall loop, cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+  const uint64_t b  = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint32_t nb = __builtin_amdgcn_readfirstlane(bytes);
+  void *p           = reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)nb, 0x00020000);
+}
+
+// v_perm_b32(a, coloff, sel): byte j of a -> bits 8..15 (table index), coloff.byte0 -> bits 0..7
+// (table half + column slot), buffer -> bit 16 (taken from coloff.byte1 == 0x01)
+__device__ __forceinline__ uint32_t perm_sel(int j, int buf) {
+  return 0x0c000000u | ((buf ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
+}
+
+template <int RG, int UG, bool PIPE, bool XOR_OUT>
+__global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|T1|T2|T3][64 B]
+  constexpr int R  = 128 * RG;  // tile rows: 128 row groups (8 waves x 16) x RG rows
+  constexpr int NG = RG / UG;  // row groups per stage (>= 8: a thread writes one table entry with each of the first 8)
+  static_assert(RG % UG == 0 && NG >= 8, "need at least 8 row groups per stage");
+
+  const int tid  = threadIdx.x;
+  const int c    = tid & 3;          // 16-byte column slot of the 64-byte table entry
+  const int rgrp = tid >> 2;         // row group 0..127
+  const int rot  = (tid >> 3) & 3;   // table this lane reads in the FIRST of a row's four gathers
+  const int bz   = tid >> 7;         // build role: table 0..3 of the stage
+  const int bhi  = (tid >> 2) & 31;  //             bits 3..7 of the entries this thread writes
+
+  // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
+  // remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8 XCDs)
+  uint32_t lid = blockIdx.x;
+  {
+    const uint32_t nwg = gridDim.x;
+    if ((nwg & 7u) == 0u) lid = (lid & 7u) * (nwg >> 3) + (lid >> 3);
+  }
+  const int tile_m = lid % p.tiles_m; lid /= p.tiles_m;
+  const int ks     = lid % p.ksplit;  lid /= p.ksplit;
+  const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
+  const int64_t bat = lid;
+
+  const uint32_t *A7b = p.A7 + bat * p.a7_bs;
+  const word *Bb      = p.B + bat * p.b_bs;
+  word *__restrict__ Cb = p.C + bat * p.c_bs;
+
+  const int nq = (p.l + K8_CHUNK - 1) / K8_CHUNK;  // stages = dwords of A per row
+  // A7 and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
+  // base, and the hardware range check returns 0 for rows >= m of A7 and rows >= l of B -- exactly
+  // the zero padding the algorithm wants, so the main loop has no edge branches.
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(A7b, (uint32_t)((int64_t)nq * p.a7_stride * 4));  // a7_stride = m_pad
+  const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(Bb, (uint32_t)(((int64_t)(p.l - 1) * p.b_stride + p.wn) * 8));
+
+  const int w0   = tile_n * K8_TW + c * 2;  // this lane's two words of the row
+  const bool v0  = w0 < p.wn;
+  const bool v1  = (w0 + 1) < p.wn;
+  const int row0 = tile_m * R + rgrp * RG;
+  const uint32_t a_qs   = (uint32_t)p.a7_stride * 4u;  // bytes between chunks of A7 (m_pad rows)
+  const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
+  const uint32_t a_lane = (uint32_t)row0 * 4u;
+  const uint32_t b_lane = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)w0 * 8u;
+  // per-lane perm operands for gather i (table (rot+i)&3 = index byte (rot+i)&3 of the A dword):
+  // coloff byte0 = table quarter (0/64/128/192) + column slot, byte1 = 0x01 (buffer bit source)
+  uint32_t coloff[4], sel_b0[4], sel_b1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int z = (rot + i) & 3;
+    coloff[i]   = (uint32_t)(z * 64 + c * 16) | 0x0100u;
+    sel_b0[i]   = perm_sel(z, 0);  // stages in buffer 0
+    sel_b1[i]   = perm_sel(z, 1);  // stages in buffer 1
+  }
+  unsigned char *const wr_base = lds + bhi * 8 * 256 + bz * 64 + c * 16;
+
+  uint32_t acc[RG][4];
+#pragma unroll
+  for (int t = 0; t < RG; ++t) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0u; }
+
+  const int q_begin = ks * p.chunks_per_split;
+  int q_end         = q_begin + p.chunks_per_split;
+  if (q_end > nq) q_end = nq;
+
+  // B rows of the table this thread helps to build: rows 3..6 of the 7 (-> base) and rows 0..2
+  // (-> Gray chain).  Columns outside the matrix may hold a neighbour's bits when B is a window;
+  // they only reach C columns that are never stored.
+  uint4 bhi_rows[5], blo_rows[3];
+  auto load_hi = [&](int stage) {
+    uint32_t off = b_lane + ((uint32_t)stage * K8_STAGE + 3u) * b_rs;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
+      off += b_rs;
+      asm volatile("" : "+v"(off));  // one running offset VGPR instead of hoisted per-row offsets
+    }
+  };
+  auto load_lo = [&](int stage) {
+    uint32_t off = b_lane + (uint32_t)stage * K8_STAGE * b_rs;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
+      off += b_rs;
+      asm volatile("" : "+v"(off));
+    }
+  };
+  uint32_t cur[4];
+  auto make_base = [&]() {
+    // the rows become visible to the optimiser only here (volatile asm stays behind the previous
+    // barrier); un-pinned, hipcc hoists these XORs up to the loads and waits out their latency
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      asm volatile("" : "+v"(bhi_rows[j].x), "+v"(bhi_rows[j].y), "+v"(bhi_rows[j].z), "+v"(bhi_rows[j].w));
+    cur[0] = cur[1] = cur[2] = cur[3] = 0u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bool on = (bhi >> j) & 1;
+      cur[0] ^= on ? bhi_rows[j].x : 0u;
+      cur[1] ^= on ? bhi_rows[j].y : 0u;
+      cur[2] ^= on ? bhi_rows[j].z : 0u;
+      cur[3] ^= on ? bhi_rows[j].w : 0u;
+    }
+  };
+  // entry number i (0..7) of the thread's 8: Gray step + one ds_write_b128 into buffer `buf`
+  auto put_entry = [&](int i, int buf) {
+    if (i > 0) {
+      const int j = __builtin_ctz(i);
+      if (i == 1) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          asm volatile("" : "+v"(blo_rows[jj].x), "+v"(blo_rows[jj].y), "+v"(blo_rows[jj].z), "+v"(blo_rows[jj].w));
+      }
+      cur[0] ^= blo_rows[j].x;
+      cur[1] ^= blo_rows[j].y;
+      cur[2] ^= blo_rows[j].z;
+      cur[3] ^= blo_rows[j].w;
+    }
+    // keep the Gray chain a chain (one XOR + one ds_write_b128 per entry)
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+    const int gcode = i ^ (i >> 1);
+    *reinterpret_cast<uint4 *>(wr_base + buf * 65536 + gcode * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+  };
+
+  static_assert(UG == 2 || UG == 4, "the A refill is one 16-byte load per 4 rows");
+  uint32_t areg[RG];
+  auto load_a4 = [&](int g, int q) {
+    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  a_rsrc, (int)(a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u), 0, 0));
+    areg[g * 4 + 0] = v.x; areg[g * 4 + 1] = v.y; areg[g * 4 + 2] = v.z; areg[g * 4 + 3] = v.w;
+  };
+#pragma unroll
+  for (int g = 0; g < RG / 4; ++g) load_a4(g, q_begin);  // q = stage here: one dword of A per stage
+
+  // one stage: gather from the four tables of stage s (buffer J = s & 1) while building those of
+  // stage s+1 into buffer J^1 and refilling the A registers with stage s+1's dword on the way
+  auto stage = [&](auto jtag, int s) {
+    constexpr int J = decltype(jtag)::value;
+    // on entry: cur = base of this thread's table of stage s+1 (made late in the previous stage),
+    // blo_rows = its chain rows, bhi_rows = the base rows of stage s+2.  Nothing but gathers happens
+    // right behind the barrier: all 8 waves come out of it together, and whatever non-LDS work sits
+    // here (VMEM issue, base XORs) would idle the LDS pipe for every one of them at once.
+    uint4 t[4][UG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t ad = __builtin_amdgcn_perm(areg[g * UG + u], coloff[i], J ? sel_b1[i] : sel_b0[i]);
+          t[i][u]           = *reinterpret_cast<const uint4 *>(lds + ad);
+        }
+      }
+      // these rows' indices are out: refill their A registers with the next stage's dword right
+      // away (one 16-byte load per 4 rows)
+      if ((g * UG) % 4 + UG == 4) load_a4((g * UG) / 4, s + 1);
+      // the 8 table entries go out with the FIRST 8 groups, so the chain rows are dead early and
+      // their successors (first needed one group into the next stage) get most of a stage to arrive
+      if (g < 8) put_entry(g, J ^ 1);
+      if (g == 8 || (NG == 8 && g == 7)) load_lo(s + 2);
+      if (g == (NG > 10 ? 10 : NG - 1)) {
+        make_base();     // base of stage s+2's table (its entries are written during stage s+1)
+        load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        uint32_t *a = acc[g * UG + u];
+        a[0] = xor3(xor3(a[0], t[0][u].x, t[1][u].x), t[2][u].x, t[3][u].x);
+        a[1] = xor3(xor3(a[1], t[0][u].y, t[1][u].y), t[2][u].y, t[3][u].y);
+        a[2] = xor3(xor3(a[2], t[0][u].z, t[1][u].z), t[2][u].z, t[3][u].z);
+        a[3] = xor3(xor3(a[3], t[0][u].w, t[1][u].w), t[2][u].w, t[3][u].w);
+        // pin the accumulation here (XOR is associative: un-pinned, hipcc re-associates the whole
+        // stage into one late XOR tree and keeps every loaded table row live)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (q_begin < q_end) {
+    // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
+    load_hi(q_begin);
+    load_lo(q_begin);
+    make_base();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) put_entry(i, 0);
+    load_hi(q_begin + 1);
+    load_lo(q_begin + 1);
+    make_base();
+    load_hi(q_begin + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // two stages per trip so the buffer parity is a compile-time constant; an odd tail runs one
+    // extra stage whose B rows and A dwords lie past the end and read as 0
+    for (int q = q_begin; q < q_end; q += 2) {
+      stage(std::integral_constant<int, 0>{}, q);
+      stage(std::integral_constant<int, 1>{}, q + 1);
+    }
+  }
+
+  // epilogue: C tile out.  One running row pointer (pinned, so hipcc cannot hoist RG 64-bit row
+  // addresses above the main loop); the column guards are loop-invariant per lane.
+  if (v0) {
+    word *cp       = Cb + (int64_t)row0 * p.c_stride + w0;
+    const int rows = (p.m - row0) < RG ? (p.m - row0) : RG;  // may be <= 0
+#pragma unroll
+    for (int t = 0; t < RG; ++t) {
+      if (t < rows) {
+        const word x0 = (word)acc[t][0] | ((word)acc[t][1] << 32);
+        const word x1 = (word)acc[t][2] | ((word)acc[t][3] << 32);
+        if constexpr (!XOR_OUT) {
+          cp[0] = x0;
+          if (v1) cp[1] = x1;
+        } else {
+          // C ^= tile: a no-return L2 atomic needs no destination registers and is what makes
+          // inner-dimension splits (ksplit > 1) race-free; XOR is exact, so order is moot
+          atomicXor(reinterpret_cast<unsigned long long *>(cp), (unsigned long long)x0);
+          if (v1) atomicXor(reinterpret_cast<unsigned long long *>(cp + 1), (unsigned long long)x1);
+        }
+      }
+      cp += p.c_stride;
+      asm volatile("" : "+v"(cp));
+    }
+  }
+}
+
+}  // namespace
+
+// Host launcher.  A must already be packed chunk-major by gf2_launch_a4_pack (m4rm8_leaf.hip) into
+// `a4_ws`.  rg: rows per lane group (tile rows = 128*rg).
+extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug) {
+  const int R = 128 * rg;
+  a.wn        = (int32_t)words_of(a.n);
+  a.tiles_m   = (a.m + R - 1) / R;
+  a.tiles_n   = (a.wn + K8_TW - 1) / K8_TW;
+  if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return hipSuccess;
+  const int64_t nq    = (a.l + K8_CHUNK - 1) / K8_CHUNK;
+  const int64_t m_pad = ((int64_t)a.m + 3) & ~(int64_t)3;
+  a.A7        = reinterpret_cast<const uint32_t *>(a4_ws);
+  a.a7_stride = m_pad;
+  a.a7_bs     = m_pad * nq;
+  if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
+  if (a.ksplit < 1) a.ksplit = 1;
+  int cps = (int)((nq + a.ksplit - 1) / a.ksplit);
+  cps     = (cps + 1) & ~1;  // even: a split starts in table buffer 0
+  if (cps < 2) cps = 2;
+  a.chunks_per_split = cps;
+  a.ksplit           = (int)((nq + cps - 1) / cps);
+  if (a.ksplit > 1 && a.mode == 0) return hipErrorInvalidValue;  // caller must pre-zero C and pass mode 1
+  const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
+  if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+  dim3 grid((unsigned)nwg), block(LEAF_THREADS);
+#define K8Q_CASE(RGV, UGV)                                                                        \
+  if (rg == RGV && ug == UGV) {                                                                     \
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, false>), grid, block, 0, stream, a); \
+    else             hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, true>), grid, block, 0, stream, a);  \
+    return hipGetLastError();                                                                     \
+  }
+  K8Q_CASE(32, 2) K8Q_CASE(32, 4)
+#undef K8Q_CASE
+  return hipErrorInvalidValue;
+}

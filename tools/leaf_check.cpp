@@ -19,6 +19,7 @@ extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a
 extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
+extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -26,6 +27,12 @@ static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 // through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 11) {  // generation 4: 8-bit tables, 64-byte entries, 4096 x 512 tiles
+    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
+    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    CK(gf2_launch_a4_pack(0, a, g_a7));
+    return gf2_launch_m4rm8q(0, a, g_a7, rg, ug);
+  }
   if (pipe == 10) {  // generation 3: 8-bit tables, 128-byte entries, 2048 x 1024 tiles
     const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
@@ -172,7 +179,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 7}, {32, 4, 10}};
+    const int v[][3] = {{32, 4, 10}, {32, 2, 11}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
@@ -182,6 +189,8 @@ int main(int argc, char **argv) {
       fails += check(3000, 1000, 3000, 1, 1, 0, x[0], 1, x[1], x[2]);
       fails += check(1, 1, 1, 1, 1, 0, x[0], 0, x[1], x[2]);
       fails += check(64, 64, 64, 5, 1, 0, x[0], 0, x[1], x[2]);
+      fails += check(5000, 1111, 700, 1, 1, 0, x[0], 1, x[1], x[2]);
+      fails += check(4096, 96, 512, 2, 1, 1, x[0], 0, x[1], x[2]);
       timeit(8192, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
       if (x[0] == 40) timeit(10240, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
     }
