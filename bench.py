@@ -96,6 +96,20 @@ def leaf_traffic(n, world):
     return d.get("bytes_per_launch") if d.get("n") == n else None
 
 
+def bytes_sched(m, l, n, levels):
+    """HBM bytes of the DECLARED, UNFUSED Strassen-Winograd schedule for C = A*B with
+    `levels` levels -- every operand read once and every result written once per kernel: a leaf `mul`
+    moves 8*(m*W(l) + l*W(n) + m*W(n)) bytes, a quadrant addition of r x c bits 3*8*r*W(c); per level 7
+    products + 15 additions (4 on A-quadrant shape, 4 on B-quadrant shape, 7 on C-quadrant shape,
+    strassen.c:111-150)."""
+    W = lambda x: (x + 63) // 64
+    if levels == 0:
+        return 8 * (m * W(l) + l * W(n) + m * W(n))
+    hm, hl, hn = m // 2, l // 2, n // 2
+    adds = 3 * 8 * (4 * hm * W(hl) + 4 * hl * W(hn) + 7 * hm * W(hn))
+    return adds + 7 * bytes_sched(hm, hl, hn, levels - 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +291,21 @@ def main():
                         "its algorithmic HBM bytes are ~1e-3 of its LDS traffic, so frac is small; see DESIGN.md",
             },
         }
+        if args.workload == "mul":
+            # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
+            # this rank's block product / step time); the compulsory bytes beside it
+            pm, pl, pn = r1 - r0, k1 - k0, c1 - c0
+            bs = float(bytes_sched(pm, pl, pn, int(stats.levels)))
+            out["roofline_schedule"] = {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "bytes_sched_per_rank": bs, "levels": int(stats.levels),
+                "bytes_compulsory_per_rank": float(bytes_sched(pm, pl, pn, 0)),
+                "achieved": bs / (ms_per_step * 1e-3) / 1e9,
+                "frac": bs / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
+                "note": "unfused reference schedule bytes (15 quadrant adds/level) over the measured step time; "
+                        "our fused down/up passes move fewer bytes (11 quadrant transfers per pass)",
+            }
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n)

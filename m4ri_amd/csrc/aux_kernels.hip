@@ -83,6 +83,104 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up_kernel(
   }
 }
 
+// ---- two levels at once ------------------------------------------------------------------------
+// The two deepest levels of the schedule fused: a grandparent is read once as a 4 x 4 grid of blocks
+// and its 49 grandchildren are written directly (index 7*j1 + j2, exactly what two single-level
+// passes produce), and on the way up 49 products become the 16 blocks of the grandparent.  Per
+// grandparent that is 1 + 49/16 transfers instead of (1 + 7/4) + (7/4 + 49/16): 38 % less HBM
+// traffic for the two largest levels of every pass.
+template <typename V, bool BSIDE>
+__device__ __forceinline__ void winograd_combos(const V x11, const V x12, const V x21, const V x22, V out[7]) {
+  if (!BSIDE) {
+    const V s1 = x21 ^ x22, s2 = s1 ^ x11, s3 = x11 ^ x21, s4 = x12 ^ s2;
+    out[0] = x11; out[1] = x12; out[2] = s4; out[3] = x22; out[4] = s1; out[5] = s2; out[6] = s3;
+  } else {
+    const V t1 = x12 ^ x11, t2 = x22 ^ t1, t3 = x22 ^ x12, t4 = t2 ^ x21;
+    out[0] = x11; out[1] = x21; out[2] = x22; out[3] = t4; out[4] = t1; out[5] = t2; out[6] = t3;
+  }
+}
+
+template <typename V>
+__device__ __forceinline__ void winograd_recombine(const V p[7], V &c11, V &c12, V &c21, V &c22) {
+  const V u2 = p[0] ^ p[5], u3 = u2 ^ p[6], u4 = u2 ^ p[4];
+  c11 = p[0] ^ p[1]; c12 = u4 ^ p[2]; c21 = u3 ^ p[3]; c22 = u3 ^ p[4];
+}
+
+template <typename V, bool BSIDE>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down2_kernel(
+    const V *__restrict__ gparent, int64_t p_stride, int64_t p_bs,  // grandparent array (units of V)
+    V *__restrict__ gchild, int64_t c_bs,                           // grandchildren, stride == cw
+    int64_t nparents, int64_t crows, int64_t cw) {                  // grandchild shape: crows x cw
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const V *p       = gparent + pi * p_bs + r * p_stride + w;
+    V x[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) x[a][b] = p[(int64_t)a * crows * p_stride + (int64_t)b * cw];
+    // level 1: child j1 of the grandparent, as its own 2 x 2 blocks y[.][a][b]
+    V y[4][7];  // y[2a+b][j1]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) winograd_combos<V, BSIDE>(x[a][b], x[a][b + 2], x[a + 2][b], x[a + 2][b + 2], y[2 * a + b]);
+    V *c = gchild + (pi * 49) * c_bs + r * cw + w;
+#pragma unroll
+    for (int j1 = 0; j1 < 7; ++j1) {
+      V g[7];
+      winograd_combos<V, BSIDE>(y[0][j1], y[1][j1], y[2][j1], y[3][j1], g);
+#pragma unroll
+      for (int j2 = 0; j2 < 7; ++j2) c[(int64_t)(7 * j1 + j2) * c_bs] = g[j2];
+    }
+  }
+}
+
+template <typename V, bool ACC>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_up2_kernel(
+    const V *__restrict__ prod, int64_t p_bs,                       // 49 products per grandparent, stride == cw
+    V *__restrict__ gparent, int64_t o_stride, int64_t o_bs,        // grandparent array
+    int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const V *q       = prod + (pi * 49) * p_bs + r * cw + w;
+    // level 2 -> 1: the four blocks of each of the 7 products of level 1
+    V y[4][7];  // y[2a+b][j1]
+#pragma unroll
+    for (int j1 = 0; j1 < 7; ++j1) {
+      V g[7];
+#pragma unroll
+      for (int j2 = 0; j2 < 7; ++j2) g[j2] = q[(int64_t)(7 * j1 + j2) * p_bs];
+      winograd_recombine<V>(g, y[0][j1], y[1][j1], y[2][j1], y[3][j1]);
+    }
+    // level 1 -> 0: block (a, b) of each quadrant of the grandparent
+    V *o = gparent + pi * o_bs + r * o_stride + w;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        V c11, c12, c21, c22;
+        winograd_recombine<V>(y[2 * a + b], c11, c12, c21, c22);
+        V *o11 = o + (int64_t)a * crows * o_stride + (int64_t)b * cw;
+        V *o12 = o11 + 2 * cw, *o21 = o11 + (int64_t)2 * crows * o_stride, *o22 = o21 + 2 * cw;
+        if (ACC) { c11 ^= *o11; c12 ^= *o12; c21 ^= *o21; c22 ^= *o22; }
+        *o11 = c11; *o12 = c12; *o21 = c21; *o22 = c22;
+      }
+  }
+}
+
 // C = A ^ B (whole words) on strided views; op 1: C = A (copy); op 2: C = 0
 __global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *__restrict__ C, int64_t cs,
                                                               const word *__restrict__ A, int64_t as,
@@ -219,5 +317,60 @@ extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t s
   const int64_t w = words_of(ncols);
   const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
   hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, M, stride, rows, w, mask, seed);
+  return hipGetLastError();
+}
+
+// Two levels per pass.  Grandchildren are crows x cw words, contiguous; a grandparent is 4*crows rows
+// x 4*cw words with row stride p_stride; grandchild 7*j1 + j2 of grandparent i is stored at index
+// 49*i + 7*j1 + j2.
+extern "C" hipError_t gf2_launch_winograd_down2(hipStream_t s, int bside, const word *gparent, int64_t p_stride,
+                                                int64_t p_bs, word *gchild, int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t c_bs = crows * cw;
+  if (nparents * c_bs == 0) return hipSuccess;
+  if (vec_ok(gparent, p_stride, p_bs, cw, cw) && vec_ok(gchild, cw, c_bs, cw, cw)) {
+    const int64_t total = nparents * crows * (cw / 2);
+    if (bside)
+      hipLaunchKernelGGL((winograd_down2_kernel<word2, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<word2 *>(gchild),
+                         c_bs / 2, nparents, crows, cw / 2);
+    else
+      hipLaunchKernelGGL((winograd_down2_kernel<word2, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<word2 *>(gchild),
+                         c_bs / 2, nparents, crows, cw / 2);
+  } else {
+    const int64_t total = nparents * crows * cw;
+    if (bside)
+      hipLaunchKernelGGL((winograd_down2_kernel<word, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, gparent,
+                         p_stride, p_bs, gchild, c_bs, nparents, crows, cw);
+    else
+      hipLaunchKernelGGL((winograd_down2_kernel<word, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, gparent,
+                         p_stride, p_bs, gchild, c_bs, nparents, crows, cw);
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_winograd_up2(hipStream_t s, int acc, const word *prod, word *gparent, int64_t o_stride,
+                                              int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t p_bs = crows * cw;
+  if (nparents * p_bs == 0) return hipSuccess;
+  if (vec_ok(prod, cw, p_bs, cw, cw) && vec_ok(gparent, o_stride, o_bs, cw, cw)) {
+    const int64_t total = nparents * crows * (cw / 2);
+    if (acc)
+      hipLaunchKernelGGL((winograd_up2_kernel<word2, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(prod), p_bs / 2, reinterpret_cast<word2 *>(gparent), o_stride / 2,
+                         o_bs / 2, nparents, crows, cw / 2);
+    else
+      hipLaunchKernelGGL((winograd_up2_kernel<word2, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s,
+                         reinterpret_cast<const word2 *>(prod), p_bs / 2, reinterpret_cast<word2 *>(gparent), o_stride / 2,
+                         o_bs / 2, nparents, crows, cw / 2);
+  } else {
+    const int64_t total = nparents * crows * cw;
+    if (acc)
+      hipLaunchKernelGGL((winograd_up2_kernel<word, true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs,
+                         gparent, o_stride, o_bs, nparents, crows, cw);
+    else
+      hipLaunchKernelGGL((winograd_up2_kernel<word, false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs,
+                         gparent, o_stride, o_bs, nparents, crows, cw);
+  }
   return hipGetLastError();
 }

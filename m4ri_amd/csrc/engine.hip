@@ -36,6 +36,10 @@ hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent
                                     int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word *prod, word *parent, int64_t o_stride,
                                   int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_down2(hipStream_t s, int bside, const word *gparent, int64_t p_stride, int64_t p_bs,
+                                     word *gchild, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_up2(hipStream_t s, int acc, const word *prod, word *gparent, int64_t o_stride,
+                                   int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A, int64_t as,
                               const word *B, int64_t bs, int64_t rows, int64_t w);
 hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols);
@@ -59,8 +63,8 @@ struct Engine {
   word *ws              = nullptr;  // grow-only workspace
   size_t ws_cap         = 0;
   size_t ws_used        = 0;
-  word *a7              = nullptr;  // packed-A scratch of the current call (inside ws)
-  size_t a7_words       = 0;
+  word *apk             = nullptr;  // packed-A scratch of the current call (inside ws)
+  size_t apk_words      = 0;
   bool profiling        = false;
   m4ri_amd_stats stats  = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
@@ -173,10 +177,10 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   // scratch first); they need that scratch and 32-bit offsets inside one packed operand
   if (kind.gen >= 2) {
     const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
-    if (e->a7 == nullptr || need > e->a7_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
+    if (e->apk == nullptr || need > e->apk_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
-      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack(st, a, e->a7));
-      else HIPTRY(gf2_launch_a7_pack(st, a, e->a7));
+      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack(st, a, e->apk));
+      else HIPTRY(gf2_launch_a7_pack(st, a, e->apk));
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
   }
@@ -185,9 +189,9 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->a7, 32, 2));
-  else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->a7, 32, 4, 0));
-  else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->a7, 32, 4, 0));
+  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk, 32, 2));
+  else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
+  else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
@@ -201,11 +205,11 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   return 0;
 }
 
-int reserve_a7(Engine *e, size_t words) {
+int reserve_apk(Engine *e, size_t words) {
   words = (words + 31) & ~(size_t)31;
   if (int rc = ws_reserve(e, words)) return rc;
-  e->a7 = ws_take(e, words);
-  e->a7_words = words;
+  e->apk = ws_take(e, words);
+  e->apk_words = words;
   return 0;
 }
 
@@ -233,10 +237,15 @@ int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
 int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  // The two deepest levels are done by ONE fused pass each way (L >= 2): level L-1 is never
+  // materialised, which saves its buffers and 38 % of the traffic of the two largest levels.
+  const bool fuse2 = L >= 2;
+  auto skipped = [&](int d) { return fuse2 && d == L - 1; };
   // workspace plan
   size_t need = 0;
   auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
   for (int d = 1; d <= L; ++d) {
+    if (skipped(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     need += pad((size_t)cnt * md * wl) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
@@ -246,27 +255,36 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   }
   a7_extra = pad(a7_extra);
   if (int rc = ws_reserve(e, need + a7_extra)) return rc;
-  e->a7 = ws_take(e, a7_extra);
-  e->a7_words = a7_extra;
-  std::vector<word *> Al(L + 1), Bl(L + 1), Pl(L + 1);
+  e->apk = ws_take(e, a7_extra);
+  e->apk_words = a7_extra;
+  std::vector<word *> Al(L + 1, nullptr), Bl(L + 1, nullptr), Pl(L + 1, nullptr);
   for (int d = 1; d <= L; ++d) {
+    if (skipped(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     Al[d] = ws_take(e, (size_t)cnt * md * wl);
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
   }
   e->stats.workspace_bytes = (double)e->ws_cap * 8.0;
-  // down passes
-  for (int d = 0; d < L; ++d) {
+  // down passes: level d -> d+1, or d -> d+2 for the fused pair at the bottom
+  for (int d = 0; d < L;) {
+    const int step    = (fuse2 && d == L - 2) ? 2 : 1;
     const int64_t cnt = ipow7(d);
-    const int64_t cm = m >> (d + 1), cl = l >> (d + 1), cn = n >> (d + 1);
+    const int64_t cm = m >> (d + step), cl = l >> (d + step), cn = n >> (d + step);
     const word *pa = d == 0 ? A.p : Al[d];
     const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
-    HIPTRY(gf2_launch_winograd_down(st, 0, pa, pas, pabs, Al[d + 1], cnt, cm, cl / 64));
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
-    HIPTRY(gf2_launch_winograd_down(st, 1, pb, pbs, pbbs, Bl[d + 1], cnt, cl, cn / 64));
-    e->stats.aux_bytes += 8.0 * cnt * 11.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));
+    if (step == 2) {
+      HIPTRY(gf2_launch_winograd_down2(st, 0, pa, pas, pabs, Al[d + 2], cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_winograd_down2(st, 1, pb, pbs, pbbs, Bl[d + 2], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * 65.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 16 in + 49 out
+    } else {
+      HIPTRY(gf2_launch_winograd_down(st, 0, pa, pas, pabs, Al[d + 1], cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_winograd_down(st, 1, pb, pbs, pbbs, Bl[d + 1], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * 11.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 4 in + 7 out
+    }
+    d += step;
   }
   // all 7^L leaf products in one launch
   {
@@ -275,15 +293,24 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
                              ll * (ln / 64), lm, ll, ln, cnt, false, 1))
       return rc;
   }
-  // up passes
-  for (int d = L - 1; d >= 0; --d) {
-    const int64_t cnt = ipow7(d);
-    const int64_t cm = m >> (d + 1), cn = n >> (d + 1);
-    word *out            = d == 0 ? C.p : Pl[d];
-    const int64_t ostr   = d == 0 ? C.stride : (n >> d) / 64;
-    const int64_t obs    = d == 0 ? 0 : (m >> d) * ostr;
-    HIPTRY(gf2_launch_winograd_up(st, (d == 0 && add) ? 1 : 0, Pl[d + 1], out, ostr, obs, cnt, cm, cn / 64));
-    e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * ((d == 0 && add) ? 15.0 : 11.0);
+  // up passes: level d+1 -> d, or d+2 -> d for the fused pair at the bottom (done first)
+  for (int d = L; d > 0;) {
+    const int step    = (fuse2 && d == L) ? 2 : 1;
+    const int dst     = d - step;
+    const int64_t cnt = ipow7(dst);
+    const int64_t cm = m >> d, cn = n >> d;
+    word *out          = dst == 0 ? C.p : Pl[dst];
+    const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
+    const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
+    const int acc      = (dst == 0 && add) ? 1 : 0;
+    if (step == 2) {
+      HIPTRY(gf2_launch_winograd_up2(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (acc ? 81.0 : 65.0);
+    } else {
+      HIPTRY(gf2_launch_winograd_up(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (acc ? 15.0 : 11.0);
+    }
+    d = dst;
   }
   return 0;
 }
@@ -294,7 +321,7 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
   int L = plan_levels(m, l, n, cutoff);
   e->stats.levels = L;
   if (L == 0) {
-    if (int rc = reserve_a7(e, packed_a_words(m, l, 1))) return rc;
+    if (int rc = reserve_apk(e, packed_a_words(m, l, 1))) return rc;
     return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
   }
   const int64_t me = m - m % (1ll << L), le = l - l % (64ll << L), ne = n - n % (64ll << L);
@@ -362,7 +389,7 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
   Engine *e = engine_for_current_device();
   if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
-  if (int rc = reserve_a7(e, packed_a_words(m, l, 1))) return rc;
+  if (int rc = reserve_apk(e, packed_a_words(m, l, 1))) return rc;
   return launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit);
 }
 

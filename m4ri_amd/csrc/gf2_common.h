@@ -42,8 +42,8 @@ static inline DMat dview(const DMat &M, int64_t r0, int64_t c0_bits, int64_t nr,
 //   C_b (^)= A_b * B_b,  X_b = X + b * x_bs  (word offsets), all the same shape.
 struct LeafArgs {
   const word *A; const word *B; word *C;
-  const uint32_t *A7;                     // packed A (m4rm7_leaf.hip), filled in by its launcher
-  int64_t a7_stride, a7_bs;               // dwords between rows / batch members of A7
+  const uint32_t *Apk;                    // packed, chunk-major copy of A (generations 2-4), set by their launchers
+  int64_t apk_stride, apk_bs;             // dwords between chunks (= padded rows) / batch members of Apk
   int64_t a_stride, b_stride, c_stride;   // words between rows
   int64_t a_bs, b_bs, c_bs;               // words between consecutive batch members
   int32_t m, l, n;                        // C is m x n, inner dimension l (bits)

@@ -60,7 +60,7 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int buf) {
 // and writes 64 chunks x 64 rows of A7 along the rows of A7 -- both sides coalesced.
 constexpr int PK_ROWS = 64, PK_CHUNKS = 64, PK_WORDS = PK_CHUNKS * K7_CHUNK / 64;  // 28 words
 __global__ __launch_bounds__(256) void a7_pack_kernel(const word *__restrict__ A, int64_t a_stride, int64_t a_bs,
-                                                      uint32_t *__restrict__ A7, int64_t m_pad, int64_t a7_bs,
+                                                      uint32_t *__restrict__ A7, int64_t m_pad, int64_t apk_bs,
                                                       int64_t m, int64_t l, int64_t row_tiles, int64_t chunk_tiles) {
   __shared__ word tile[PK_ROWS][PK_WORDS + 1];
   const int64_t nq = (l + K7_CHUNK - 1) / K7_CHUNK;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void a7_pack_kernel(const word *__restrict__ A
     const int64_t left = l - q * K7_CHUNK;  // inner bits that exist from this chunk on (>= 1)
     if (left < K7_CHUNK) v &= (1u << left) - 1u;
     // rows m .. m_pad-1 come out as index 0 of both tables (zero entries) because the tile is 0 there
-    A7[b * a7_bs + q * m_pad + r0 + r] =
+    A7[b * apk_bs + q * m_pad + r0 + r] =
         (v & 0x7fu) | ((((v >> 7) & 0x7fu) | 0x80u) << 8) | (((v >> 14) & 0x7fu) << 16) | ((((v >> 21) & 0x7fu) | 0x80u) << 24);
   }
 }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm7_kernel(const LeafArgs p) {
   const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
   const int64_t bat = lid;
 
-  const uint32_t *A7b = p.A7 + bat * p.a7_bs;
+  const uint32_t *Apkb = p.Apk + bat * p.apk_bs;
   const word *Bb      = p.B + bat * p.b_bs;
   word *__restrict__ Cb = p.C + bat * p.c_bs;
 
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm7_kernel(const LeafArgs p) {
   // A7 and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
   // base, and the hardware range check returns 0 for rows >= m of A7 and rows >= l of B -- exactly
   // the zero padding the algorithm wants, so the main loop has no edge branches.
-  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(A7b, (uint32_t)((int64_t)nq * p.a7_stride * 4));  // a7_stride = m_pad
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(Apkb, (uint32_t)((int64_t)nq * p.apk_stride * 4));  // apk_stride = m_pad
   const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(Bb, (uint32_t)(((int64_t)(p.l - 1) * p.b_stride + p.wn) * 8));
 
   const int w0   = tile_n * LEAF_TW + c * 2;  // this lane's two words of the row
   const bool v0  = w0 < p.wn;
   const bool v1  = (w0 + 1) < p.wn;
   const int row0 = tile_m * R + rgrp * RG;
-  const uint32_t a_qs   = (uint32_t)p.a7_stride * 4u;  // bytes between chunks of A7 (m_pad rows)
+  const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of A7 (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
   const uint32_t b_lane = (uint32_t)bz * K7_BITS * b_rs + (uint32_t)w0 * 8u;
@@ -339,9 +339,9 @@ static bool k7_geometry(LeafArgs &a, word *a7_ws, int rg, int64_t &nq, int64_t &
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return false;
   nq          = (a.l + K7_CHUNK - 1) / K7_CHUNK;
   m_pad       = ((int64_t)a.m + 3) & ~(int64_t)3;
-  a.A7        = reinterpret_cast<const uint32_t *>(a7_ws);
-  a.a7_stride = m_pad;
-  a.a7_bs     = m_pad * nq;
+  a.Apk        = reinterpret_cast<const uint32_t *>(a7_ws);
+  a.apk_stride = m_pad;
+  a.apk_bs     = m_pad * nq;
   return true;
 }
 
@@ -353,7 +353,7 @@ extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a
   const int64_t g = row_tiles * chunk_tiles * a.batch;
   if (g > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(a7_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, a.A, a.a_stride, a.a_bs,
-                     reinterpret_cast<uint32_t *>(a7_ws), m_pad, a.a7_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles);
+                     reinterpret_cast<uint32_t *>(a7_ws), m_pad, a.apk_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles);
   return hipGetLastError();
 }
 

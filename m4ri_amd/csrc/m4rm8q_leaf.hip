@@ -84,22 +84,22 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
   const int64_t bat = lid;
 
-  const uint32_t *A7b = p.A7 + bat * p.a7_bs;
+  const uint32_t *Apkb = p.Apk + bat * p.apk_bs;
   const word *Bb      = p.B + bat * p.b_bs;
   word *__restrict__ Cb = p.C + bat * p.c_bs;
 
   const int nq = (p.l + K8_CHUNK - 1) / K8_CHUNK;  // stages = dwords of A per row
-  // A7 and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
-  // base, and the hardware range check returns 0 for rows >= m of A7 and rows >= l of B -- exactly
+  // The packed A and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
+  // base, and the hardware range check returns 0 for rows >= m of the packed A and rows >= l of B -- exactly
   // the zero padding the algorithm wants, so the main loop has no edge branches.
-  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(A7b, (uint32_t)((int64_t)nq * p.a7_stride * 4));  // a7_stride = m_pad
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(Apkb, (uint32_t)((int64_t)nq * p.apk_stride * 4));  // apk_stride = m_pad
   const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(Bb, (uint32_t)(((int64_t)(p.l - 1) * p.b_stride + p.wn) * 8));
 
   const int w0   = tile_n * K8_TW + c * 2;  // this lane's two words of the row
   const bool v0  = w0 < p.wn;
   const bool v1  = (w0 + 1) < p.wn;
   const int row0 = tile_m * R + rgrp * RG;
-  const uint32_t a_qs   = (uint32_t)p.a7_stride * 4u;  // bytes between chunks of A7 (m_pad rows)
+  const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
   const uint32_t b_lane = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)w0 * 8u;
@@ -300,9 +300,9 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return hipSuccess;
   const int64_t nq    = (a.l + K8_CHUNK - 1) / K8_CHUNK;
   const int64_t m_pad = ((int64_t)a.m + 3) & ~(int64_t)3;
-  a.A7        = reinterpret_cast<const uint32_t *>(a4_ws);
-  a.a7_stride = m_pad;
-  a.a7_bs     = m_pad * nq;
+  a.Apk        = reinterpret_cast<const uint32_t *>(a4_ws);
+  a.apk_stride = m_pad;
+  a.apk_bs     = m_pad * nq;
   if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
   if (a.ksplit < 1) a.ksplit = 1;
   int cps = (int)((nq + a.ksplit - 1) / a.ksplit);

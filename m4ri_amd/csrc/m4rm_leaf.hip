@@ -1,5 +1,7 @@
-// m4rm_leaf.hip -- the hot kernel: C (^)= A*B over GF(2) by the Method of Four Russians,
-// hand-written for gfx950 (MI355X / CDNA4).  No MFMA: this is a lookup + XOR path.
+// m4rm_leaf.hip -- M4RM leaf, generation 1 (two-phase, k = 8): C (^)= A*B over GF(2) by the Method of
+// Four Russians, hand-written for gfx950 (MI355X / CDNA4).  No MFMA: this is a lookup + XOR path.
+// The engine uses it for tiles shorter than 1024 rows and as the fallback that needs no packed A;
+// full tiles run generations 2-4 (m4rm7_leaf.hip, m4rm8_leaf.hip, m4rm8q_leaf.hip).
 //
 // Replaces (result-identical, not structure-identical) the reference's leaf
 //   _mzd_mul_m4rm           /root/reference m4ri/brilliantrussian.c:1032-1190
@@ -25,10 +27,11 @@
 #include <hip/hip_runtime.h>
 #include "gf2_common.h"
 
-// (rg, ug, pipe) instantiations.  Product defaults first; the others exist for tools/leaf_check.
+// (rg, ug, variant) instantiations.  variant bit 0 = software-pipelined gathers, bit 1 = B rows staged
+// through LDS; both were measured and are not instantiated in the product.
 #ifndef LEAF_VARIANTS
 #define LEAF_VARIANTS(X) \
-  X(32, 4, 0) X(24, 4, 0) X(16, 4, 0) X(32, 2, 0) X(32, 2, 2) X(32, 4, 2) X(32, 4, 3) X(32, 8, 2) X(40, 2, 2) X(40, 4, 2) X(40, 4, 3) X(24, 4, 2) X(16, 4, 2)
+  X(32, 4, 0) X(24, 4, 0) X(16, 4, 0)
 #endif
 #define LEAF_DEFAULT_UG(rg) 4
 #define LEAF_DEFAULT_PIPE(rg) 0

@@ -164,14 +164,14 @@ int main(int argc, char **argv) {
   const int rgs[3] = {32, 24, 16};
   if (!(argc > 1 && !strcmp(argv[1], "--one")))
   for (int rg : rgs) {
-    fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0);
-    fails += check(1000, 777, 1234, 1, 1, 0, rg, 1);
-    fails += check(1000, 777, 1234, 2, 1, 1, rg, 3);
-    fails += check(1, 1, 1, 1, 1, 0, rg, 0);
-    fails += check(3, 131, 257, 1, 1, 0, rg, 0);
-    fails += check(2100, 300, 4100, 2, 3, 1, rg, 2);
-    fails += check(64, 64, 64, 5, 1, 0, rg, 0);
-    fails += check(193, 65, 65, 1, 2, 1, rg, 0);
+    fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0, 4, 0);
+    fails += check(1000, 777, 1234, 1, 1, 0, rg, 1, 4, 0);
+    fails += check(1000, 777, 1234, 2, 1, 1, rg, 3, 4, 0);
+    fails += check(1, 1, 1, 1, 1, 0, rg, 0, 4, 0);
+    fails += check(3, 131, 257, 1, 1, 0, rg, 0, 4, 0);
+    fails += check(2100, 300, 4100, 2, 3, 1, rg, 2, 4, 0);
+    fails += check(64, 64, 64, 5, 1, 0, rg, 0, 4, 0);
+    fails += check(193, 65, 65, 1, 2, 1, rg, 0, 4, 0);
   }
   if (argc > 1 && !strcmp(argv[1], "--check-only")) return fails != 0;
   if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch : profile a single variant
@@ -179,7 +179,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 10}, {32, 2, 11}};
+    const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 4, 7}, {32, 4, 10}, {32, 2, 11}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
@@ -198,14 +198,10 @@ int main(int argc, char **argv) {
     return fails != 0;
   }
   for (int rg : rgs) {
-    timeit(8192, 8192, 8192, 8, 1, rg, 5);
-    timeit(16384, 16384, 16384, 1, 1, rg, 5);
-    timeit(16384, 16384, 16384, 1, 2, rg, 5);
-    timeit(16384, 16384, 16384, 1, 4, rg, 5);
+    timeit(8192, 8192, 8192, 8, 1, rg, 5, 4, 0);
+    timeit(16384, 16384, 16384, 1, 4, rg, 5, 4, 0);
   }
-  timeit(4096, 4096, 4096, 1, 1, 32, 5);
-  timeit(4096, 4096, 4096, 1, 8, 16, 5);
-  timeit(4096, 4096, 4096, 64, 1, 32, 5);
+  timeit(4096, 4096, 4096, 64, 1, 32, 5, 4, 0);
   printf("%s\n", fails ? "LEAF_CHECK FAILED" : "LEAF_CHECK ALL OK");
   return fails != 0;
 }
