@@ -136,7 +136,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm7_kernel(const LeafArgs p) {
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of A7 (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
-  const uint32_t b_lane = (uint32_t)bz * K7_BITS * b_rs + (uint32_t)w0 * 8u;
+  // B offsets = wave-uniform part (table, tile column: SGPRs) + the lane's 16-byte slot; keeping the
+  // uniform part out of VGPRs avoids spilled offsets (a scratch reload costs a vmcnt(0) drain)
+  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(bz) * K7_BITS * b_rs + (uint32_t)tile_n * (LEAF_TW * 8u);
+  const uint32_t b_slot = (uint32_t)c * 16u;
   const uint32_t coloff = (uint32_t)(c * 16) | 0x0100u;  // byte0 = column slot, byte1 = 0x01 (buffer bit)
   unsigned char *const wr_base = lds + bz * 32768 + bhi * 8 * 256 + c * 16;
 
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm7_kernel(const LeafArgs p) {
   // they only reach C columns that are never stored.
   uint4 bhi_rows[4], blo_rows[3];
   auto load_hi = [&](int stage) {
-    uint32_t off = b_lane + ((uint32_t)stage * K7_STAGE + 3u) * b_rs;
+    uint32_t off = (b_uni + ((uint32_t)stage * K7_STAGE + 3u) * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm7_kernel(const LeafArgs p) {
     }
   };
   auto load_lo = [&](int stage) {
-    uint32_t off = b_lane + (uint32_t)stage * K7_STAGE * b_rs;
+    uint32_t off = (b_uni + (uint32_t)stage * K7_STAGE * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));

@@ -136,7 +136,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
-  const uint32_t b_lane = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)w0 * 8u;
+  // B offsets = wave-uniform part (table, tile column: SGPRs) + the lane's 16-byte slot; keeping the
+  // uniform part out of VGPRs avoids spilled offsets (a scratch reload costs a vmcnt(0) drain)
+  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(bz) * K8_BITS * b_rs + (uint32_t)tile_n * (K8_TW * 8u);
+  const uint32_t b_slot = (uint32_t)c * 16u;
   // per-lane perm operands: byte0 = table half (0 / 128) + column slot, byte1 = 0x01 (buffer bit)
   const uint32_t coloff1 = (uint32_t)(par * 128 + c * 16) | 0x0100u;        // first gather: table `par`
   const uint32_t coloff2 = (uint32_t)((par ^ 1) * 128 + c * 16) | 0x0100u;  // second gather: the other one
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
   // they only reach C columns that are never stored.
   uint4 bhi_rows[5], blo_rows[3];
   auto load_hi = [&](int stage) {
-    uint32_t off = b_lane + ((uint32_t)stage * K8_STAGE + 3u) * b_rs;
+    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 3u) * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
     }
   };
   auto load_lo = [&](int stage) {
-    uint32_t off = b_lane + (uint32_t)stage * K8_STAGE * b_rs;
+    uint32_t off = (b_uni + (uint32_t)stage * K8_STAGE * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));

@@ -102,7 +102,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
-  const uint32_t b_lane = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)w0 * 8u;
+  // B offsets = wave-uniform part (table, tile column: SGPRs) + the lane's 16-byte slot.  Keeping the
+  // uniform part out of VGPRs matters: at 256 VGPRs a spilled offset costs a scratch reload + vmcnt(0),
+  // i.e. a full drain of the A/B prefetches, twice per stage pair
+  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(bz) * K8_BITS * b_rs + (uint32_t)tile_n * (K8_TW * 8u);
+  const uint32_t b_slot = (uint32_t)c * 16u;
   // per-lane perm operands for gather i (table (rot+i)&3 = index byte (rot+i)&3 of the A dword):
   // coloff byte0 = table quarter (0/64/128/192) + column slot, byte1 = 0x01 (buffer bit source)
   uint32_t coloff[4], sel_b0[4], sel_b1[4];
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // they only reach C columns that are never stored.
   uint4 bhi_rows[5], blo_rows[3];
   auto load_hi = [&](int stage) {
-    uint32_t off = b_lane + ((uint32_t)stage * K8_STAGE + 3u) * b_rs;
+    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 3u) * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     }
   };
   auto load_lo = [&](int stage) {
-    uint32_t off = b_lane + (uint32_t)stage * K8_STAGE * b_rs;
+    uint32_t off = (b_uni + (uint32_t)stage * K8_STAGE * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
