@@ -84,6 +84,26 @@ def cpu_baseline(n_workload: int):
     return out
 
 
+LEAF_KERNELS = {1: "m4rm_leaf_kernel", 2: "m4rm7_kernel", 3: "m4rm8_kernel", 4: "m4rm8q_kernel"}
+# (tile rows, tile columns, inner bits per stage, LDS-array clocks per stage): gathers at 256 B/clk/CU
+# + table writes at 128 B/clk/CU, both measured with tools/ubench.hip
+LEAF_LDS_MODEL = {2: (1024, 2048, 14, 2560), 3: (2048, 1024, 16, 2560), 4: (4096, 512, 32, 4608)}
+CU_COUNT, PEAK_CLOCK_HZ = 256, 2.4e9
+
+
+def lds_model(gen, m, l, n, products, launch_ms):
+    """The leaf launch against the LDS-array bound of its own design: CU-clocks the gathers and table
+    writes need at the measured LDS rates, spread over 256 CUs at the 2.4 GHz peak clock."""
+    if gen not in LEAF_LDS_MODEL or launch_ms <= 0:
+        return None
+    tr, tc, bits, clk = LEAF_LDS_MODEL[gen]
+    tiles = -(-m // tr) * -(-n // tc)
+    stages = -(-l // bits)
+    bound_ms = products * tiles * stages * clk / (CU_COUNT * PEAK_CLOCK_HZ) * 1e3
+    return {"bound_ms": bound_ms, "frac": bound_ms / launch_ms, "clk_per_stage": clk,
+            "tile": [tr, tc], "bits_per_stage": bits, "clock_hz": PEAK_CLOCK_HZ}
+
+
 def leaf_traffic(n, world):
     """HBM bytes of one leaf launch from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
     correction + WRITE_SIZE, MI355X_MICROARCH.md HBM section) -- counters cannot be read from inside
@@ -276,7 +296,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "m4rm7_kernel (the M4RM leaf; one batched launch per step, HIP events around that launch alone)",
+                "kernel": LEAF_KERNELS.get(int(stats.leaf_gen), "?") + " (the M4RM leaf; one batched launch per step, HIP events around that launch alone)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -287,8 +307,11 @@ def main():
                 "algorithmic_bytes_per_launch": leaf_launch_bytes,
                 "leaf_bitops_per_sec": (leaf_ops / (stats.leaf_ms * 1e-3)) if stats.leaf_ms > 0 else 0.0,
                 "aux_pass_bytes_per_step": stats.aux_bytes,
+                "lds": lds_model(int(stats.leaf_gen), int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n),
+                                 int(stats.leaf_products) // max(1, int(stats.leaf_launches)), leaf_launch_ms),
                 "note": "the leaf is LDS-bound by design (table gathers at 256 B/clk/CU), not HBM-bound: "
-                        "its algorithmic HBM bytes are ~1e-3 of its LDS traffic, so frac is small; see DESIGN.md",
+                        "its algorithmic HBM bytes are ~1e-3 of its LDS traffic, so frac is small; the `lds` object "
+                        "prices the launch against the LDS-array cycles it needs (DESIGN.md 3.1)",
             },
         }
         if args.workload == "mul":

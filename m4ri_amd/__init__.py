@@ -30,7 +30,7 @@ class Stats(ctypes.Structure):
         ("leaf_m", ctypes.c_int32),
         ("leaf_l", ctypes.c_int32),
         ("leaf_n", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("leaf_gen", ctypes.c_int32),
         ("leaf_ms", ctypes.c_double),
         ("leaf_bytes", ctypes.c_double),
         ("aux_bytes", ctypes.c_double),

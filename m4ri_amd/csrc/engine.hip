@@ -28,7 +28,7 @@ hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
-hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
+hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
@@ -179,7 +179,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
     if (e->apk == nullptr || need > e->apk_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
-      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack(st, a, e->apk));
+      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen == 4));
       else HIPTRY(gf2_launch_a7_pack(st, a, e->apk));
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
@@ -201,6 +201,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   e->stats.leaf_launches += 1;
   e->stats.leaf_products += batch;
   e->stats.leaf_m = (int32_t)m; e->stats.leaf_l = (int32_t)l; e->stats.leaf_n = (int32_t)n;
+  e->stats.leaf_gen = kind.gen;
   e->stats.leaf_bytes += 8.0 * (double)batch * ((double)m * words_of(l) + (double)l * wn + (double)m * wn * (add ? 2 : 1));
   return 0;
 }

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t perm_sel(int j, int buf) {
 constexpr int PK_ROWS = 64, PK_WORDS = 32;
 __global__ __launch_bounds__(256) void a4_pack_kernel(const word *__restrict__ A, int64_t a_stride, int64_t a_bs,
                                                       uint32_t *__restrict__ A4, int64_t m_pad, int64_t a4_bs,
-                                                      int64_t m, int64_t l, int64_t row_tiles, int64_t word_tiles) {
+                                                      int64_t m, int64_t l, int64_t row_tiles, int64_t word_tiles, int rot) {
   __shared__ uint32_t tile[PK_ROWS][2 * PK_WORDS + 1];
   const int64_t nq = (l + K8_CHUNK - 1) / K8_CHUNK;
   const int64_t wa = (l + 63) >> 6;
@@ -88,7 +88,12 @@ __global__ __launch_bounds__(256) void a4_pack_kernel(const word *__restrict__ A
     const int r = i % PK_ROWS, ql = i / PK_ROWS;
     const int64_t q = 2 * w0 + ql;
     if (q >= nq || r0 + r >= m_pad) continue;
-    A4[b * a4_bs + q * m_pad + r0 + r] = tile[r][ql];  // rows m .. m_pad-1 come out 0 (index 0 = zero entries)
+    uint32_t v = tile[r][ql];
+    // generation 4 reads table (rot + i) & 3 in a row's i-th gather, rot = (row >> 6) & 3 (its lane
+    // geometry): store the four index bytes pre-rotated so that byte i IS the i-th gather's index
+    // and the kernel's v_perm selectors are compile-time constants
+    if (rot) v = __builtin_amdgcn_alignbyte(v, v, (uint32_t)(((r0 + r) >> 6) & 3));
+    A4[b * a4_bs + q * m_pad + r0 + r] = v;  // rows m .. m_pad-1 come out 0 (index 0 = zero entries)
   }
 }
 
@@ -103,8 +108,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
   const int c    = tid & 7;          // 16-byte column slot of the 128-byte table entry
   const int rgrp = tid >> 3;         // row group 0..63
   const int par  = (tid >> 4) & 1;   // which table this lane reads FIRST in a pair of gathers
-  const int bz   = tid >> 8;         // build role: table 0/1 of the stage
-  const int bhi  = (tid >> 3) & 31;  //             bits 3..7 of the entries this thread writes
+  // build role: 16 consecutive lanes = 8 slots x 2 tables of ONE entry index = one whole 256-byte
+  // bank row per ds_write_b128 service group (conflict-free; see m4rm8q_leaf.hip)
+  const int bz   = (tid >> 3) & 1;   // table 0/1 of the stage
+  const int bhi  = tid >> 4;         // bits 3..7 of the entries this thread writes
 
   // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
   // remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8 XCDs)
@@ -138,8 +145,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
   const uint32_t a_lane = (uint32_t)row0 * 4u;
   // B offsets = wave-uniform part (table, tile column: SGPRs) + the lane's 16-byte slot; keeping the
   // uniform part out of VGPRs avoids spilled offsets (a scratch reload costs a vmcnt(0) drain)
-  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(bz) * K8_BITS * b_rs + (uint32_t)tile_n * (K8_TW * 8u);
-  const uint32_t b_slot = (uint32_t)c * 16u;
+  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(tile_n) * (K8_TW * 8u);
+  const uint32_t b_slot = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)c * 16u;
   // per-lane perm operands: byte0 = table half (0 / 128) + column slot, byte1 = 0x01 (buffer bit)
   const uint32_t coloff1 = (uint32_t)(par * 128 + c * 16) | 0x0100u;        // first gather: table `par`
   const uint32_t coloff2 = (uint32_t)((par ^ 1) * 128 + c * 16) | 0x0100u;  // second gather: the other one
@@ -354,7 +361,7 @@ static bool k8_geometry(LeafArgs &a, word *a4_ws, int rg, int64_t &nq, int64_t &
   return true;
 }
 
-extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws) {
+extern "C" hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot) {
   int64_t nq, m_pad;
   if (!k8_geometry(a, a4_ws, 32, nq, m_pad)) return hipSuccess;
   if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
@@ -363,8 +370,12 @@ extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a
   const int64_t g = row_tiles * chunk_tiles * a.batch;
   if (g > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(a4_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, a.A, a.a_stride, a.a_bs,
-                     reinterpret_cast<uint32_t *>(a4_ws), m_pad, a.apk_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles);
+                     reinterpret_cast<uint32_t *>(a4_ws), m_pad, a.apk_bs, (int64_t)a.m, (int64_t)a.l, row_tiles, chunk_tiles, rot);
   return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws) {
+  return gf2_launch_a4_pack_rot(stream, a, a4_ws, 0);
 }
 
 extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe) {

@@ -1,3 +1,4 @@
+// EXPERIMENT (not in the product): generation 4 with the table building given to waves 0..3 only.
 // m4rm8q_leaf.hip -- M4RM leaf, generation 4: 8-bit tables with 64-byte entries, FOUR tables
 // interleaved per LDS bank row, double-buffered, every wave symmetric.
 //
@@ -59,7 +60,7 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int buf) {
 }
 
 template <int RG, int UG, bool PIPE, bool XOR_OUT>
-__global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) {
+__global__ __launch_bounds__(LEAF_THREADS) void m4rm8qb_kernel(const LeafArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|T1|T2|T3][64 B]
   constexpr int R  = 128 * RG;  // tile rows: 128 row groups (8 waves x 16) x RG rows
   constexpr int NG = RG / UG;  // row groups per stage (>= 8: a thread writes one table entry with each of the first 8)
@@ -69,11 +70,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const int c    = tid & 3;          // 16-byte column slot of the 64-byte table entry
   const int rgrp = tid >> 2;         // row group 0..127
   const int rot  = (tid >> 3) & 3;   // table this lane reads in the FIRST of a row's four gathers
-  // build role: 16 consecutive lanes = 4 slots x 4 tables of ONE entry index, i.e. one whole 256-byte
-  // bank row per ds_write_b128 service group -- conflict-free (one table per wave put 4 rows on the
-  // same 16 banks: SQ_LDS_BANK_CONFLICT showed 8 extra clocks per write, 11 % of the LDS time)
-  const int bz   = (tid >> 2) & 3;   // table 0..3 of the stage
-  const int bhi  = tid >> 4;         // bits 3..7 of the entries this thread writes
+  // build roles -- only waves 0..3 build (one wave per table, 16 entries per thread and stage): on
+  // each SIMD the wave dispatched first wins arbitration and used to wait ~1300 clk per stage at the
+  // barrier for its younger partner; giving it all of the table building evens the two out
+  const int bz   = (tid >> 6) & 3;   // table 0..3 of the stage
+  const int bhi  = (tid >> 2) & 15;  // bits 4..7 of the entries this thread writes
 
   // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
   // remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8 XCDs)
@@ -105,18 +106,18 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
-  // B offsets = wave-uniform part (tile column, stage: SGPRs) + ONE per-lane VGPR (table, 16-byte
-  // slot).  Keeping the uniform part out of VGPRs matters: at 256 VGPRs a spilled offset costs a
-  // scratch reload + vmcnt(0), i.e. a full drain of the A/B prefetches, twice per stage pair
-  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(tile_n) * (K8_TW * 8u);
-  const uint32_t b_slot = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)c * 16u;
+  // B offsets = wave-uniform part (table, tile column: SGPRs) + the lane's 16-byte slot.  Keeping the
+  // uniform part out of VGPRs matters: at 256 VGPRs a spilled offset costs a scratch reload + vmcnt(0),
+  // i.e. a full drain of the A/B prefetches, twice per stage pair
+  const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(bz) * K8_BITS * b_rs + (uint32_t)tile_n * (K8_TW * 8u);
+  const uint32_t b_slot = (uint32_t)c * 16u;
   // per-lane perm operands for gather i (table (rot+i)&3 = index byte (rot+i)&3 of the A dword):
   // coloff byte0 = table quarter (0/64/128/192) + column slot, byte1 = 0x01 (buffer bit source)
   // (the packed A holds a row's four index bytes already rotated by `rot`, so byte i is gather i's)
   uint32_t coloff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) coloff[i] = (uint32_t)(((rot + i) & 3) * 64 + c * 16) | 0x0100u;
-  unsigned char *const wr_base = lds + bhi * 8 * 256 + bz * 64 + c * 16;
+  unsigned char *const wr_base = lds + bhi * 16 * 256 + bz * 64 + c * 16;
 
   uint32_t acc[RG][4];
 #pragma unroll
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // B rows of the table this thread helps to build: rows 3..6 of the 7 (-> base) and rows 0..2
   // (-> Gray chain).  Columns outside the matrix may hold a neighbour's bits when B is a window;
   // they only reach C columns that are never stored.
-  uint4 bhi_rows[5], blo_rows[3];
+  uint4 bhi_rows[4], blo_rows[4];
   auto load_hi = [&](int stage) {
-    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 3u) * b_rs) + b_slot;
+    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 4u) * b_rs) + b_slot;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 4; ++j) {
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
       off += b_rs;
       asm volatile("" : "+v"(off));  // one running offset VGPR instead of hoisted per-row offsets
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   auto load_lo = [&](int stage) {
     uint32_t off = (b_uni + (uint32_t)stage * K8_STAGE * b_rs) + b_slot;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 4; ++j) {
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
       off += b_rs;
       asm volatile("" : "+v"(off));
@@ -153,11 +154,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     // the rows become visible to the optimiser only here (volatile asm stays behind the previous
     // barrier); un-pinned, hipcc hoists these XORs up to the loads and waits out their latency
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < 4; ++j)
       asm volatile("" : "+v"(bhi_rows[j].x), "+v"(bhi_rows[j].y), "+v"(bhi_rows[j].z), "+v"(bhi_rows[j].w));
     cur[0] = cur[1] = cur[2] = cur[3] = 0u;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const bool on = (bhi >> j) & 1;
       cur[0] ^= on ? bhi_rows[j].x : 0u;
       cur[1] ^= on ? bhi_rows[j].y : 0u;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
       const int j = __builtin_ctz(i);
       if (i == 1) {
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
           asm volatile("" : "+v"(blo_rows[jj].x), "+v"(blo_rows[jj].y), "+v"(blo_rows[jj].z), "+v"(blo_rows[jj].w));
       }
       cur[0] ^= blo_rows[j].x;
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
   // one stage: gather from the four tables of stage s (buffer J = s & 1) while building those of
   // stage s+1 into buffer J^1 and refilling the A registers with stage s+1's dword on the way
-  auto stage = [&](auto jtag, int s) {
-    constexpr int J = decltype(jtag)::value;
+  auto stage = [&](auto jtag, auto btag, int s) {
+    constexpr int J        = decltype(jtag)::value;
+    constexpr bool BUILDER = decltype(btag)::value;
     // on entry: cur = base of this thread's table of stage s+1 (made late in the previous stage),
     // blo_rows = its chain rows, bhi_rows = the base rows of stage s+2.  Nothing but gathers happens
     // right behind the barrier: all 8 waves come out of it together, and whatever non-LDS work sits
@@ -219,11 +221,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
       if ((g * UG) % 4 + UG == 4) load_a4((g * UG) / 4, s + 1);
       // the 8 table entries go out with the FIRST 8 groups, so the chain rows are dead early and
       // their successors (first needed one group into the next stage) get most of a stage to arrive
-      if (g < 8) put_entry(g, J ^ 1);
-      if (g == 8 || (NG == 8 && g == 7)) load_lo(s + 2);
-      if (g == (NG > 10 ? 10 : NG - 1)) {
-        make_base();     // base of stage s+2's table (its entries are written during stage s+1)
-        load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
+      if constexpr (BUILDER) {
+        if (g < 16) put_entry(g, J ^ 1);
+        if (g == 15) {
+          load_lo(s + 2);
+          make_base();     // base of stage s+2's table (its entries are written during stage s+1)
+          load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -243,26 +247,30 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if (q_begin < q_end) {
-    // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
-    load_hi(q_begin);
-    load_lo(q_begin);
-    make_base();
+  auto run = [&](auto btag) {
+    constexpr bool BUILDER = decltype(btag)::value;
+    if constexpr (BUILDER) {
+      load_hi(q_begin);
+      load_lo(q_begin);
+      make_base();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) put_entry(i, 0);
-    load_hi(q_begin + 1);
-    load_lo(q_begin + 1);
-    make_base();
-    load_hi(q_begin + 2);
+      for (int i = 0; i < 16; ++i) put_entry(i, 0);
+      load_hi(q_begin + 1);
+      load_lo(q_begin + 1);
+      make_base();
+      load_hi(q_begin + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    // two stages per trip so the buffer parity is a compile-time constant; an odd tail runs one
-    // extra stage whose B rows and A dwords lie past the end and read as 0
     for (int q = q_begin; q < q_end; q += 2) {
-      stage(std::integral_constant<int, 0>{}, q);
-      stage(std::integral_constant<int, 1>{}, q + 1);
+      stage(std::integral_constant<int, 0>{}, btag, q);
+      stage(std::integral_constant<int, 1>{}, btag, q + 1);
     }
+  };
+  if (q_begin < q_end) {
+    if (__builtin_amdgcn_readfirstlane(tid >> 8) == 0) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   // epilogue: C tile out.  One running row pointer (pinned, so hipcc cannot hoist RG 64-bit row
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
 // Host launcher.  A must already be packed chunk-major by gf2_launch_a4_pack (m4rm8_leaf.hip) into
 // `a4_ws`.  rg: rows per lane group (tile rows = 128*rg).
-extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug) {
+extern "C" hipError_t gf2_launch_m4rm8qb(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug) {
   const int R = 128 * rg;
   a.wn        = (int32_t)words_of(a.n);
   a.tiles_m   = (a.m + R - 1) / R;
@@ -319,8 +327,8 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
 #define K8Q_CASE(RGV, UGV)                                                                        \
   if (rg == RGV && ug == UGV) {                                                                     \
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, false>), grid, block, 0, stream, a); \
-    else             hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, true>), grid, block, 0, stream, a);  \
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm8qb_kernel<RGV, UGV, false, false>), grid, block, 0, stream, a); \
+    else             hipLaunchKernelGGL((m4rm8qb_kernel<RGV, UGV, false, true>), grid, block, 0, stream, a);  \
     return hipGetLastError();                                                                     \
   }
   K8Q_CASE(32, 2) K8Q_CASE(32, 4)

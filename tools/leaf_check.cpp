@@ -2,7 +2,8 @@
 // not a test the driver runs): checks gf2_launch_m4rm_leaf against a definitional CPU multiply on
 // ragged/batched/strided shapes, then times the bench-sized launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp \
-//         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/m4rm7_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
+//         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/m4rm7_leaf.hip m4ri_amd/csrc/m4rm8_leaf.hip \
+//         m4ri_amd/csrc/m4rm8q_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,8 @@ extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a
 extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
+extern "C" hipError_t gf2_launch_m4rm8qb(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
+extern "C" hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
@@ -27,10 +30,16 @@ static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 // through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 12) {  // experiment: generation 4 with builder waves
+    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
+    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    CK(gf2_launch_a4_pack_rot(0, a, g_a7, 1));
+    return gf2_launch_m4rm8qb(0, a, g_a7, rg, ug);
+  }
   if (pipe == 11) {  // generation 4: 8-bit tables, 64-byte entries, 4096 x 512 tiles
     const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
-    CK(gf2_launch_a4_pack(0, a, g_a7));
+    CK(gf2_launch_a4_pack_rot(0, a, g_a7, 1));
     return gf2_launch_m4rm8q(0, a, g_a7, rg, ug);
   }
   if (pipe == 10) {  // generation 3: 8-bit tables, 128-byte entries, 2048 x 1024 tiles
@@ -162,7 +171,7 @@ int main(int argc, char **argv) {
   sm_state = 12345;
   int fails = 0;
   const int rgs[3] = {32, 24, 16};
-  if (!(argc > 1 && !strcmp(argv[1], "--one")))
+  if (!(argc > 1 && (!strcmp(argv[1], "--one") || !strcmp(argv[1], "--v4"))))
   for (int rg : rgs) {
     fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0, 4, 0);
     fails += check(1000, 777, 1234, 1, 1, 0, rg, 1, 4, 0);
@@ -177,6 +186,19 @@ int main(int argc, char **argv) {
   if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch : profile a single variant
     timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), 3, atoi(argv[3]), atoi(argv[4]));
     return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--v4")) {  // generation 4 against its builder-wave experiment
+    const int v[][3] = {{32, 2, 11}, {32, 2, 12}};
+    for (auto &x : v) {
+      fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
+      fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
+      fails += check(5000, 1111, 700, 1, 1, 0, x[0], 1, x[1], x[2]);
+      fails += check(4096, 96, 512, 2, 1, 1, x[0], 0, x[1], x[2]);
+      timeit(8192, 8192, 8192, 64, 1, x[0], 3, x[1], x[2]);
+      timeit(8192, 8192, 8192, 343, 1, x[0], 2, x[1], x[2]);
+    }
+    printf("%s\n", fails ? "LEAF_CHECK FAILED" : "LEAF_CHECK ALL OK");
+    return fails != 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
     const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 4, 7}, {32, 4, 10}, {32, 2, 11}};

@@ -15,3 +15,4 @@ for d in trace pmc_lds pmc_fetch pmc_write; do
 done
 grep -h '"metric"' $O/trace.log | tail -1 > $O/bench_under_trace.json
 ls -la $O
+python $R/tools/make_leaf_traffic.py $O/pmc_fetch.summary.txt $O/pmc_write.summary.txt 65536 $O/leaf_traffic.json "${1:-}"
