@@ -189,7 +189,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk, 32, 2));
+  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk, 32, 1));  // ug 1 = the software-pipelined variant
   else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
   else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   constexpr int R  = 128 * RG;  // tile rows: 128 row groups (8 waves x 16) x RG rows
   constexpr int NG = RG / UG;  // row groups per stage (>= 8: a thread writes one table entry with each of the first 8)
   static_assert(RG % UG == 0 && NG >= 8, "need at least 8 row groups per stage");
+  static_assert(!PIPE || (UG == 1 && RG == 32), "the software-pipelined stage works row by row");
 
   const int tid  = threadIdx.x;
   const int c    = tid & 3;          // 16-byte column slot of the 64-byte table entry
@@ -185,15 +186,19 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     *reinterpret_cast<uint4 *>(wr_base + buf * 65536 + gcode * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
   };
 
-  static_assert(UG == 2 || UG == 4, "the A refill is one 16-byte load per 4 rows");
-  uint32_t areg[RG];
-  auto load_a4 = [&](int g, int q) {
+  static_assert(UG == 1 || UG == 2 || UG == 4, "the A refill is one 16-byte load per 4 rows");
+  // the A dwords of the rows ahead: the whole stage (refilled in place), or -- pipelined variant, which
+  // needs the registers -- a ring of the next 16 rows
+  constexpr int AR = PIPE ? 16 : RG;
+  uint32_t areg[AR];
+  auto load_a4s = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[4*slot ..]
     const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   a_rsrc, (int)(a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u), 0, 0));
-    areg[g * 4 + 0] = v.x; areg[g * 4 + 1] = v.y; areg[g * 4 + 2] = v.z; areg[g * 4 + 3] = v.w;
+    areg[slot * 4 + 0] = v.x; areg[slot * 4 + 1] = v.y; areg[slot * 4 + 2] = v.z; areg[slot * 4 + 3] = v.w;
   };
+  auto load_a4 = [&](int g, int q) { load_a4s(g, g, q); };
 #pragma unroll
-  for (int g = 0; g < RG / 4; ++g) load_a4(g, q_begin);  // q = stage here: one dword of A per stage
+  for (int g = 0; g < AR / 4; ++g) load_a4(g, q_begin);  // q = stage here: one dword of A per stage
 
   // one stage: gather from the four tables of stage s (buffer J = s & 1) while building those of
   // stage s+1 into buffer J^1 and refilling the A registers with stage s+1's dword on the way
@@ -203,6 +208,47 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     // blo_rows = its chain rows, bhi_rows = the base rows of stage s+2.  Nothing but gathers happens
     // right behind the barrier: all 8 waves come out of it together, and whatever non-LDS work sits
     // here (VMEM issue, base XORs) would idle the LDS pipe for every one of them at once.
+    if constexpr (PIPE) {
+      // software-pipelined: row g+1's four gathers are issued BEFORE row g's XORs, so a wave keeps
+      // 4..8 reads in flight while its VALU works (un-pipelined, a wave's LDS latency and its VALU
+      // time add up: ~390 clk per 2-row group against the 288 the LDS array needs)
+      uint4 tp[2][4];
+      auto issue = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t ad = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
+          tp[g & 1][i]      = *reinterpret_cast<const uint4 *>(lds + ad);
+        }
+      };
+      issue(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if (g + 1 < RG) issue(g + 1);
+        if ((g + 2) % 4 == 0) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
+          const int k = (g + 1) / 4, ahead = 4 * k + AR;
+          load_a4s(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
+        }
+        if (g % 2 == 0 && g < 16) put_entry(g / 2, J ^ 1);
+        if (g == 17) load_lo(s + 2);
+        if (g == 21) {
+          make_base();
+          load_hi(s + 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t *a = acc[g];
+        const uint4 *tt = tp[g & 1];
+        a[0] = xor3(xor3(a[0], tt[0].x, tt[1].x), tt[2].x, tt[3].x);
+        a[1] = xor3(xor3(a[1], tt[0].y, tt[1].y), tt[2].y, tt[3].y);
+        a[2] = xor3(xor3(a[2], tt[0].z, tt[1].z), tt[2].z, tt[3].z);
+        a[3] = xor3(xor3(a[3], tt[0].w, tt[1].w), tt[2].w, tt[3].w);
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     uint4 t[4][UG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -325,5 +371,10 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   }
   K8Q_CASE(32, 2) K8Q_CASE(32, 4)
 #undef K8Q_CASE
+  if (rg == 32 && ug == 1) {  // software-pipelined variant
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<32, 1, true, false>), grid, block, 0, stream, a);
+    else             hipLaunchKernelGGL((m4rm8q_kernel<32, 1, true, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   return hipErrorInvalidValue;
 }
