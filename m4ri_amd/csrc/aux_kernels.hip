@@ -320,6 +320,93 @@ extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t s
   return hipGetLastError();
 }
 
+// ---- two levels down on the A side, written straight into the leaf's packed form ------------------
+// The M4RM leaf (generations 3 and 4) reads A chunk-major: A4[q][r] = the q-th 32-bit chunk of row r
+// (m4rm8_leaf.hip).  Producing that layout here saves the separate pack pass -- one read and one
+// write of all 7^L leaf operands, the largest single item of the schedule's HBM traffic.  A
+// workgroup owns a 32-row x 32-chunk tile of the grandchild grid; every one of its 49 outputs goes
+// through a (double-buffered) LDS transpose so that both the reads of the grandparent (128 B per
+// row and block) and the writes of the packed rows (128 B per chunk) are coalesced.
+namespace {
+constexpr int DP_ROWS = 32, DP_V = 8, DP_PITCH = 36;  // tile rows, 16-byte vectors per row, LDS row pitch (dwords)
+
+template <bool ROT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down2_pack_kernel(
+    const word2 *__restrict__ gparent, int64_t p_stride, int64_t p_bs,  // grandparent array (units of word2)
+    uint32_t *__restrict__ a4, int64_t a4_bs,                           // packed grandchildren, a4_bs dwords each
+    int64_t crows, int64_t cw2, int64_t tiles_r, int64_t tiles_w) {     // grandchild: crows x cw2 word2
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][DP_ROWS * DP_PITCH];
+  int64_t bid      = blockIdx.x;
+  const int64_t wt = bid % tiles_w; bid /= tiles_w;
+  const int64_t rt = bid % tiles_r; bid /= tiles_r;
+  const int64_t pi = bid;
+  const int t = threadIdx.x, r = t >> 3, v = t & 7;
+  const word2 *p = gparent + pi * p_bs + (rt * DP_ROWS + r) * p_stride + (wt * DP_V + v);
+  word2 x[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[a][b] = p[(int64_t)a * crows * p_stride + (int64_t)b * cw2];
+  word2 y[4][7];  // y[2a+b][j1]: block (a, b) of child j1
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) winograd_combos<word2, false>(x[a][b], x[a][b + 2], x[a + 2][b], x[a + 2][b + 2], y[2 * a + b]);
+  // write side: thread -> chunk q (0..31 of the tile) and four consecutive rows
+  const int q = t >> 3, r4 = (t & 7) * 4;
+  uint32_t *o = a4 + (pi * 49) * a4_bs + (wt * (DP_V * 4) + q) * crows + rt * DP_ROWS + r4;
+  // generation 4 wants the four index bytes of a dword rotated by (row >> 6) & 3 (m4rm8q_leaf.hip);
+  // the four rows of one store share that value
+  const uint32_t rot = ROT ? (uint32_t)(((rt * DP_ROWS + r4) >> 6) & 3) : 0u;
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word2 g[7];
+    winograd_combos<word2, false>(y[0][j1], y[1][j1], y[2][j1], y[3][j1], g);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      uint32_t *tb = tile[(7 * j1 + j2) & 1];
+      *reinterpret_cast<word2 *>(tb + r * DP_PITCH + 4 * v) = g[j2];
+      __syncthreads();  // one barrier per output: the other buffer is only rewritten after the next one
+      uint4 w;
+      w.x = tb[(r4 + 0) * DP_PITCH + q]; w.y = tb[(r4 + 1) * DP_PITCH + q];
+      w.z = tb[(r4 + 2) * DP_PITCH + q]; w.w = tb[(r4 + 3) * DP_PITCH + q];
+      if (ROT) {
+        w.x = __builtin_amdgcn_alignbyte(w.x, w.x, rot); w.y = __builtin_amdgcn_alignbyte(w.y, w.y, rot);
+        w.z = __builtin_amdgcn_alignbyte(w.z, w.z, rot); w.w = __builtin_amdgcn_alignbyte(w.w, w.w, rot);
+      }
+      *reinterpret_cast<uint4 *>(o + (int64_t)(7 * j1 + j2) * a4_bs) = w;
+    }
+  }
+}
+}  // namespace
+
+// Grandchild i of the pass lands at a4 + i * (crows * cw * 2) dwords, laid out exactly as
+// gf2_launch_a4_pack(_rot) would have packed the row-major grandchild.  Returns
+// hipErrorInvalidValue when the shape does not tile (caller falls back to down2 + pack).
+extern "C" int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4,
+                                          int64_t crows, int64_t cw) {
+  return vec_ok(gparent, p_stride, p_bs, cw, cw) && crows > 0 && cw > 0 && crows % DP_ROWS == 0 && cw % (2 * DP_V) == 0 &&
+         (reinterpret_cast<uintptr_t>(a4) & 15) == 0;
+}
+
+extern "C" hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs,
+                                                     word *a4, int64_t nparents, int64_t crows, int64_t cw, int rot) {
+  if (nparents * crows * cw == 0) return hipSuccess;
+  if (!gf2_winograd_down2_pack_ok(gparent, p_stride, p_bs, a4, crows, cw)) return hipErrorInvalidValue;
+  const int64_t tiles_r = crows / DP_ROWS, tiles_w = (cw / 2) / DP_V;
+  const int64_t grid = nparents * tiles_r * tiles_w;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (rot)
+    hipLaunchKernelGGL((winograd_down2_pack_kernel<true>), dim3((unsigned)grid), dim3(AUX_THREADS), 0, s,
+                       reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<uint32_t *>(a4),
+                       crows * cw * 2, crows, cw / 2, tiles_r, tiles_w);
+  else
+    hipLaunchKernelGGL((winograd_down2_pack_kernel<false>), dim3((unsigned)grid), dim3(AUX_THREADS), 0, s,
+                       reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<uint32_t *>(a4),
+                       crows * cw * 2, crows, cw / 2, tiles_r, tiles_w);
+  return hipGetLastError();
+}
+
 // Two levels per pass.  Grandchildren are crows x cw words, contiguous; a grandparent is 4*crows rows
 // x 4*cw words with row stride p_stride; grandchild 7*j1 + j2 of grandparent i is stored at index
 // 49*i + 7*j1 + j2.

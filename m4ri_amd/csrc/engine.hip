@@ -29,6 +29,9 @@ hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg,
 hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
+int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs, word *a4,
+                                          int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
@@ -135,9 +138,18 @@ size_t packed_a_words(int64_t m, int64_t l, int64_t batch) {
   return a > b ? a : b;
 }
 
+// can a leaf launch of this shape use the packed-A kernel `kind` with the scratch the engine holds?
+bool packed_a_fits(const Engine *e, const LeafKind &kind, int64_t m, int64_t l, int64_t batch) {
+  if (kind.gen < 2 || batch <= 0) return false;
+  const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
+  return e->apk != nullptr && need <= e->apk_words && (uint64_t)need * 8 / (uint64_t)batch < (1ull << 32);
+}
+
+// a_prepacked: the engine's packed-A scratch already holds A in the form the picked kernel reads
+// (written by the fused down pass); A itself is then not touched.
 int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
                 const word *B, int64_t bs, int64_t bbs, int64_t m, int64_t l, int64_t n, int64_t batch,
-                bool add, int ksplit_req) {
+                bool add, int ksplit_req, bool a_prepacked = false) {
   if (m == 0 || n == 0 || batch == 0) return 0;
   if (m > INT32_MAX || l > INT32_MAX || n > INT32_MAX) return (int)hipErrorInvalidValue;
   // 32-bit byte offsets inside one operand (raw buffer addressing)
@@ -175,10 +187,12 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   a.mode  = (add || ksplit > 1) ? 1 : 0;
   // generations 2 and 3 consume A in a packed, chunk-major form (one streaming pass into the call's
   // scratch first); they need that scratch and 32-bit offsets inside one packed operand
-  if (kind.gen >= 2) {
-    const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
-    if (e->apk == nullptr || need > e->apk_words || (uint64_t)need * 8 / (uint64_t)batch >= (1ull << 32)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
+  if (a_prepacked) {
+    if (kind.gen < 3 || !packed_a_fits(e, kind, m, l, batch)) return (int)hipErrorInvalidValue;  // caller checked
+  } else if (kind.gen >= 2) {
+    if (!packed_a_fits(e, kind, m, l, batch)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
+      const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
       if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen == 4));
       else HIPTRY(gf2_launch_a7_pack(st, a, e->apk));
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
@@ -242,13 +256,26 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // materialised, which saves its buffers and 38 % of the traffic of the two largest levels.
   const bool fuse2 = L >= 2;
   auto skipped = [&](int d) { return fuse2 && d == L - 1; };
+  // With a fused last pass and a leaf that reads packed A, the pass writes the packed form itself:
+  // the row-major A operands of the leaves are never materialised and the pack pass disappears.
+  const LeafKind leaf_kind = pick_leaf(m >> L);
+  bool prepack = false;
+  if (fuse2 && leaf_kind.gen >= 3) {
+    static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
+    const int d0      = L - 2;
+    const word *pa    = d0 == 0 ? A.p : aligned16;  // deeper levels live in the 256-byte aligned workspace
+    const int64_t pas = d0 == 0 ? A.stride : (l >> d0) / 64;
+    const uint64_t a4_bytes = (uint64_t)gf2_m4rm8_a4_words(m >> L, l >> L, 1) * 8;  // one packed operand: 32-bit offsets
+    prepack = a4_bytes < (1ull << 32) &&
+              gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? 0 : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0;
+  }
   // workspace plan
   size_t need = 0;
   auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
   for (int d = 1; d <= L; ++d) {
     if (skipped(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
-    need += pad((size_t)cnt * md * wl) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
+    need += (prepack && d == L ? 0 : pad((size_t)cnt * md * wl)) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
   {
     const size_t a7_bfs = packed_a_words(m >> L, l >> L, ipow7(L));
@@ -259,10 +286,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   e->apk = ws_take(e, a7_extra);
   e->apk_words = a7_extra;
   std::vector<word *> Al(L + 1, nullptr), Bl(L + 1, nullptr), Pl(L + 1, nullptr);
+  if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, ipow7(L))) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
   for (int d = 1; d <= L; ++d) {
     if (skipped(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
-    Al[d] = ws_take(e, (size_t)cnt * md * wl);
+    if (!(prepack && d == L)) Al[d] = ws_take(e, (size_t)cnt * md * wl);
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
   }
@@ -277,7 +305,8 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
     if (step == 2) {
-      HIPTRY(gf2_launch_winograd_down2(st, 0, pa, pas, pabs, Al[d + 2], cnt, cm, cl / 64));
+      if (prepack) HIPTRY(gf2_launch_winograd_down2_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, leaf_kind.gen == 4));
+      else HIPTRY(gf2_launch_winograd_down2(st, 0, pa, pas, pabs, Al[d + 2], cnt, cm, cl / 64));
       HIPTRY(gf2_launch_winograd_down2(st, 1, pb, pbs, pbbs, Bl[d + 2], cnt, cl, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * 65.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 16 in + 49 out
     } else {
@@ -291,7 +320,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   {
     const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = ipow7(L);
     if (int rc = launch_leaf(e, st, Pl[L], ln / 64, lm * (ln / 64), Al[L], ll / 64, lm * (ll / 64), Bl[L], ln / 64,
-                             ll * (ln / 64), lm, ll, ln, cnt, false, 1))
+                             ll * (ln / 64), lm, ll, ln, cnt, false, 1, prepack))
       return rc;
   }
   // up passes: level d+1 -> d, or d+2 -> d for the fused pair at the bottom (done first)

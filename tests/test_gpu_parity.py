@@ -300,3 +300,24 @@ def test_device_views_and_ragged_strassen(oracle):
     want = oracle.mul(None, hA, hB, 8192)
     assert got.equal(want)
     assert np.all(got.rows()[:, got.width:] == 0)  # padding words never written
+
+
+@pytest.mark.parametrize("m,l,n,cutoff,a_shift,leaf_gen", [
+    (8192, 8192, 8192, 2048, 0, 3),    # two fused levels, 2048-row leaves: pass writes generation 3's packed A
+    (16384, 4096, 4096, 1024, 0, 4),   # 4096-row leaves: generation 4's rotated packed A, short inner dimension
+    (8192, 5120, 8192, 1024, 0, 3),    # 20-word leaf rows do not tile the fused pass: down2 + separate pack
+    (8192, 8192, 8192, 2048, 1, 3),    # A view starting one word into its rows (8-byte aligned, odd stride)
+])
+def test_fused_down_pack_paths(oracle, m, l, n, cutoff, a_shift, leaf_gen):
+    """The last A-side pass of the breadth-first schedule writes the leaf's packed operand directly
+    (engine.hip bfs_product); shapes and views that cannot take it fall back to pass + pack."""
+    hA, hB = Mzd.random(m, l, 61), Mzd.random(l, n, 62)
+    wa, wn = hA.rowstride, hB.rowstride
+    At = torch.zeros((m, wa + a_shift), dtype=torch.int64, device="cuda")
+    At[:, a_shift:] = torch.from_numpy(hA.rows().view(np.int64).copy()).cuda()
+    B = torch.from_numpy(hB.rows().view(np.int64).copy()).cuda()
+    C = torch.empty((m, wn), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), wn, At.data_ptr() + 8 * a_shift, wa + a_shift, B.data_ptr(), wn, m, l, n, cutoff=cutoff)
+    st = m4ri_amd.get_stats()
+    assert st.levels == 2 and st.leaf_gen == leaf_gen
+    assert to_host(C, m, n).equal(oracle.mul(None, hA, hB, cutoff))
