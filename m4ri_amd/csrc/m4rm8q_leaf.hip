@@ -30,6 +30,11 @@
 #include <type_traits>
 #include "gf2_common.h"
 
+// first row of a stage whose XORs are followed by a table write (8 writes, every other row)
+#ifndef K8Q_PUT_START
+#define K8Q_PUT_START 0
+#endif
+
 namespace {
 
 constexpr int K8_BITS  = 8;             // bits per table index
@@ -229,9 +234,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
           const int k = (g + 1) / 4, ahead = 4 * k + AR;
           load_a4s(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
         }
-        if (g % 2 == 0 && g < 16) put_entry(g / 2, J ^ 1);
-        if (g == 17) load_lo(s + 2);
-        if (g == 21) {
+        if (g >= K8Q_PUT_START && (g - K8Q_PUT_START) % 2 == 0 && g < K8Q_PUT_START + 16) put_entry((g - K8Q_PUT_START) / 2, J ^ 1);
+        if (g == K8Q_PUT_START + 17) load_lo(s + 2);
+        if (g == K8Q_PUT_START + 21) {
           make_base();
           load_hi(s + 3);
         }
@@ -369,7 +374,7 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
     else             hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, true>), grid, block, 0, stream, a);  \
     return hipGetLastError();                                                                     \
   }
-  K8Q_CASE(32, 2) K8Q_CASE(32, 4)
+  K8Q_CASE(32, 2)
 #undef K8Q_CASE
   if (rg == 32 && ug == 1) {  // software-pipelined variant
     if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<32, 1, true, false>), grid, block, 0, stream, a);

@@ -27,14 +27,11 @@
 #include <hip/hip_runtime.h>
 #include "gf2_common.h"
 
-// (rg, ug, variant) instantiations.  variant bit 0 = software-pipelined gathers, bit 1 = B rows staged
-// through LDS; both were measured and are not instantiated in the product.
-#ifndef LEAF_VARIANTS
-#define LEAF_VARIANTS(X) \
-  X(32, 4, 0) X(24, 4, 0) X(16, 4, 0)
-#endif
+// (rg, ug) instantiations.  Two variants of this kernel were measured and removed again: software-
+// pipelined gathers (two register sets; +-1 %) and B rows staged once per workgroup through LDS
+// (-3 %); DESIGN.md 3.1 has the table.
+#define LEAF_VARIANTS(X) X(32, 4) X(24, 4) X(16, 4)
 #define LEAF_DEFAULT_UG(rg) 4
-#define LEAF_DEFAULT_PIPE(rg) 0
 
 namespace {
 
@@ -61,12 +58,9 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int z) {
   return 0x0c000000u | ((z ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
-template <int RG, int UG, int VAR, bool XOR_OUT>
+template <int RG, int UG, bool XOR_OUT>
 __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs p) {
-  constexpr bool PIPE    = (VAR & 1) != 0;  // software-pipelined use phase
-  constexpr bool STAGE_B = (VAR & 2) != 0;  // B rows staged once per workgroup through LDS
-  constexpr int STG_OFF  = LEAF_NT * 65536; // staging area behind the tables: 2 buffers x 4 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LEAF_NT * 65536 + (STAGE_B ? 2 * 4096 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LEAF_NT * 65536];
   constexpr int R = 32 * RG;  // tile rows: 32 row groups (8 waves x 4) x RG rows
 
   const int tid  = threadIdx.x;
@@ -124,7 +118,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
   // stored).
   uint4 brow[8];
   const uint32_t b_lane = (uint32_t)bz * 8u * b_rs + (uint32_t)w0 * 8u;
-  auto load_b = [&](int s) {  // direct variant: every thread fetches its 8 rows itself (16x redundant)
+  auto load_b = [&](int s) {  // every thread fetches its 8 rows itself (16x redundant, L1/L2 hits)
     // one running offset VGPR (the empty asm keeps hipcc from materialising 8 hoisted offsets)
     uint32_t off = b_lane + (uint32_t)s * LEAF_STAGE * b_rs;
 #pragma unroll
@@ -134,25 +128,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
       asm volatile("" : "+v"(off));
     }
   };
-  // staged variant: the 16 rows x 256 B of a stage are fetched ONCE per workgroup -- 8 bytes per
-  // thread, row tid>>5, word tid&31 -- parked in a 2-deep LDS ring one stage ahead, and every
-  // thread picks its 8 rows up from there at build time.  Costs 64 extra ds_read_b128 per stage
-  // (+8 % LDS work) and buys back 1024 clk/stage of texture-addresser time, ~270 clk of VMEM issue
-  // per wave in the build phase, and 28 VGPRs during the use phase.
-  uint2 bpiece = make_uint2(0u, 0u);
-  const uint32_t s_lane = (uint32_t)(tid >> 5) * b_rs + (uint32_t)(tile_n * LEAF_TW + (tid & 31)) * 8u;
-  unsigned char *const stg_wr = lds + STG_OFF + (tid >> 5) * 256 + (tid & 31) * 8;
-  const unsigned char *const stg_rd = lds + STG_OFF + bz * 8 * 256 + c * 16;
-  auto fetch_piece = [&](int s) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b64(b_rsrc, (int)(s_lane + (uint32_t)s * LEAF_STAGE * b_rs), 0, 0);
-    bpiece = __builtin_bit_cast(uint2, v);
-  };
-  auto park_piece = [&](int s) { *reinterpret_cast<uint2 *>(stg_wr + (s & 1) * 4096) = bpiece; };
-  auto pick_rows = [&](int s) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) brow[j] = *reinterpret_cast<const uint4 *>(stg_rd + (s & 1) * 4096 + j * 256);
-  };
-
   uint32_t areg[RG];
   const uint32_t a_lane = (uint32_t)row0 * a_rs;
   auto load_a = [&](int q) {
@@ -165,14 +140,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
     }
   };
 
-  if constexpr (STAGE_B) {
-    fetch_piece(s_begin);
-    park_piece(s_begin);
-    fetch_piece(s_begin + 1);
-    __syncthreads();
-  } else {
-    if (s_begin < s_end) load_b(s_begin);
-  }
+  if (s_begin < s_end) load_b(s_begin);
 
   for (int q = s_begin >> 1; 2 * q < s_end; ++q) {
     load_a(q);
@@ -184,7 +152,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
         // the B rows become visible to the optimiser only HERE (volatile asm stays behind the
         // preceding barrier): otherwise hipcc hoists this build's first XORs up to where the rows
         // were requested, one use phase earlier, and waits out the whole load latency there.
-        if constexpr (STAGE_B) pick_rows(s);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           asm volatile("" : "+v"(brow[j].x), "+v"(brow[j].y), "+v"(brow[j].z), "+v"(brow[j].w));
@@ -220,65 +187,44 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
       // check): a branch makes hipcc resolve the merge with v_movs of the loaded registers, i.e.
       // an immediate vmcnt(0).  The sched_barriers keep the next build's XORs from being hoisted up
       // to the loads.
-      if constexpr (!STAGE_B) load_b(s + 1);
+      load_b(s + 1);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (STAGE_B) {
-        // rows of stage s+1 (requested one stage ago) go into the ring slot the build of stage
-        // s-1 has finished with; then request stage s+2.  One ds_write_b64 + one buffer_load per
-        // thread, overlapping the gathers below.
-        park_piece(s + 1);
-        fetch_piece(s + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       // ---------------- use: RG rows x 2 lookups ------------------------------------------
-      // Rows go through in groups of UG: 2*UG ds_read_b128 per group.  PIPE issues group g+1's
-      // reads before folding group g into the accumulators (two register sets), so the LDS queue
-      // never drains while a wave does its XORs.  The sched_barriers pin that shape: un-pinned,
-      // hipcc hoists every read of the phase above the XORs and spills the tile.
+      // Rows go through in groups of UG: 2*UG ds_read_b128 per group, then their XORs.  The
+      // sched_barriers pin that shape: un-pinned, hipcc hoists every read of the phase above the
+      // XORs and spills the tile.
       static_assert(RG % UG == 0, "RG must be a multiple of UG");
       constexpr int NG = RG / UG;
-      uint4 t0[PIPE ? 2 : 1][UG], t1[PIPE ? 2 : 1][UG];
-      auto issue = [&](int g, int slot) {
+      uint4 t0[UG], t1[UG];
+      auto issue = [&](int g) {
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           const uint32_t a0 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, perm_sel(2 * half + 0, 0));
           const uint32_t a1 = __builtin_amdgcn_perm(areg[g * UG + u], coloff, perm_sel(2 * half + 1, 1));
-          t0[slot][u]       = *reinterpret_cast<const uint4 *>(lds + a0);
-          t1[slot][u]       = *reinterpret_cast<const uint4 *>(lds + a1);
+          t0[u]             = *reinterpret_cast<const uint4 *>(lds + a0);
+          t1[u]             = *reinterpret_cast<const uint4 *>(lds + a1);
         }
       };
-      auto fold = [&](int g, int slot) {
+      auto fold = [&](int g) {
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           uint32_t *a = acc[g * UG + u];
-          a[0] = xor3(a[0], t0[slot][u].x, t1[slot][u].x);
-          a[1] = xor3(a[1], t0[slot][u].y, t1[slot][u].y);
-          a[2] = xor3(a[2], t0[slot][u].z, t1[slot][u].z);
-          a[3] = xor3(a[3], t0[slot][u].w, t1[slot][u].w);
+          a[0] = xor3(a[0], t0[u].x, t1[u].x);
+          a[1] = xor3(a[1], t0[u].y, t1[u].y);
+          a[2] = xor3(a[2], t0[u].z, t1[u].z);
+          a[3] = xor3(a[3], t0[u].w, t1[u].w);
           // pin the accumulation here: XOR is associative, and without this hipcc re-associates
           // the whole phase into one late XOR tree and keeps every loaded table row live.
           asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
         }
       };
-      if constexpr (PIPE) {
-        issue(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        issue(g);
+        fold(g);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) issue(g + 1, (g + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          fold(g, g & 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          issue(g, 0);
-          fold(g, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -315,8 +261,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm_leaf_kernel(const LeafArgs 
 
 }  // namespace
 
-// Host launcher.  rg: tile height / 32 (rows = 32*rg); ug: rows per read group; pipe: software-
-// pipelined use phase.  ug == 0 picks the tuned default for rg.
+// Host launcher.  rg: tile height / 32 (rows = 32*rg); ug: rows per read group, 0 picks the tuned
+// default for rg.  (`pipe` is what is left of the removed variants' selector: must be 0.)
 extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs a, int rg, int ug, int pipe) {
   const int R = 32 * rg;
   a.wn        = (int32_t)words_of(a.n);
@@ -335,12 +281,13 @@ extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs 
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
-  if (ug == 0) { ug = LEAF_DEFAULT_UG(rg); pipe = LEAF_DEFAULT_PIPE(rg); }
-#define LEAF_CASE(RGV, UGV, PV)                                                                        \
-  if (rg == RGV && ug == UGV && pipe == PV) {                                                          \
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV, false>), grid, block, 0, stream, a); \
-    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, PV, true>), grid, block, 0, stream, a);  \
-    return hipGetLastError();                                                                          \
+  if (ug == 0) ug = LEAF_DEFAULT_UG(rg);
+  if (pipe != 0) return hipErrorInvalidValue;
+#define LEAF_CASE(RGV, UGV)                                                                        \
+  if (rg == RGV && ug == UGV) {                                                                      \
+    if (a.mode == 0) hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, false>), grid, block, 0, stream, a); \
+    else             hipLaunchKernelGGL((m4rm_leaf_kernel<RGV, UGV, true>), grid, block, 0, stream, a);  \
+    return hipGetLastError();                                                                      \
   }
   LEAF_VARIANTS(LEAF_CASE)
 #undef LEAF_CASE
