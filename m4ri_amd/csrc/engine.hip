@@ -32,7 +32,7 @@ hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, i
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
-hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
+hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
@@ -114,10 +114,10 @@ hipEvent_t take_event(Engine *e) {
 // ---- leaf launch ------------------------------------------------------------------------------
 // Four generations of the leaf kernel exist (m4rm8q / m4rm8 / m4rm7 / m4rm_leaf); they differ in tile
 // shape (4096x512, 2048x1024, 1024x2048 and shorter) and in measured throughput on full tiles
-// (8192^3 batches: 5.7 / 5.3 / 4.8 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time
+// (8192^3 batches: 6.7 / 5.3 / 4.7 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time
 // on padded rows.
 struct LeafKind { int gen; int rg; int rows; double rate; };
-const LeafKind LEAF_KINDS[6] = {{4, 32, 4096, 5.7}, {3, 32, 2048, 5.3}, {2, 32, 1024, 4.8},
+const LeafKind LEAF_KINDS[6] = {{4, 32, 4096, 6.7}, {3, 32, 2048, 5.3}, {2, 32, 1024, 4.7},
                                 {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
 constexpr int LEAF_KIND_FALLBACK = 3;  // generation 1, 1024 rows: needs no packed A
 
@@ -203,7 +203,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk, 32, 1));  // ug 1 = the software-pipelined variant
+  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk));
   else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
   else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));

@@ -1,5 +1,6 @@
 // m4rm8q_leaf.hip -- M4RM leaf, generation 4: 8-bit tables with 64-byte entries, FOUR tables
-// interleaved per LDS bank row, double-buffered, every wave symmetric.
+// interleaved per LDS bank row, double-buffered, software-pipelined gathers, table building on the
+// four older waves.
 //
 // One more turn of generation 3's screw (m4rm8_leaf.hip).  The leaf is bound by LDS-array cycles,
 // and for a tile of fixed area the gathers cost the same while the table writes shrink with the
@@ -9,20 +10,29 @@
 //     entry 128 B (gen 3): 2048 x 1024 tile, 2560 clk per 16 inner bits  -> 160 clk/bit
 //     entry  64 B (here) : 4096 x  512 tile, 4608 clk per 32 inner bits  -> 144 clk/bit
 //
-// A stage is now a whole 32-bit word of A = four 256-entry tables (4 x 16 KiB), two stages resident.
+// A stage is a whole 32-bit word of A = four 256-entry tables (4 x 16 KiB), two stages resident.
 //   * LDS bank row x holds [T0[x] | T1[x] | T2[x] | T3[x]], 64 bytes each.
 //   * lane = (row group lane>>2, 16-byte slot lane&3).  A row takes four gathers per stage; in
 //     gather i the row group reads table (rot + i) & 3 with rot = (row group >> 1) & 3.  Each of
 //     ds_read_b128's four 16-lane service groups holds four row groups -- {0,3,5,6}, {1,2,4,7},
 //     {8,11,13,14}, {9,10,12,15} -- whose `rot` values are 0,1,2,3 in every case, so the four row
 //     groups always sit in four different quarters of the bank row: conflict-free for ANY indices.
-//   * per stage a thread still builds 8 entries of one table from 8 rows of B, so B traffic per
-//     inner bit HALVES; barriers per inner bit halve too.
+//   * The packed A (a4_pack_kernel of m4rm8_leaf.hip, or the fused Winograd pass of aux_kernels.hip)
+//     holds a row's four index bytes already rotated by `rot`, so byte i of the dword IS gather i's
+//     index and the four v_perm selectors are compile-time constants.
+//   * Software pipeline: row g+1's four gathers are issued before row g's XORs, so a wave keeps
+//     4..8 reads in flight while its VALU works; the A dwords live in a ring of the next 16 rows.
+//   * Table building belongs to waves 0..3 (16 entries per thread and stage: 4 B rows for the
+//     base, 4 for a 4-bit Gray chain).  On every SIMD the wave dispatched first wins issue
+//     arbitration; with symmetric work it reached the stage's barrier ~15 % early and idled there.
+//     Giving it ALL of the building (B loads, base XORs, chain XORs, ds_writes) evens the two out:
+//     -6.5 % on the launch.  (The younger waves as builders: no gain.)  16 consecutive builder lanes
+//     = 4 slots x 4 tables of ONE entry index = one whole bank row per ds_write service group, so
+//     the table writes are conflict-free as well.
 //
 // Everything else is generation 3's: C-stationary tile in VGPRs (128 dwords per lane), one
-// v_perm_b32 per lookup address (per-lane selector), one v_bitop3_b32 per dword folds two lookups,
-// Gray-code table build, chunk-major A (a4_pack_kernel of m4rm8_leaf.hip), range-checked buffer
-// descriptors, one barrier per stage.
+// v_perm_b32 per lookup address, one v_bitop3_b32 per dword folds two lookups, Gray-code table
+// build, chunk-major A, range-checked buffer descriptors, one barrier per stage.
 //
 // Replaces (result-identical) _mzd_mul_m4rm, mzd_make_table and _mzd_combine_N of the reference
 // (/root/reference m4ri/brilliantrussian.c:1032-1190, :163-211, m4ri/xor_template.h:12-227).
@@ -30,9 +40,9 @@
 #include <type_traits>
 #include "gf2_common.h"
 
-// first row of a stage whose XORs are followed by a table write (8 writes, every other row)
-#ifndef K8Q_PUT_START
-#define K8Q_PUT_START 0
+// which half of the workgroup builds the tables: 0 = waves 0..3 (dispatched first), 1 = waves 4..7
+#ifndef K8Q_BUILDER_HALF
+#define K8Q_BUILDER_HALF 0
 #endif
 
 namespace {
@@ -41,6 +51,9 @@ constexpr int K8_BITS  = 8;             // bits per table index
 constexpr int K8_STAGE = 4 * K8_BITS;   // inner bits per stage (four tables) = one dword of A
 constexpr int K8_CHUNK = K8_STAGE;      // inner bits per A dword
 constexpr int K8_TW    = 8;             // tile width in words (512 columns, 64 B per entry)
+constexpr int K8_RG    = 32;            // rows per lane
+constexpr int K8_R     = 128 * K8_RG;   // tile rows: 128 row groups (8 waves x 16) x 32 rows
+constexpr int K8_AR    = 16;            // rows of A held ahead (ring)
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
@@ -58,28 +71,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, ui
 }
 
 // v_perm_b32(a, coloff, sel): byte j of a -> bits 8..15 (table index), coloff.byte0 -> bits 0..7
-// (table half + column slot), buffer -> bit 16 (taken from coloff.byte1 == 0x01)
+// (table quarter + column slot), buffer -> bit 16 (taken from coloff.byte1 == 0x01)
 __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int buf) {
   return 0x0c000000u | ((buf ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
-template <int RG, int UG, bool PIPE, bool XOR_OUT>
+template <bool XOR_OUT>
 __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|T1|T2|T3][64 B]
-  constexpr int R  = 128 * RG;  // tile rows: 128 row groups (8 waves x 16) x RG rows
-  constexpr int NG = RG / UG;  // row groups per stage (>= 8: a thread writes one table entry with each of the first 8)
-  static_assert(RG % UG == 0 && NG >= 8, "need at least 8 row groups per stage");
-  static_assert(!PIPE || (UG == 1 && RG == 32), "the software-pipelined stage works row by row");
+  constexpr int RG = K8_RG, AR = K8_AR;
 
   const int tid  = threadIdx.x;
   const int c    = tid & 3;          // 16-byte column slot of the 64-byte table entry
   const int rgrp = tid >> 2;         // row group 0..127
   const int rot  = (tid >> 3) & 3;   // table this lane reads in the FIRST of a row's four gathers
-  // build role: 16 consecutive lanes = 4 slots x 4 tables of ONE entry index, i.e. one whole 256-byte
-  // bank row per ds_write_b128 service group -- conflict-free (one table per wave put 4 rows on the
-  // same 16 banks: SQ_LDS_BANK_CONFLICT showed 8 extra clocks per write, 11 % of the LDS time)
+  // build role (builder waves only): 16 consecutive lanes = 4 slots x 4 tables of one entry index
   const int bz   = (tid >> 2) & 3;   // table 0..3 of the stage
-  const int bhi  = tid >> 4;         // bits 3..7 of the entries this thread writes
+  const int bhi  = (tid >> 4) & 15;  // bits 4..7 of the 16 entries this thread writes
 
   // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
   // remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8 XCDs)
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const int w0   = tile_n * K8_TW + c * 2;  // this lane's two words of the row
   const bool v0  = w0 < p.wn;
   const bool v1  = (w0 + 1) < p.wn;
-  const int row0 = tile_m * R + rgrp * RG;
+  const int row0 = tile_m * K8_R + rgrp * RG;
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
@@ -116,13 +124,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // scratch reload + vmcnt(0), i.e. a full drain of the A/B prefetches, twice per stage pair
   const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(tile_n) * (K8_TW * 8u);
   const uint32_t b_slot = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)c * 16u;
-  // per-lane perm operands for gather i (table (rot+i)&3 = index byte (rot+i)&3 of the A dword):
-  // coloff byte0 = table quarter (0/64/128/192) + column slot, byte1 = 0x01 (buffer bit source)
-  // (the packed A holds a row's four index bytes already rotated by `rot`, so byte i is gather i's)
+  // per-lane perm operand of gather i: byte0 = table quarter ((rot + i) & 3) * 64 + column slot,
+  // byte1 = 0x01 (buffer bit source)
   uint32_t coloff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) coloff[i] = (uint32_t)(((rot + i) & 3) * 64 + c * 16) | 0x0100u;
-  unsigned char *const wr_base = lds + bhi * 8 * 256 + bz * 64 + c * 16;
+  unsigned char *const wr_base = lds + bhi * 16 * 256 + bz * 64 + c * 16;
 
   uint32_t acc[RG][4];
 #pragma unroll
@@ -132,14 +139,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   int q_end         = q_begin + p.chunks_per_split;
   if (q_end > nq) q_end = nq;
 
-  // B rows of the table this thread helps to build: rows 3..6 of the 7 (-> base) and rows 0..2
+  // B rows of the table this thread helps to build: rows 4..7 of the 8 (-> base) and rows 0..3
   // (-> Gray chain).  Columns outside the matrix may hold a neighbour's bits when B is a window;
   // they only reach C columns that are never stored.
-  uint4 bhi_rows[5], blo_rows[3];
+  uint4 bhi_rows[4], blo_rows[4];
   auto load_hi = [&](int stage) {
-    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 3u) * b_rs) + b_slot;
+    uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 4u) * b_rs) + b_slot;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 4; ++j) {
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
       off += b_rs;
       asm volatile("" : "+v"(off));  // one running offset VGPR instead of hoisted per-row offsets
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   auto load_lo = [&](int stage) {
     uint32_t off = (b_uni + (uint32_t)stage * K8_STAGE * b_rs) + b_slot;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 4; ++j) {
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
       off += b_rs;
       asm volatile("" : "+v"(off));
@@ -159,11 +166,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     // the rows become visible to the optimiser only here (volatile asm stays behind the previous
     // barrier); un-pinned, hipcc hoists these XORs up to the loads and waits out their latency
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < 4; ++j)
       asm volatile("" : "+v"(bhi_rows[j].x), "+v"(bhi_rows[j].y), "+v"(bhi_rows[j].z), "+v"(bhi_rows[j].w));
     cur[0] = cur[1] = cur[2] = cur[3] = 0u;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const bool on = (bhi >> j) & 1;
       cur[0] ^= on ? bhi_rows[j].x : 0u;
       cur[1] ^= on ? bhi_rows[j].y : 0u;
@@ -171,13 +178,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
       cur[3] ^= on ? bhi_rows[j].w : 0u;
     }
   };
-  // entry number i (0..7) of the thread's 8: Gray step + one ds_write_b128 into buffer `buf`
+  // entry number i (0..15) of the thread's 16: Gray step + one ds_write_b128 into buffer `buf`
   auto put_entry = [&](int i, int buf) {
     if (i > 0) {
       const int j = __builtin_ctz(i);
       if (i == 1) {
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
           asm volatile("" : "+v"(blo_rows[jj].x), "+v"(blo_rows[jj].y), "+v"(blo_rows[jj].z), "+v"(blo_rows[jj].w));
       }
       cur[0] ^= blo_rows[j].x;
@@ -191,129 +198,95 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     *reinterpret_cast<uint4 *>(wr_base + buf * 65536 + gcode * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
   };
 
-  static_assert(UG == 1 || UG == 2 || UG == 4, "the A refill is one 16-byte load per 4 rows");
-  // the A dwords of the rows ahead: the whole stage (refilled in place), or -- pipelined variant, which
-  // needs the registers -- a ring of the next 16 rows
-  constexpr int AR = PIPE ? 16 : RG;
+  // the A dwords of the next 16 rows (a whole stage would cost the registers the pipeline needs)
   uint32_t areg[AR];
-  auto load_a4s = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[4*slot ..]
+  auto load_a4 = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[4*slot ..]
     const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   a_rsrc, (int)(a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u), 0, 0));
     areg[slot * 4 + 0] = v.x; areg[slot * 4 + 1] = v.y; areg[slot * 4 + 2] = v.z; areg[slot * 4 + 3] = v.w;
   };
-  auto load_a4 = [&](int g, int q) { load_a4s(g, g, q); };
 #pragma unroll
-  for (int g = 0; g < AR / 4; ++g) load_a4(g, q_begin);  // q = stage here: one dword of A per stage
+  for (int g = 0; g < AR / 4; ++g) load_a4(g, g, q_begin);  // q = stage here: one dword of A per stage
 
-  // one stage: gather from the four tables of stage s (buffer J = s & 1) while building those of
-  // stage s+1 into buffer J^1 and refilling the A registers with stage s+1's dword on the way
-  auto stage = [&](auto jtag, int s) {
-    constexpr int J = decltype(jtag)::value;
-    // on entry: cur = base of this thread's table of stage s+1 (made late in the previous stage),
-    // blo_rows = its chain rows, bhi_rows = the base rows of stage s+2.  Nothing but gathers happens
-    // right behind the barrier: all 8 waves come out of it together, and whatever non-LDS work sits
-    // here (VMEM issue, base XORs) would idle the LDS pipe for every one of them at once.
-    if constexpr (PIPE) {
-      // software-pipelined: row g+1's four gathers are issued BEFORE row g's XORs, so a wave keeps
-      // 4..8 reads in flight while its VALU works (un-pipelined, a wave's LDS latency and its VALU
-      // time add up: ~390 clk per 2-row group against the 288 the LDS array needs)
-      uint4 tp[2][4];
-      auto issue = [&](int g) {
+  // one stage: gather from the four tables of stage s (buffer J = s & 1) while the builder waves
+  // write those of stage s+1 into buffer J^1
+  auto stage = [&](auto jtag, auto btag, int s) {
+    constexpr int J        = decltype(jtag)::value;
+    constexpr bool BUILDER = decltype(btag)::value;
+    // builder, on entry: cur = base of this thread's table of stage s+1 (made late in the previous
+    // stage), blo_rows = its chain rows, bhi_rows = the base rows of stage s+2
+    uint4 tp[2][4];
+    auto issue = [&](int g) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t ad = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
-          tp[g & 1][i]      = *reinterpret_cast<const uint4 *>(lds + ad);
-        }
-      };
-      issue(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if (g + 1 < RG) issue(g + 1);
-        if ((g + 2) % 4 == 0) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
-          const int k = (g + 1) / 4, ahead = 4 * k + AR;
-          load_a4s(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
-        }
-        if (g >= K8Q_PUT_START && (g - K8Q_PUT_START) % 2 == 0 && g < K8Q_PUT_START + 16) put_entry((g - K8Q_PUT_START) / 2, J ^ 1);
-        if (g == K8Q_PUT_START + 17) load_lo(s + 2);
-        if (g == K8Q_PUT_START + 21) {
-          make_base();
-          load_hi(s + 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t *a = acc[g];
-        const uint4 *tt = tp[g & 1];
-        a[0] = xor3(xor3(a[0], tt[0].x, tt[1].x), tt[2].x, tt[3].x);
-        a[1] = xor3(xor3(a[1], tt[0].y, tt[1].y), tt[2].y, tt[3].y);
-        a[2] = xor3(xor3(a[2], tt[0].z, tt[1].z), tt[2].z, tt[3].z);
-        a[3] = xor3(xor3(a[3], tt[0].w, tt[1].w), tt[2].w, tt[3].w);
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t ad = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
+        tp[g & 1][i]      = *reinterpret_cast<const uint4 *>(lds + ad);
       }
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      return;
-    }
-    uint4 t[4][UG];
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-      for (int u = 0; u < UG; ++u) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t ad = __builtin_amdgcn_perm(areg[g * UG + u], coloff[i], perm_sel(i, J));
-          t[i][u]           = *reinterpret_cast<const uint4 *>(lds + ad);
-        }
+    for (int g = 0; g < RG; ++g) {
+      if (g + 1 < RG) issue(g + 1);
+      if ((g + 2) % 4 == 0) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
+        const int k = (g + 1) / 4, ahead = 4 * k + AR;
+        load_a4(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
       }
-      // these rows' indices are out: refill their A registers with the next stage's dword right
-      // away (one 16-byte load per 4 rows)
-      if ((g * UG) % 4 + UG == 4) load_a4((g * UG) / 4, s + 1);
-      // the 8 table entries go out with the FIRST 8 groups, so the chain rows are dead early and
-      // their successors (first needed one group into the next stage) get most of a stage to arrive
-      if (g < 8) put_entry(g, J ^ 1);
-      if (g == 8 || (NG == 8 && g == 7)) load_lo(s + 2);
-      if (g == (NG > 10 ? 10 : NG - 1)) {
-        make_base();     // base of stage s+2's table (its entries are written during stage s+1)
-        load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
+      if constexpr (BUILDER) {
+        // the 16 table entries go out with the first 16 rows, so the chain rows are dead early and
+        // their successors (first needed two rows into the next stage) get half a stage to arrive
+        if (g < 16) put_entry(g, J ^ 1);
+        if (g == 17) load_lo(s + 2);
+        if (g == 21) {
+          make_base();     // base of stage s+2's table (its entries are written during stage s+1)
+          load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < UG; ++u) {
-        uint32_t *a = acc[g * UG + u];
-        a[0] = xor3(xor3(a[0], t[0][u].x, t[1][u].x), t[2][u].x, t[3][u].x);
-        a[1] = xor3(xor3(a[1], t[0][u].y, t[1][u].y), t[2][u].y, t[3][u].y);
-        a[2] = xor3(xor3(a[2], t[0][u].z, t[1][u].z), t[2][u].z, t[3][u].z);
-        a[3] = xor3(xor3(a[3], t[0][u].w, t[1][u].w), t[2][u].w, t[3][u].w);
-        // pin the accumulation here (XOR is associative: un-pinned, hipcc re-associates the whole
-        // stage into one late XOR tree and keeps every loaded table row live)
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-      }
+      uint32_t *a     = acc[g];
+      const uint4 *tt = tp[g & 1];
+      a[0] = xor3(xor3(a[0], tt[0].x, tt[1].x), tt[2].x, tt[3].x);
+      a[1] = xor3(xor3(a[1], tt[0].y, tt[1].y), tt[2].y, tt[3].y);
+      a[2] = xor3(xor3(a[2], tt[0].z, tt[1].z), tt[2].z, tt[3].z);
+      a[3] = xor3(xor3(a[3], tt[0].w, tt[1].w), tt[2].w, tt[3].w);
+      // pin the accumulation here (XOR is associative: un-pinned, hipcc re-associates the whole
+      // stage into one late XOR tree and keeps every loaded table row live)
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if (q_begin < q_end) {
-    // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
-    load_hi(q_begin);
-    load_lo(q_begin);
-    make_base();
+  // the two roles are two loops (wave-uniform branch), so each gets its own register allocation:
+  // the gather-only waves carry no B rows at all
+  auto run = [&](auto btag) {
+    constexpr bool BUILDER = decltype(btag)::value;
+    if constexpr (BUILDER) {
+      // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
+      load_hi(q_begin);
+      load_lo(q_begin);
+      make_base();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) put_entry(i, 0);
-    load_hi(q_begin + 1);
-    load_lo(q_begin + 1);
-    make_base();
-    load_hi(q_begin + 2);
+      for (int i = 0; i < 16; ++i) put_entry(i, 0);
+      load_hi(q_begin + 1);
+      load_lo(q_begin + 1);
+      make_base();
+      load_hi(q_begin + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     // two stages per trip so the buffer parity is a compile-time constant; an odd tail runs one
     // extra stage whose B rows and A dwords lie past the end and read as 0
     for (int q = q_begin; q < q_end; q += 2) {
-      stage(std::integral_constant<int, 0>{}, q);
-      stage(std::integral_constant<int, 1>{}, q + 1);
+      stage(std::integral_constant<int, 0>{}, btag, q);
+      stage(std::integral_constant<int, 1>{}, btag, q + 1);
     }
+  };
+  if (q_begin < q_end) {
+    if (__builtin_amdgcn_readfirstlane(tid >> 8) == K8Q_BUILDER_HALF) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   // epilogue: C tile out.  One running row pointer (pinned, so hipcc cannot hoist RG 64-bit row
@@ -344,12 +317,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
 }  // namespace
 
-// Host launcher.  A must already be packed chunk-major by gf2_launch_a4_pack (m4rm8_leaf.hip) into
-// `a4_ws`.  rg: rows per lane group (tile rows = 128*rg).
-extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug) {
-  const int R = 128 * rg;
+// Host launcher.  A must already be packed chunk-major WITH the byte rotation (gf2_launch_a4_pack_rot
+// of m4rm8_leaf.hip, rot = 1, or gf2_launch_winograd_down2_pack) into `a4_ws`.  Tiles are 4096 rows
+// x 512 columns.
+extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws) {
   a.wn        = (int32_t)words_of(a.n);
-  a.tiles_m   = (a.m + R - 1) / R;
+  a.tiles_m   = (a.m + K8_R - 1) / K8_R;
   a.tiles_n   = (a.wn + K8_TW - 1) / K8_TW;
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return hipSuccess;
   const int64_t nq    = (a.l + K8_CHUNK - 1) / K8_CHUNK;
@@ -368,18 +341,7 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
-#define K8Q_CASE(RGV, UGV)                                                                        \
-  if (rg == RGV && ug == UGV) {                                                                     \
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, false>), grid, block, 0, stream, a); \
-    else             hipLaunchKernelGGL((m4rm8q_kernel<RGV, UGV, false, true>), grid, block, 0, stream, a);  \
-    return hipGetLastError();                                                                     \
-  }
-  K8Q_CASE(32, 2)
-#undef K8Q_CASE
-  if (rg == 32 && ug == 1) {  // software-pipelined variant
-    if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<32, 1, true, false>), grid, block, 0, stream, a);
-    else             hipLaunchKernelGGL((m4rm8q_kernel<32, 1, true, true>), grid, block, 0, stream, a);
-    return hipGetLastError();
-  }
-  return hipErrorInvalidValue;
+  if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<false>), grid, block, 0, stream, a);
+  else             hipLaunchKernelGGL((m4rm8q_kernel<true>), grid, block, 0, stream, a);
+  return hipGetLastError();
 }

@@ -20,9 +20,8 @@ extern "C" hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a
 extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
-extern "C" hipError_t gf2_launch_m4rm8qb(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
 extern "C" hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
-extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug);
+extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -30,17 +29,11 @@ static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 // through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
-  if (pipe == 12) {  // experiment: generation 4 with builder waves
-    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
-    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
-    CK(gf2_launch_a4_pack_rot(0, a, g_a7, 1));
-    return gf2_launch_m4rm8qb(0, a, g_a7, rg, ug);
-  }
   if (pipe == 11) {  // generation 4: 8-bit tables, 64-byte entries, 4096 x 512 tiles
     const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
     CK(gf2_launch_a4_pack_rot(0, a, g_a7, 1));
-    return gf2_launch_m4rm8q(0, a, g_a7, rg, ug);
+    return gf2_launch_m4rm8q(0, a, g_a7);
   }
   if (pipe == 10) {  // generation 3: 8-bit tables, 128-byte entries, 2048 x 1024 tiles
     const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
@@ -187,8 +180,8 @@ int main(int argc, char **argv) {
     timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), 3, atoi(argv[3]), atoi(argv[4]));
     return 0;
   }
-  if (argc > 1 && !strcmp(argv[1], "--v4")) {  // generation 4 against its builder-wave experiment
-    const int v[][3] = {{32, 2, 11}, {32, 1, 11}};
+  if (argc > 1 && !strcmp(argv[1], "--v4")) {  // generation 4 alone (build with -DK8Q_BUILDER_HALF=1 for the control experiment)
+    const int v[][3] = {{32, 1, 11}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
@@ -201,7 +194,7 @@ int main(int argc, char **argv) {
     return fails != 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 4, 7}, {32, 4, 10}, {32, 2, 11}};
+    const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 4, 7}, {32, 4, 10}, {32, 1, 11}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
