@@ -44,6 +44,13 @@
 #ifndef K8Q_BUILDER_HALF
 #define K8Q_BUILDER_HALF 0
 #endif
+// rows in flight ahead of the XORs, per role
+#ifndef K8Q_PD_BUILDER
+#define K8Q_PD_BUILDER 1
+#endif
+#ifndef K8Q_PD_OTHER
+#define K8Q_PD_OTHER 1  // 2 and 3 fit in the gather-only waves' registers and measure the same
+#endif
 
 namespace {
 
@@ -215,21 +222,25 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     constexpr bool BUILDER = decltype(btag)::value;
     // builder, on entry: cur = base of this thread's table of stage s+1 (made late in the previous
     // stage), blo_rows = its chain rows, bhi_rows = the base rows of stage s+2
-    uint4 tp[2][4];
+    // pipeline depth: rows whose gathers are in flight ahead of the XORs
+    constexpr int PD = BUILDER ? K8Q_PD_BUILDER : K8Q_PD_OTHER;
+    uint4 tp[PD + 1][4];
     auto issue = [&](int g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t ad = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
-        tp[g & 1][i]      = *reinterpret_cast<const uint4 *>(lds + ad);
+        const uint32_t ad  = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
+        tp[g % (PD + 1)][i] = *reinterpret_cast<const uint4 *>(lds + ad);
       }
     };
-    issue(0);
+#pragma unroll
+    for (int g = 0; g < PD; ++g) issue(g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
-      if (g + 1 < RG) issue(g + 1);
-      if ((g + 2) % 4 == 0) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
-        const int k = (g + 1) / 4, ahead = 4 * k + AR;
+      const int j = g + PD;  // the row whose gathers go out now
+      if (j < RG) issue(j);
+      if (j < RG && j % 4 == 3) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
+        const int k = j / 4, ahead = 4 * k + AR;
         load_a4(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
       }
       if constexpr (BUILDER) {
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
       }
       __builtin_amdgcn_sched_barrier(0);
       uint32_t *a     = acc[g];
-      const uint4 *tt = tp[g & 1];
+      const uint4 *tt = tp[g % (PD + 1)];
       a[0] = xor3(xor3(a[0], tt[0].x, tt[1].x), tt[2].x, tt[3].x);
       a[1] = xor3(xor3(a[1], tt[0].y, tt[1].y), tt[2].y, tt[3].y);
       a[2] = xor3(xor3(a[2], tt[0].z, tt[1].z), tt[2].z, tt[3].z);
