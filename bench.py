@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--size", type=int, default=65536, help="n of the n x n x n product")
     ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384"])
     ap.add_argument("--cutoff", type=int, default=0)
+    ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: development aid -- several ranks may share one GPU, P2P is staged through the host")
@@ -164,6 +165,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
     m4ri_amd.init(dev)
+    if args.max_fuse:
+        m4ri_amd.set_max_fuse(args.max_fuse)
     stream = torch.cuda.current_stream().cuda_stream
 
     if args.workload == "leaf16384":

@@ -128,6 +128,11 @@ typedef struct m4ri_amd_stats {
 void m4ri_amd_set_profiling(int on);
 int m4ri_amd_get_stats(m4ri_amd_stats *out);
 
+/* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..3, default 3;
+   a scheduling knob: results are bit-identical for every value).  Returns the previous value;
+   out-of-range arguments only query. */
+int m4ri_amd_set_max_fuse(int levels);
+
 /* Release the engine's workspace (device memory pool). */
 void m4ri_amd_release_workspace(void);
 

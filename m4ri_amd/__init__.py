@@ -67,6 +67,7 @@ SYMBOLS = {
     "m4ri_amd_fill_dev": (_I, [_P, _I64, _I64, _I64, ctypes.c_uint64, _P]),
     "m4ri_amd_mask_tail_dev": (_I, [_P, _I64, _I64, _I64, _P]),
     "m4ri_amd_set_profiling": (None, [_I]),
+    "m4ri_amd_set_max_fuse": (_I, [_I]),
     "m4ri_amd_get_stats": (_I, [ctypes.POINTER(Stats)]),
     "m4ri_amd_release_workspace": (None, []),
 }
@@ -175,6 +176,11 @@ def xor_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int,
 
 def fill_dev(M: int, stride: int, rows: int, ncols: int, seed: int, stream: int = 0) -> None:
     _check(lib().m4ri_amd_fill_dev(M, stride, rows, ncols, seed, stream), "m4ri_amd_fill_dev")
+
+
+def set_max_fuse(levels: int) -> int:
+    """Deepest Strassen-Winograd levels covered by one fused pass (1..3); returns the previous value."""
+    return int(lib().m4ri_amd_set_max_fuse(int(levels)))
 
 
 def set_profiling(on: bool) -> None:

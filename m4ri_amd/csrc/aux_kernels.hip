@@ -407,6 +407,256 @@ extern "C" hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *
   return hipGetLastError();
 }
 
+// ---- three levels at once ----------------------------------------------------------------------
+// The whole schedule of a 3-level product in one pass each way: an ancestor is read once as an 8 x 8
+// grid of blocks and its 343 great-grandchildren are written directly (index 49*j1 + 7*j2 + j3,
+// exactly what three single-level passes produce); on the way up 343 products become 64 blocks.
+// Neither intermediate level is materialised: per operand 1 + 343/64 block transfers instead of
+// (1 + 7/4) + (7/4 + 343/64) with one single + one double pass.  One 64-bit word per lane (64
+// operand words live); children are produced one at a time to keep the register count down.
+namespace {
+
+// child j (0..6) of a 2 x 2 split, in the order of winograd_combos
+template <typename V, bool BSIDE>
+__device__ __forceinline__ V winograd_child(const V x11, const V x12, const V x21, const V x22, int j) {
+  if (!BSIDE) {  // [A11, A12, S4, A22, S1, S2, S3]
+    switch (j) {
+      case 0: return x11;
+      case 1: return x12;
+      case 2: return x12 ^ x21 ^ x22 ^ x11;
+      case 3: return x22;
+      case 4: return x21 ^ x22;
+      case 5: return x21 ^ x22 ^ x11;
+      default: return x11 ^ x21;
+    }
+  } else {       // [B11, B21, B22, T4, T1, T2, T3]
+    switch (j) {
+      case 0: return x11;
+      case 1: return x21;
+      case 2: return x22;
+      case 3: return x22 ^ x12 ^ x11 ^ x21;
+      case 4: return x12 ^ x11;
+      case 5: return x22 ^ x12 ^ x11;
+      default: return x22 ^ x12;
+    }
+  }
+}
+
+// product j's contribution to the four quadrants (the transpose of winograd_recombine):
+// C11 = P1+P2, C12 = P1+P6+P5+P3, C21 = P1+P6+P7+P4, C22 = P1+P6+P7+P5
+template <typename V>
+__device__ __forceinline__ void winograd_scatter(const V pr, int j, V &c11, V &c12, V &c21, V &c22) {
+  switch (j) {
+    case 0: c11 ^= pr; c12 ^= pr; c21 ^= pr; c22 ^= pr; break;
+    case 1: c11 ^= pr; break;
+    case 2: c12 ^= pr; break;
+    case 3: c21 ^= pr; break;
+    case 4: c12 ^= pr; c22 ^= pr; break;
+    case 5: c12 ^= pr; c21 ^= pr; c22 ^= pr; break;
+    default: c21 ^= pr; c22 ^= pr; break;
+  }
+}
+
+template <bool BSIDE>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down3_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,  // ancestor array
+    word *__restrict__ gchild, int64_t c_bs,                       // great-grandchildren, stride == cw
+    int64_t nparents, int64_t crows, int64_t cw) {                 // great-grandchild shape: crows x cw
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const word *p    = anc + pi * p_bs + r * p_stride + w;
+    word x[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) x[a][b] = p[(int64_t)a * crows * p_stride + (int64_t)b * cw];
+    word *c = gchild + (pi * 343) * c_bs + r * cw + w;
+#pragma unroll
+    for (int j1 = 0; j1 < 7; ++j1) {
+      word c1[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c1[a][b] = winograd_child<word, BSIDE>(x[a][b], x[a][b + 4], x[a + 4][b], x[a + 4][b + 4], j1);
+#pragma unroll
+      for (int j2 = 0; j2 < 7; ++j2) {
+        word c2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, BSIDE>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+#pragma unroll
+        for (int j3 = 0; j3 < 7; ++j3)
+          c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs] = winograd_child<word, BSIDE>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+      }
+    }
+  }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
+    const word *__restrict__ prod, int64_t p_bs,                   // 343 products per ancestor, stride == cw
+    word *__restrict__ anc, int64_t o_stride, int64_t o_bs,        // ancestor array
+    int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t per    = crows * cw;
+  const int64_t total  = nparents * per;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t pi = i / per;
+    const int64_t rm = i - pi * per;
+    const int64_t r  = rm / cw;
+    const int64_t w  = rm - r * cw;
+    const word *q    = prod + (pi * 343) * p_bs + r * cw + w;
+    word out[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) out[a][b] = 0;
+#pragma unroll
+    for (int j1 = 0; j1 < 7; ++j1) {
+      word c1[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c1[a][b] = 0;
+#pragma unroll
+      for (int j2 = 0; j2 < 7; ++j2) {
+        word c2[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int j3 = 0; j3 < 7; ++j3)
+          winograd_scatter<word>(q[(int64_t)(49 * j1 + 7 * j2 + j3) * p_bs], j3, c2[0][0], c2[0][1], c2[1][0], c2[1][1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) winograd_scatter<word>(c2[a][b], j2, c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) winograd_scatter<word>(c1[a][b], j1, out[a][b], out[a][b + 4], out[a + 4][b], out[a + 4][b + 4]);
+    }
+    word *o = anc + pi * o_bs + r * o_stride + w;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        word *oo = o + (int64_t)a * crows * o_stride + (int64_t)b * cw;
+        *oo      = ACC ? (*oo ^ out[a][b]) : out[a][b];
+      }
+  }
+}
+
+// A side, written in the leaf's packed chunk-major form (see winograd_down2_pack_kernel): 512
+// threads own a 32-row x 16-word tile of the great-grandchild grid; each of the 343 outputs goes
+// through a double-buffered LDS transpose (8-byte rows in, 8-byte row pairs of one chunk out).
+constexpr int DP3_ROWS = 32, DP3_W = 16, DP3_PITCH = 34, DP3_THREADS = 512;
+
+template <bool ROT>
+__global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
+    uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed great-grandchildren, a4_bs dwords each
+    int64_t crows, int64_t cw, int64_t tiles_r, int64_t tiles_w) {
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][DP3_ROWS * DP3_PITCH];
+  int64_t bid      = blockIdx.x;
+  const int64_t wt = bid % tiles_w; bid /= tiles_w;
+  const int64_t rt = bid % tiles_r; bid /= tiles_r;
+  const int64_t pi = bid;
+  const int t = threadIdx.x, r = t >> 4, v = t & 15;
+  const word *p = anc + pi * p_bs + (rt * DP3_ROWS + r) * p_stride + (wt * DP3_W + v);
+  word x[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) x[a][b] = p[(int64_t)a * crows * p_stride + (int64_t)b * cw];
+  // write side: thread -> chunk q (0..31 of the tile) and two consecutive rows
+  const int q = t >> 4, r2 = (t & 15) * 2;
+  uint32_t *o = a4 + (pi * 343) * a4_bs + (wt * (DP3_W * 2) + q) * crows + rt * DP3_ROWS + r2;
+  const uint32_t rot = ROT ? (uint32_t)(((rt * DP3_ROWS + r2) >> 6) & 3) : 0u;  // both rows share it
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c1[a][b] = winograd_child<word, false>(x[a][b], x[a][b + 4], x[a + 4][b], x[a + 4][b + 4], j1);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      word c2[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, false>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) {
+        const int k  = 49 * j1 + 7 * j2 + j3;
+        uint32_t *tb = tile[k & 1];
+        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * v) = winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        __syncthreads();  // one barrier per output: the other buffer is only rewritten after the next one
+        uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + q], w1 = tb[(r2 + 1) * DP3_PITCH + q];
+        if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
+        *reinterpret_cast<uint2 *>(o + (int64_t)k * a4_bs) = make_uint2(w0, w1);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs,
+                                                word *gchild, int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t c_bs = crows * cw;
+  if (nparents * c_bs == 0) return hipSuccess;
+  const int64_t total = nparents * c_bs;
+  if (bside)
+    hipLaunchKernelGGL((winograd_down3_kernel<true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs,
+                       gchild, c_bs, nparents, crows, cw);
+  else
+    hipLaunchKernelGGL((winograd_down3_kernel<false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs,
+                       gchild, c_bs, nparents, crows, cw);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_winograd_up3(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride,
+                                              int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t p_bs = crows * cw;
+  if (nparents * p_bs == 0) return hipSuccess;
+  const int64_t total = nparents * p_bs;
+  if (acc)
+    hipLaunchKernelGGL((winograd_up3_kernel<true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride,
+                       o_bs, nparents, crows, cw);
+  else
+    hipLaunchKernelGGL((winograd_up3_kernel<false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride,
+                       o_bs, nparents, crows, cw);
+  return hipGetLastError();
+}
+
+extern "C" int gf2_winograd_down3_pack_ok(const word *a4, int64_t crows, int64_t cw) {
+  return crows > 0 && cw > 0 && crows % DP3_ROWS == 0 && cw % DP3_W == 0 && (reinterpret_cast<uintptr_t>(a4) & 7) == 0;
+}
+
+// Great-grandchild i of the pass lands at a4 + i * (crows * cw * 2) dwords, laid out exactly as
+// gf2_launch_a4_pack(_rot) would have packed the row-major great-grandchild.
+extern "C" hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs,
+                                                     word *a4, int64_t nparents, int64_t crows, int64_t cw, int rot) {
+  if (nparents * crows * cw == 0) return hipSuccess;
+  if (!gf2_winograd_down3_pack_ok(a4, crows, cw)) return hipErrorInvalidValue;
+  const int64_t tiles_r = crows / DP3_ROWS, tiles_w = cw / DP3_W;
+  const int64_t grid = nparents * tiles_r * tiles_w;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (rot)
+    hipLaunchKernelGGL((winograd_down3_pack_kernel<true>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs,
+                       reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w);
+  else
+    hipLaunchKernelGGL((winograd_down3_pack_kernel<false>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs,
+                       reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w);
+  return hipGetLastError();
+}
+
 // Two levels per pass.  Grandchildren are crows x cw words, contiguous; a grandparent is 4*crows rows
 // x 4*cw words with row stride p_stride; grandchild 7*j1 + j2 of grandparent i is stored at index
 // 49*i + 7*j1 + j2.

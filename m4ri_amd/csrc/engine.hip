@@ -30,6 +30,13 @@ hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *gchild,
+                                     int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_up3(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs,
+                                   int64_t nparents, int64_t crows, int64_t cw);
+int gf2_winograd_down3_pack_ok(const word *a4, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4,
+                                          int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
@@ -52,6 +59,7 @@ hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int6
 namespace {
 
 constexpr int MAX_LEVELS      = 6;
+int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
 constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(m,l,n)/2 >= this (leaf >= 8192)
 constexpr int NUM_DEVICES_MAX = 16;
 
@@ -252,28 +260,30 @@ int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
 int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
-  // The two deepest levels are done by ONE fused pass each way (L >= 2): level L-1 is never
-  // materialised, which saves its buffers and 38 % of the traffic of the two largest levels.
-  const bool fuse2 = L >= 2;
-  auto skipped = [&](int d) { return fuse2 && d == L - 1; };
+  // The deepest levels are done by ONE fused pass each way: up to three of them (g_max_fuse), whose
+  // intermediate levels are never materialised -- that saves their buffers and a write + a read of
+  // the 7/4-times-larger operands per skipped level.  Levels above go one at a time.
+  const int fuse = L < g_max_fuse ? L : g_max_fuse;            // levels covered by the bottom pass
+  auto materialised = [&](int d) { return d <= L - fuse || d == L; };
   // With a fused last pass and a leaf that reads packed A, the pass writes the packed form itself:
   // the row-major A operands of the leaves are never materialised and the pack pass disappears.
   const LeafKind leaf_kind = pick_leaf(m >> L);
   bool prepack = false;
-  if (fuse2 && leaf_kind.gen >= 3) {
+  if (fuse >= 2 && leaf_kind.gen >= 3) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
-    const int d0      = L - 2;
+    const int d0      = L - fuse;
     const word *pa    = d0 == 0 ? A.p : aligned16;  // deeper levels live in the 256-byte aligned workspace
     const int64_t pas = d0 == 0 ? A.stride : (l >> d0) / 64;
     const uint64_t a4_bytes = (uint64_t)gf2_m4rm8_a4_words(m >> L, l >> L, 1) * 8;  // one packed operand: 32-bit offsets
     prepack = a4_bytes < (1ull << 32) &&
-              gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? 0 : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0;
+              (fuse == 3 ? gf2_winograd_down3_pack_ok(aligned16, m >> L, (l >> L) / 64) != 0
+                         : gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? 0 : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0);
   }
   // workspace plan
   size_t need = 0;
   auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
   for (int d = 1; d <= L; ++d) {
-    if (skipped(d)) continue;
+    if (!materialised(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     need += (prepack && d == L ? 0 : pad((size_t)cnt * md * wl)) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
@@ -288,24 +298,30 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   std::vector<word *> Al(L + 1, nullptr), Bl(L + 1, nullptr), Pl(L + 1, nullptr);
   if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, ipow7(L))) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
   for (int d = 1; d <= L; ++d) {
-    if (skipped(d)) continue;
+    if (!materialised(d)) continue;
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     if (!(prepack && d == L)) Al[d] = ws_take(e, (size_t)cnt * md * wl);
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
   }
   e->stats.workspace_bytes = (double)e->ws_cap * 8.0;
-  // down passes: level d -> d+1, or d -> d+2 for the fused pair at the bottom
+  // down passes: level d -> d+1, and d -> L for the fused pass at the bottom
   for (int d = 0; d < L;) {
-    const int step    = (fuse2 && d == L - 2) ? 2 : 1;
+    const int step    = d == L - fuse ? fuse : 1;
     const int64_t cnt = ipow7(d);
     const int64_t cm = m >> (d + step), cl = l >> (d + step), cn = n >> (d + step);
     const word *pa = d == 0 ? A.p : Al[d];
     const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
-    if (step == 2) {
-      if (prepack) HIPTRY(gf2_launch_winograd_down2_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, leaf_kind.gen == 4));
+    const int rot = leaf_kind.gen == 4;
+    if (step == 3) {
+      if (prepack) HIPTRY(gf2_launch_winograd_down3_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
+      else HIPTRY(gf2_launch_winograd_down3(st, 0, pa, pas, pabs, Al[d + 3], cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_winograd_down3(st, 1, pb, pbs, pbbs, Bl[d + 3], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * 407.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 64 in + 343 out
+    } else if (step == 2) {
+      if (prepack) HIPTRY(gf2_launch_winograd_down2_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down2(st, 0, pa, pas, pabs, Al[d + 2], cnt, cm, cl / 64));
       HIPTRY(gf2_launch_winograd_down2(st, 1, pb, pbs, pbbs, Bl[d + 2], cnt, cl, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * 65.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 16 in + 49 out
@@ -323,9 +339,9 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
                              ll * (ln / 64), lm, ll, ln, cnt, false, 1, prepack))
       return rc;
   }
-  // up passes: level d+1 -> d, or d+2 -> d for the fused pair at the bottom (done first)
+  // up passes: the fused pass at the bottom first (L -> L - fuse), then level d+1 -> d
   for (int d = L; d > 0;) {
-    const int step    = (fuse2 && d == L) ? 2 : 1;
+    const int step    = d == L ? fuse : 1;
     const int dst     = d - step;
     const int64_t cnt = ipow7(dst);
     const int64_t cm = m >> d, cn = n >> d;
@@ -333,7 +349,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
     const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
-    if (step == 2) {
+    if (step == 3) {
+      HIPTRY(gf2_launch_winograd_up3(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (acc ? 471.0 : 407.0);
+    } else if (step == 2) {
       HIPTRY(gf2_launch_winograd_up2(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (acc ? 81.0 : 65.0);
     } else {
@@ -434,6 +453,13 @@ int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint
 
 int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, void *stream) {
   return (int)gf2_launch_mask_tail((hipStream_t)stream, M, stride, rows, ncols);
+}
+
+int m4ri_amd_set_max_fuse(int levels) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int old = g_max_fuse;
+  if (levels >= 1 && levels <= 3) g_max_fuse = levels;
+  return old;
 }
 
 void m4ri_amd_set_profiling(int on) {

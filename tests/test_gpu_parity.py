@@ -321,3 +321,31 @@ def test_fused_down_pack_paths(oracle, m, l, n, cutoff, a_shift, leaf_gen):
     st = m4ri_amd.get_stats()
     assert st.levels == 2 and st.leaf_gen == leaf_gen
     assert to_host(C, m, n).equal(oracle.mul(None, hA, hB, cutoff))
+
+
+@pytest.mark.parametrize("m,l,n,cutoff,leaf_gen,add", [
+    (16384, 16384, 16384, 2048, 3, False),  # 343 leaves of 2048^3: three-level pass writes generation 3's packed A
+    (32768, 8192, 8192, 1024, 4, False),    # 4096-row leaves: generation 4's rotated packed A
+    (8192, 10240, 8192, 1024, 2, False),    # 20-word leaf rows: plain three-level passes + generation 2's own pack
+    (4096, 4096, 4096, 512, 1, True),       # accumulate through the three-level up pass
+])
+def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
+    """One fused pass per operand for the three deepest levels (aux_kernels.hip winograd_down3 / up3);
+    fusing 1, 2 or 3 levels is a scheduling choice and must not change a bit."""
+    hA, hB, hC = Mzd.random(m, l, 71), Mzd.random(l, n, 72), Mzd.random(m, n, 73)
+    wa, wn = hA.rowstride, hB.rowstride
+    A = torch.from_numpy(hA.rows().view(np.int64).copy()).cuda()
+    B = torch.from_numpy(hB.rows().view(np.int64).copy()).cuda()
+    C0 = torch.from_numpy(hC.rows().view(np.int64).copy()).cuda()
+    want = oracle.addmul(hC.copy(), hA, hB, cutoff) if add else oracle.mul(None, hA, hB, cutoff)
+    old = m4ri_amd.set_max_fuse(0)
+    try:
+        for fuse in (3, 2, 1):
+            m4ri_amd.set_max_fuse(fuse)
+            C = C0.clone()
+            m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wa, B.data_ptr(), wn, m, l, n, add=add, cutoff=cutoff)
+            st = m4ri_amd.get_stats()
+            assert st.levels == 3 and st.leaf_gen == leaf_gen
+            assert to_host(C, m, n).equal(want), f"max_fuse={fuse}"
+    finally:
+        m4ri_amd.set_max_fuse(old)
