@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--size", type=int, default=65536, help="n of the n x n x n product")
     ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384"])
     ap.add_argument("--cutoff", type=int, default=0)
+    ap.add_argument("--grid", default="", help="gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
     ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -181,7 +182,7 @@ def main():
     B = torch.empty((n, w), dtype=torch.int64, device="cuda")
     m4ri_amd.fill_dev(A.data_ptr(), w, n, n, 3, stream)
     m4ri_amd.fill_dev(B.data_ptr(), w, n, n, 4, stream)
-    plan = sharding.make_plan(world, rank, n, n, n)
+    plan = sharding.make_plan(world, rank, n, n, n, grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None)
     r0, r1 = plan.row_range()
     c0, c1 = plan.col_range()
     k0, k1 = plan.inner_range()

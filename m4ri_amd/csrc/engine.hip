@@ -60,7 +60,8 @@ namespace {
 
 constexpr int MAX_LEVELS      = 6;
 int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
-constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(m,l,n)/2 >= this (leaf >= 8192)
+constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
+constexpr int DEFAULT_CUTOFF_M = 4096; // ... and m/2 >= this (one generation-4 tile row)
 constexpr int NUM_DEVICES_MAX = 16;
 
 #define HIPTRY(expr)                                                  \
@@ -81,6 +82,7 @@ struct Engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
   std::vector<hipEvent_t> event_pool;
   hipStream_t pending_stream = nullptr;
+  int cus               = 0;        // compute units of the device (workgroups resident at once: one per CU)
 };
 
 std::mutex g_mu;
@@ -91,6 +93,10 @@ Engine *engine_for_current_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NUM_DEVICES_MAX) return nullptr;
   Engine *e = &g_engines[dev];
   e->device = dev;
+  if (e->cus == 0) {
+    int n = 0;
+    e->cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
   return e;
 }
 
@@ -167,23 +173,37 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   const int64_t wn   = words_of(n);
   const int64_t tw   = kind.gen == 4 ? 8 : kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
-  const int64_t stages = (l + LEAF_STAGE - 1) / LEAF_STAGE;
+  const int64_t sbits  = kind.gen == 4 ? 32 : kind.gen == 2 ? 14 : 16;  // inner bits per stage (barrier to barrier)
+  const int64_t stages = (l + sbits - 1) / sbits;
   int ksplit = ksplit_req;
   if (ksplit <= 0) {
-    // fill the chip: aim for >= 512 workgroups (2 per CU), but keep >= 64 stages (1024 inner
-    // bits) per split so the C tile traffic stays amortised
-    ksplit = 1;
-    if (tiles < 512) {
-      int64_t want = (512 + tiles - 1) / tiles;
-      int64_t cap  = stages / 64;
-      if (cap < 1) cap = 1;
-      ksplit = (int)(want < cap ? want : cap);
-    }
+    // One workgroup per CU is resident at a time (LDS), so a launch runs in ceil(workgroups / CUs)
+    // rounds and a short last round idles most of the chip: 784 tiles on 256 CUs take 4 rounds for
+    // 3.06 rounds of work.  Splitting the inner dimension trades that for more, shorter workgroups
+    // (combined by atomic XOR into a zeroed C).  Cost in stages: rounds x (stages per split +
+    // prologue/epilogue, + the atomic epilogue when split); keep >= 64 stages per split so the C
+    // tile traffic stays amortised, and take a split only when it pays >= 3 %.
+    const double fixed = 4.0, atomic = 6.0;
+    auto cost = [&](int64_t ks) {
+      const int64_t rounds = (tiles * ks + e->cus - 1) / e->cus;
+      return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? atomic : 0.0));
+    };
+    int64_t cap = stages / 64;
+    if (cap < 1) cap = 1;
+    if (cap > 32) cap = 32;
+    ksplit           = 1;
+    double best_cost = cost(1) * 0.97;
+    for (int64_t ks = 2; ks <= cap; ++ks)
+      if (cost(ks) < best_cost) { best_cost = cost(ks); ksplit = (int)ks; }
   }
   if (l == 0 || (ksplit > 1 && !add)) {  // empty inner dimension, or atomics need a zeroed C
-    if (!add)
-      for (int64_t b = 0; b < batch; ++b)
-        HIPTRY(gf2_launch_rowwise(st, 2, C + b * cbs, cs, nullptr, 0, nullptr, 0, m, wn));
+    if (!add) {
+      if (cs == wn && (batch == 1 || cbs == m * wn))  // one contiguous block
+        HIPTRY(hipMemsetAsync(C, 0, (size_t)batch * m * wn * 8, st));
+      else
+        for (int64_t b = 0; b < batch; ++b)
+          HIPTRY(gf2_launch_rowwise(st, 2, C + b * cbs, cs, nullptr, 0, nullptr, 0, m, wn));
+    }
     if (l == 0) return 0;
   }
   LeafArgs a{};
@@ -242,8 +262,11 @@ bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strass
 int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   int L = 0;
   if (cutoff == 0) {
-    int64_t mn = m < l ? m : l; if (n < mn) mn = n;
-    while (L < MAX_LEVELS && mn / 2 >= DEFAULT_CUTOFF) { mn /= 2; ++L; }
+    // leaves keep >= 8192 inner bits and columns (256 stages, 16 column tiles per product) but may
+    // be as short as ONE 4096-row tile: the rectangular blocks of a multi-GPU split (e.g.
+    // 16384 x 65536 x 32768 per rank at 8 GPUs) then still get their full Strassen depth
+    int64_t mm = m, ln = l < n ? l : n;
+    while (L < MAX_LEVELS && mm / 2 >= DEFAULT_CUTOFF_M && ln / 2 >= DEFAULT_CUTOFF) { mm /= 2; ln /= 2; ++L; }
   } else {
     // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
     int64_t a = m, b = l, c = n;
@@ -336,7 +359,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   {
     const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = ipow7(L);
     if (int rc = launch_leaf(e, st, Pl[L], ln / 64, lm * (ln / 64), Al[L], ll / 64, lm * (ll / 64), Bl[L], ln / 64,
-                             ll * (ln / 64), lm, ll, ln, cnt, false, 1, prepack))
+                             ll * (ln / 64), lm, ll, ln, cnt, false, 0, prepack))
       return rc;
   }
   // up passes: the fused pass at the bottom first (L -> L - fuse), then level d+1 -> d

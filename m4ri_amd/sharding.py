@@ -2,13 +2,17 @@
 no data-path collective except ONE pairwise XOR exchange when the inner dimension is split.
 
 The template is the reference's own multi-core path, _mzd_mul_mp4 (reference m4ri/mp.c:158-275): C is
-split 2x2 and every block C_ij = A_i0*B_0j + A_i1*B_1j.  With 8 GPUs the two terms of each block go to
-two different GPUs (grid 2x2x2) and are combined by a pairwise exchange over xGMI; RCCL has no XOR
-reduction, so the reduce is "send/recv half of the partial product + local XOR kernel" -- each pair
-talks over its own point-to-point link, nothing is ring-shaped.
+split into blocks and every rank computes its block(s) C_ij = A_i* x B_*j.  The default grids split
+only the rows and columns of C, so no rank ever needs another rank's data:
 
-    world 1: (1,1,1)   world 2: (2,1,1) rows of C     world 4: (2,2,1) blocks of C
-    world 8: (2,2,2) blocks of C x halves of the inner dimension, pair exchange
+    world 1: (1,1,1)   world 2: (2,1,1) rows of C   world 4: (2,2,1)   world 8: (4,2,1) blocks of C
+
+(the engine gives the resulting rectangular blocks, e.g. 16384 x 65536 x 32768 at 8 GPUs, the same
+Strassen depth per leaf size as a cube).  A grid may also split the inner dimension (gh > 1, e.g.
+(2,2,2)): the gh partial products of a block then sit on different GPUs and are combined by a
+pairwise exchange over xGMI; RCCL has no XOR reduction, so the reduce is "send/recv half of the
+partial product + local XOR kernel" -- each pair talks over its own point-to-point link, nothing is
+ring-shaped.  That costs 64 MiB per rank and product at n = 65536, which is why it is not the default.
 
 Everything here is device-agnostic (views are (row0, rows, col0_bits, cols_bits) tuples; the multiply,
 XOR and transport are injected), so the same code runs under gloo on CPU tensors in the tests and
@@ -65,7 +69,7 @@ class ShardPlan:
 
 
 def default_grid(world: int):
-    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world) or _fallback_grid(world)
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1)}.get(world) or _fallback_grid(world)
 
 
 def _fallback_grid(world: int):

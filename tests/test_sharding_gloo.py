@@ -87,11 +87,11 @@ def test_two_rank_sharded_product_matches_oracle(tmp_path, oracle, grid, m, l, n
 
 def test_plans_tile_the_product():
     """Every default grid covers C exactly once and splits the inner dimension without gaps."""
-    for world in (1, 2, 4, 8):
+    for world, grid in ((1, None), (2, None), (4, None), (8, None), (8, (2, 2, 2)), (4, (1, 2, 2))):
         m = l = n = 65536
         seen = {}
         for rank in range(world):
-            p = sharding.make_plan(world, rank, m, l, n)
+            p = sharding.make_plan(world, rank, m, l, n, grid=grid)
             r0, r1 = p.row_range(); c0, c1 = p.col_range(); k0, k1 = p.inner_range()
             assert c0 % 64 == 0 and k0 % 64 == 0
             seen.setdefault((r0, r1, c0, c1), []).append((k0, k1))
@@ -103,4 +103,5 @@ def test_plans_tile_the_product():
             ks.sort()
             assert ks[0][0] == 0 and ks[-1][1] == l and all(a[1] == b[0] for a, b in zip(ks, ks[1:]))
         assert area == m * n
-    assert sharding.default_grid(8) == (2, 2, 2) and sharding.default_grid(4) == (2, 2, 1)
+    # the defaults never split the inner dimension: no exchange on the data path
+    assert sharding.default_grid(8) == (4, 2, 1) and sharding.default_grid(4) == (2, 2, 1)

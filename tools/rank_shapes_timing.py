@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Time the per-rank block products of the default multi-GPU grids on ONE GPU (what each rank of an
+N-GPU run computes at n = 65536), to estimate strong scaling without an 8-GPU node."""
+import json
+import sys
+import time
+
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+import m4ri_amd
+
+n = 65536
+SHAPES = {"N=1 (1,1,1)": (n, n, n), "N=2 (2,1,1)": (n // 2, n, n), "N=4 (2,2,1)": (n // 2, n, n // 2),
+          "N=8 (4,2,1)": (n // 4, n, n // 2), "N=8 (2,2,2) + exchange": (n // 2, n // 2, n // 2)}
+m4ri_amd.init(0)
+out = {}
+for name, (m, l, k) in SHAPES.items():
+    wl, wk = l // 64, k // 64
+    A = torch.empty((m, wl), dtype=torch.int64, device="cuda")
+    B = torch.empty((l, wk), dtype=torch.int64, device="cuda")
+    C = torch.empty((m, wk), dtype=torch.int64, device="cuda")
+    m4ri_amd.fill_dev(A.data_ptr(), wl, m, l, 3)
+    m4ri_amd.fill_dev(B.data_ptr(), wk, l, k, 4)
+    for _ in range(2):
+        m4ri_amd.mul_dev(C.data_ptr(), wk, A.data_ptr(), wl, B.data_ptr(), wk, m, l, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m4ri_amd.mul_dev(C.data_ptr(), wk, A.data_ptr(), wl, B.data_ptr(), wk, m, l, k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    st = m4ri_amd.get_stats()
+    out[name] = {"shape": [m, l, k], "ms": ms, "levels": st.levels, "leaf": [st.leaf_m, st.leaf_l, st.leaf_n],
+                 "leaf_products": st.leaf_products, "leaf_gen": st.leaf_gen}
+    print(name, out[name], flush=True)
+    del A, B, C
+    m4ri_amd.lib().m4ri_amd_release_workspace()
+base = out["N=1 (1,1,1)"]["ms"]
+for name, d in out.items():
+    print(f"{name}: {d['ms']:.2f} ms -> speedup {base / d['ms']:.2f}x (compute only)")
