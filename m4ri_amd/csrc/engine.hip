@@ -62,6 +62,7 @@ constexpr int MAX_LEVELS      = 6;
 int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
 constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
 constexpr int DEFAULT_CUTOFF_M = 4096; // ... and m/2 >= this (one generation-4 tile row)
+constexpr int DEFAULT_CUTOFF_N = 4096; // ... and n/2 >= this (8 column tiles)
 constexpr int NUM_DEVICES_MAX = 16;
 
 #define HIPTRY(expr)                                                  \
@@ -265,8 +266,8 @@ int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
     // leaves keep >= 8192 inner bits and columns (256 stages, 16 column tiles per product) but may
     // be as short as ONE 4096-row tile: the rectangular blocks of a multi-GPU split (e.g.
     // 16384 x 65536 x 32768 per rank at 8 GPUs) then still get their full Strassen depth
-    int64_t mm = m, ln = l < n ? l : n;
-    while (L < MAX_LEVELS && mm / 2 >= DEFAULT_CUTOFF_M && ln / 2 >= DEFAULT_CUTOFF) { mm /= 2; ln /= 2; ++L; }
+    int64_t mm = m, ll = l, nn = n;
+    while (L < MAX_LEVELS && mm / 2 >= DEFAULT_CUTOFF_M && ll / 2 >= DEFAULT_CUTOFF && nn / 2 >= DEFAULT_CUTOFF_N) { mm /= 2; ll /= 2; nn /= 2; ++L; }
   } else {
     // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
     int64_t a = m, b = l, c = n;
