@@ -330,7 +330,7 @@ extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t s
 namespace {
 constexpr int DP_ROWS = 32, DP_V = 8, DP_PITCH = 36;  // tile rows, 16-byte vectors per row, LDS row pitch (dwords)
 
-template <bool ROT>
+template <int ROT>  // 0: plain chunk-major, 1: generation 4's byte rotation, 2: generation 5's rotation + chunk swap
 __global__ __launch_bounds__(AUX_THREADS) void winograd_down2_pack_kernel(
     const word2 *__restrict__ gparent, int64_t p_stride, int64_t p_bs,  // grandparent array (units of word2)
     uint32_t *__restrict__ a4, int64_t a4_bs,                           // packed grandchildren, a4_bs dwords each
@@ -354,10 +354,13 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_down2_pack_kernel(
     for (int b = 0; b < 2; ++b) winograd_combos<word2, false>(x[a][b], x[a][b + 2], x[a + 2][b], x[a + 2][b + 2], y[2 * a + b]);
   // write side: thread -> chunk q (0..31 of the tile) and four consecutive rows
   const int q = t >> 3, r4 = (t & 7) * 4;
-  uint32_t *o = a4 + (pi * 49) * a4_bs + (wt * (DP_V * 4) + q) * crows + rt * DP_ROWS + r4;
-  // generation 4 wants the four index bytes of a dword rotated by (row >> 6) & 3 (m4rm8q_leaf.hip);
-  // the four rows of one store share that value
-  const uint32_t rot = ROT ? (uint32_t)(((rt * DP_ROWS + r4) >> 6) & 3) : 0u;
+  // generation 4 wants the four index bytes of a dword rotated by (row >> 6) & 3 (m4rm8q_leaf.hip),
+  // generation 5 by (row >> 7) & 3 with the two chunks of a word swapped when (row >> 5) & 1
+  // (m4rm8o_leaf.hip); the four rows of one store share those values
+  const int64_t orow = rt * DP_ROWS + r4;
+  const uint32_t rot = ROT == 1 ? (uint32_t)((orow >> 6) & 3) : ROT == 2 ? (uint32_t)((orow >> 7) & 3) : 0u;
+  const int64_t oq   = (wt * (DP_V * 4) + q) ^ (ROT == 2 ? ((orow >> 5) & 1) : 0);
+  uint32_t *o = a4 + (pi * 49) * a4_bs + oq * crows + orow;
 #pragma unroll
   for (int j1 = 0; j1 < 7; ++j1) {
     word2 g[7];
@@ -396,14 +399,12 @@ extern "C" hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *
   const int64_t tiles_r = crows / DP_ROWS, tiles_w = (cw / 2) / DP_V;
   const int64_t grid = nparents * tiles_r * tiles_w;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (rot)
-    hipLaunchKernelGGL((winograd_down2_pack_kernel<true>), dim3((unsigned)grid), dim3(AUX_THREADS), 0, s,
-                       reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<uint32_t *>(a4),
-                       crows * cw * 2, crows, cw / 2, tiles_r, tiles_w);
-  else
-    hipLaunchKernelGGL((winograd_down2_pack_kernel<false>), dim3((unsigned)grid), dim3(AUX_THREADS), 0, s,
-                       reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<uint32_t *>(a4),
-                       crows * cw * 2, crows, cw / 2, tiles_r, tiles_w);
+#define DP2_LAUNCH(R)                                                                                         \
+  hipLaunchKernelGGL((winograd_down2_pack_kernel<R>), dim3((unsigned)grid), dim3(AUX_THREADS), 0, s,                \
+                     reinterpret_cast<const word2 *>(gparent), p_stride / 2, p_bs / 2, reinterpret_cast<uint32_t *>(a4), \
+                     crows * cw * 2, crows, cw / 2, tiles_r, tiles_w)
+  if (rot == 2) DP2_LAUNCH(2); else if (rot == 1) DP2_LAUNCH(1); else DP2_LAUNCH(0);
+#undef DP2_LAUNCH
   return hipGetLastError();
 }
 
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
 // through a double-buffered LDS transpose (8-byte rows in, 8-byte row pairs of one chunk out).
 constexpr int DP3_ROWS = 32, DP3_W = 16, DP3_PITCH = 34, DP3_THREADS = 512;
 
-template <bool ROT>
+template <int ROT>
 __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
     uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed great-grandchildren, a4_bs dwords each
@@ -576,8 +577,10 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
     for (int b = 0; b < 8; ++b) x[a][b] = p[(int64_t)a * crows * p_stride + (int64_t)b * cw];
   // write side: thread -> chunk q (0..31 of the tile) and two consecutive rows
   const int q = t >> 4, r2 = (t & 15) * 2;
-  uint32_t *o = a4 + (pi * 343) * a4_bs + (wt * (DP3_W * 2) + q) * crows + rt * DP3_ROWS + r2;
-  const uint32_t rot = ROT ? (uint32_t)(((rt * DP3_ROWS + r2) >> 6) & 3) : 0u;  // both rows share it
+  const int64_t orow = rt * DP3_ROWS + r2;  // both rows share the rotation / swap
+  const uint32_t rot = ROT == 1 ? (uint32_t)((orow >> 6) & 3) : ROT == 2 ? (uint32_t)((orow >> 7) & 3) : 0u;
+  const int64_t oq   = (wt * (DP3_W * 2) + q) ^ (ROT == 2 ? ((orow >> 5) & 1) : 0);
+  uint32_t *o = a4 + (pi * 343) * a4_bs + oq * crows + orow;
 #pragma unroll
   for (int j1 = 0; j1 < 7; ++j1) {
     word c1[4][4];
@@ -648,12 +651,11 @@ extern "C" hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *
   const int64_t tiles_r = crows / DP3_ROWS, tiles_w = cw / DP3_W;
   const int64_t grid = nparents * tiles_r * tiles_w;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (rot)
-    hipLaunchKernelGGL((winograd_down3_pack_kernel<true>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs,
-                       reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w);
-  else
-    hipLaunchKernelGGL((winograd_down3_pack_kernel<false>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs,
-                       reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w);
+#define DP3_LAUNCH(R)                                                                                              \
+  hipLaunchKernelGGL((winograd_down3_pack_kernel<R>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs, \
+                     reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w)
+  if (rot == 2) DP3_LAUNCH(2); else if (rot == 1) DP3_LAUNCH(1); else DP3_LAUNCH(0);
+#undef DP3_LAUNCH
   return hipGetLastError();
 }
 

@@ -184,12 +184,12 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     // (combined by atomic XOR into a zeroed C).  Cost in stages: rounds x (stages per split +
     // prologue/epilogue, + the atomic epilogue when split); keep >= 64 stages per split so the C
     // tile traffic stays amortised, and take a split only when it pays >= 3 %.
-    const double fixed = 4.0, atomic = 6.0;
+    const double fixed = 128.0 / (double)sbits, atomic = 192.0 / (double)sbits;  // measured on generation 4, in inner bits
     auto cost = [&](int64_t ks) {
       const int64_t rounds = (tiles * ks + e->cus - 1) / e->cus;
       return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? atomic : 0.0));
     };
-    int64_t cap = stages / 64;
+    int64_t cap = stages * sbits / 2048;  // >= 2048 inner bits per split
     if (cap < 1) cap = 1;
     if (cap > 32) cap = 32;
     ksplit           = 1;
@@ -222,7 +222,7 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     if (!packed_a_fits(e, kind, m, l, batch)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
       const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
-      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen == 4));
+      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen - 3));  // 0 / 1 / 2: the generation's index twists
       else HIPTRY(gf2_launch_a7_pack(st, a, e->apk));
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
@@ -338,7 +338,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
-    const int rot = leaf_kind.gen == 4;
+    const int rot = leaf_kind.gen >= 3 ? leaf_kind.gen - 3 : 0;  // the leaf generation's index twists (pack mode)
     if (step == 3) {
       if (prepack) HIPTRY(gf2_launch_winograd_down3_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down3(st, 0, pa, pas, pabs, Al[d + 3], cnt, cm, cl / 64));

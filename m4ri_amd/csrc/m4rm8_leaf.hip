@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void a4_pack_kernel(const word *__restrict__ A
                                                       uint32_t *__restrict__ A4, int64_t m_pad, int64_t a4_bs,
                                                       int64_t m, int64_t l, int64_t row_tiles, int64_t word_tiles, int rot) {
   __shared__ uint32_t tile[PK_ROWS][2 * PK_WORDS + 1];
-  const int64_t nq = (l + K8_CHUNK - 1) / K8_CHUNK;
+  const int64_t nq = 2 * ((l + 63) / 64);  // two 32-bit chunks per word of A (always even)
   const int64_t wa = (l + 63) >> 6;
   int64_t bid      = blockIdx.x;
   const int64_t wt = bid % word_tiles; bid /= word_tiles;
@@ -91,9 +91,16 @@ __global__ __launch_bounds__(256) void a4_pack_kernel(const word *__restrict__ A
     uint32_t v = tile[r][ql];
     // generation 4 reads table (rot + i) & 3 in a row's i-th gather, rot = (row >> 6) & 3 (its lane
     // geometry): store the four index bytes pre-rotated so that byte i IS the i-th gather's index
-    // and the kernel's v_perm selectors are compile-time constants
-    if (rot) v = __builtin_amdgcn_alignbyte(v, v, (uint32_t)(((r0 + r) >> 6) & 3));
-    A4[b * a4_bs + q * m_pad + r0 + r] = v;  // rows m .. m_pad-1 come out 0 (index 0 = zero entries)
+    // and the kernel's v_perm selectors are compile-time constants.  Generation 5 (rot == 2) does the
+    // same with rot = (row >> 7) & 3 and additionally swaps the two chunks of a word for rows with
+    // (row >> 5) & 1 (m4rm8o_leaf.hip)
+    int64_t qo = q;
+    if (rot == 1) v = __builtin_amdgcn_alignbyte(v, v, (uint32_t)(((r0 + r) >> 6) & 3));
+    if (rot == 2) {
+      v = __builtin_amdgcn_alignbyte(v, v, (uint32_t)(((r0 + r) >> 7) & 3));
+      qo = q ^ (((r0 + r) >> 5) & 1);
+    }
+    A4[b * a4_bs + qo * m_pad + r0 + r] = v;  // rows m .. m_pad-1 come out 0 (index 0 = zero entries)
   }
 }
 
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
   const word *Bb      = p.B + bat * p.b_bs;
   word *__restrict__ Cb = p.C + bat * p.c_bs;
 
-  const int nq = (p.l + K8_CHUNK - 1) / K8_CHUNK;
+  const int nq = 2 * ((p.l + 63) / 64);
   // The packed A and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
   // base, and the hardware range check returns 0 for rows >= m of the packed A and rows >= l of B -- exactly
   // the zero padding the algorithm wants, so the main loop has no edge branches.
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8_kernel(const LeafArgs p) {
 
 // words of workspace the packed copy of A needs for a launch (uint32 units rounded to 64-bit words)
 extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch) {
-  const int64_t nq = (l + K8_CHUNK - 1) / K8_CHUNK;
+  const int64_t nq = 2 * ((l + 63) / 64);  // two 32-bit chunks per word of A (always even)
   return (batch * ((m + 3) & ~(int64_t)3) * nq + 1) / 2;
 }
 
@@ -353,7 +360,7 @@ static bool k8_geometry(LeafArgs &a, word *a4_ws, int rg, int64_t &nq, int64_t &
   a.tiles_m   = (a.m + R - 1) / R;
   a.tiles_n   = (a.wn + K8_TW - 1) / K8_TW;
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return false;
-  nq          = (a.l + K8_CHUNK - 1) / K8_CHUNK;
+  nq          = 2 * (((int64_t)a.l + 63) / 64);
   m_pad       = ((int64_t)a.m + 3) & ~(int64_t)3;
   a.Apk        = reinterpret_cast<const uint32_t *>(a4_ws);
   a.apk_stride = m_pad;

@@ -1,38 +1,30 @@
-// m4rm8q_leaf.hip -- M4RM leaf, generation 4: 8-bit tables with 64-byte entries, FOUR tables
-// interleaved per LDS bank row, double-buffered, software-pipelined gathers, table building on the
-// four older waves.
+// EXPERIMENT (not in the product, measured slower than generation 4: its LDS-array time is 5.5 % lower as
+// designed -- SQ_LDS_IDX_ACTIVE -- but the narrower tile doubles the A traffic per inner bit and the A
+// loads arrive late).
+// m4rm8o_leaf.hip -- M4RM leaf, generation 5: 8-bit tables with 32-byte entries, EIGHT tables
+// interleaved per LDS bank row, 64-bit stages, 8192 x 256 tiles.
 //
-// One more turn of generation 3's screw (m4rm8_leaf.hip).  The leaf is bound by LDS-array cycles,
-// and for a tile of fixed area the gathers cost the same while the table writes shrink with the
-// entry size, because more rows share every entry:
+// Generation 4 (m4rm8q_leaf.hip) with the entry halved once more: the gathers cost the same per
+// inner bit, the table writes half as much (twice the rows share every entry), and there is one
+// barrier per 64 inner bits:
 //
-//     entry 256 B (gen 2): 1024 x 2048 tile, 2560 clk per 14 inner bits  -> 183 clk/bit
-//     entry 128 B (gen 3): 2048 x 1024 tile, 2560 clk per 16 inner bits  -> 160 clk/bit
-//     entry  64 B (here) : 4096 x  512 tile, 4608 clk per 32 inner bits  -> 144 clk/bit
+//     entry 64 B (gen 4): 4096 x 512 tile, 4608 LDS clk per 32 inner bits -> 144 clk/bit
+//     entry 32 B (here) : 8192 x 256 tile, 8704 LDS clk per 64 inner bits -> 136 clk/bit
 //
-// A stage is a whole 32-bit word of A = four 256-entry tables (4 x 16 KiB), two stages resident.
-//   * LDS bank row x holds [T0[x] | T1[x] | T2[x] | T3[x]], 64 bytes each.
-//   * lane = (row group lane>>2, 16-byte slot lane&3).  A row takes four gathers per stage; in
-//     gather i the row group reads table (rot + i) & 3 with rot = (row group >> 1) & 3.  Each of
-//     ds_read_b128's four 16-lane service groups holds four row groups -- {0,3,5,6}, {1,2,4,7},
-//     {8,11,13,14}, {9,10,12,15} -- whose `rot` values are 0,1,2,3 in every case, so the four row
-//     groups always sit in four different quarters of the bank row: conflict-free for ANY indices.
-//   * The packed A (a4_pack_kernel of m4rm8_leaf.hip, or the fused Winograd pass of aux_kernels.hip)
-//     holds a row's four index bytes already rotated by `rot`, so byte i of the dword IS gather i's
-//     index and the four v_perm selectors are compile-time constants.
-//   * Software pipeline: row g+1's four gathers are issued before row g's XORs, so a wave keeps
-//     4..8 reads in flight while its VALU works; the A dwords live in a ring of the next 16 rows.
-//   * Table building belongs to waves 0..3 (16 entries per thread and stage: 4 B rows for the
-//     base, 4 for a 4-bit Gray chain).  On every SIMD the wave dispatched first wins issue
-//     arbitration; with symmetric work it reached the stage's barrier ~15 % early and idled there.
-//     Giving it ALL of the building (B loads, base XORs, chain XORs, ds_writes) evens the two out:
-//     -6.5 % on the launch.  (The younger waves as builders: no gain.)  16 consecutive builder lanes
-//     = 4 slots x 4 tables of ONE entry index = one whole bank row per ds_write service group, so
-//     the table writes are conflict-free as well.
-//
-// Everything else is generation 3's: C-stationary tile in VGPRs (128 dwords per lane), one
-// v_perm_b32 per lookup address, one v_bitop3_b32 per dword folds two lookups, Gray-code table
-// build, chunk-major A, range-checked buffer descriptors, one barrier per stage.
+//   * LDS bank row x holds [T0[x] | ... | T7[x]], 32 bytes each; a stage is one 64-bit word of A.
+//   * lane = (row group lane>>1, 16-byte slot lane&1); a row takes eight gathers per stage.  A
+//     16-lane service group of ds_read_b128 holds eight row groups; they must sit in eight different
+//     32-byte slices of the bank row.  Row group g reads, in gather i, table
+//     4*((i>>2) ^ s) + ((r4 + i) & 3) with s = g & 1 and r4 = (g >> 2) & 3: the eight row groups of
+//     every service group carry the eight different (s, r4) pairs -- conflict-free for ANY indices.
+//   * The packed A is generation 3/4's chunk-major dword array with two per-row twists applied by
+//     the pack (rot mode 2): the index bytes of every dword rotated by r4(row), and the two dwords
+//     of a word swapped for rows with s(row) = 1 -- so dword slot h, byte i IS gather 4h+i's index
+//     and the v_perm selectors are compile-time constants.
+//   * The stage loop is generation 4's, run over 64 half-rows (4 gathers each) instead of 32 rows:
+//     software pipeline one half-row deep, A dwords in a ring of the next 8 rows, table building
+//     on waves 0..3 (16 entries per thread and stage), conflict-free table writes (16 consecutive
+//     builder lanes = 2 slots x 8 tables of ONE entry index).
 //
 // Replaces (result-identical) _mzd_mul_m4rm, mzd_make_table and _mzd_combine_N of the reference
 // (/root/reference m4ri/brilliantrussian.c:1032-1190, :163-211, m4ri/xor_template.h:12-227).
@@ -41,30 +33,29 @@
 #include "gf2_common.h"
 
 // which half of the workgroup builds the tables: 0 = waves 0..3 (dispatched first), 1 = waves 4..7
-#ifndef K8Q_BUILDER_HALF
-#define K8Q_BUILDER_HALF 0
+#ifndef K8O_BUILDER_HALF
+#define K8O_BUILDER_HALF 0
 #endif
 // rows in flight ahead of the XORs, per role
-#ifndef K8Q_PD_BUILDER
-#define K8Q_PD_BUILDER 1
+#ifndef K8O_PD_BUILDER
+#define K8O_PD_BUILDER 1
 #endif
-// rows of A held ahead by the gather-only waves (the builders hold K8_AR = 16)
-#ifndef K8Q_AR_OTHER
-#define K8Q_AR_OTHER 16
+// rows of A held ahead by the gather-only waves (the builders hold K8_AR = 8)
+#ifndef K8O_AR_OTHER
+#define K8O_AR_OTHER 16
 #endif
-#ifndef K8Q_PD_OTHER
-#define K8Q_PD_OTHER 1  // 2 and 3 fit in the gather-only waves' registers and measure the same
+#ifndef K8O_PD_OTHER
+#define K8O_PD_OTHER 1  // 2 and 3 fit in the gather-only waves' registers and measure the same
 #endif
 
 namespace {
 
 constexpr int K8_BITS  = 8;             // bits per table index
-constexpr int K8_STAGE = 4 * K8_BITS;   // inner bits per stage (four tables) = one dword of A
-constexpr int K8_CHUNK = K8_STAGE;      // inner bits per A dword
-constexpr int K8_TW    = 8;             // tile width in words (512 columns, 64 B per entry)
+constexpr int K8_STAGE = 8 * K8_BITS;   // inner bits per stage (eight tables) = one 64-bit word of A
+constexpr int K8_TW    = 4;             // tile width in words (256 columns, 32 B per entry)
 constexpr int K8_RG    = 32;            // rows per lane
-constexpr int K8_R     = 128 * K8_RG;   // tile rows: 128 row groups (8 waves x 16) x 32 rows
-constexpr int K8_AR    = 16;            // rows of A held ahead (ring)
+constexpr int K8_R     = 256 * K8_RG;   // tile rows: 256 row groups (8 waves x 32) x 32 rows
+constexpr int K8_AR    = 8;             // rows of A held ahead (ring; two dwords per row)
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
@@ -82,22 +73,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, ui
 }
 
 // v_perm_b32(a, coloff, sel): byte j of a -> bits 8..15 (table index), coloff.byte0 -> bits 0..7
-// (table quarter + column slot), buffer -> bit 16 (taken from coloff.byte1 == 0x01)
+// (table slice + column slot), buffer -> bit 16 (taken from coloff.byte1 == 0x01)
 __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int buf) {
   return 0x0c000000u | ((buf ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
 template <bool XOR_OUT>
-__global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|T1|T2|T3][64 B]
+__global__ __launch_bounds__(LEAF_THREADS) void m4rm8o_kernel(const LeafArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|...|T7][32 B]
   constexpr int RG = K8_RG, AR_MAX = 32;
 
   const int tid  = threadIdx.x;
-  const int c    = tid & 3;          // 16-byte column slot of the 64-byte table entry
-  const int rgrp = tid >> 2;         // row group 0..127
-  const int rot  = (tid >> 3) & 3;   // table this lane reads in the FIRST of a row's four gathers
-  // build role (builder waves only): 16 consecutive lanes = 4 slots x 4 tables of one entry index
-  const int bz   = (tid >> 2) & 3;   // table 0..3 of the stage
+  const int c    = tid & 1;          // 16-byte column slot of the 32-byte table entry
+  const int rgrp = tid >> 1;         // row group 0..255
+  const int r4   = (tid >> 3) & 3;   // (row group >> 2) & 3: byte rotation inside a dword's four tables
+  const int sw   = (tid >> 1) & 1;   // row group & 1: which half of the eight tables comes first
+  // build role (builder waves only): 16 consecutive lanes = 2 slots x 8 tables of one entry index
+  const int bz   = (tid >> 1) & 7;   // table 0..7 of the stage
   const int bhi  = (tid >> 4) & 15;  // bits 4..7 of the 16 entries this thread writes
 
   // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
@@ -116,7 +108,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const word *Bb      = p.B + bat * p.b_bs;
   word *__restrict__ Cb = p.C + bat * p.c_bs;
 
-  const int nq = 2 * ((p.l + 63) / 64);  // stages = dwords of A per row
+  const int nq = 2 * ((p.l + 63) / 64);  // dwords of A per row = 2 per stage
   // The packed A and B are read through raw buffer descriptors: per-lane 32-bit offsets from a wave-uniform
   // base, and the hardware range check returns 0 for rows >= m of the packed A and rows >= l of B -- exactly
   // the zero padding the algorithm wants, so the main loop has no edge branches.
@@ -135,20 +127,23 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // scratch reload + vmcnt(0), i.e. a full drain of the A/B prefetches, twice per stage pair
   const uint32_t b_uni  = (uint32_t)__builtin_amdgcn_readfirstlane(tile_n) * (K8_TW * 8u);
   const uint32_t b_slot = (uint32_t)bz * K8_BITS * b_rs + (uint32_t)c * 16u;
-  // per-lane perm operand of gather i: byte0 = table quarter ((rot + i) & 3) * 64 + column slot,
-  // byte1 = 0x01 (buffer bit source)
-  uint32_t coloff[4];
+  // per-lane perm operand of gather i of dword slot h: byte0 = table slice
+  // (4 * (h ^ sw) + ((r4 + i) & 3)) * 32 + column slot, byte1 = 0x01 (buffer bit source)
+  uint32_t coloff[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) coloff[i] = (uint32_t)(((rot + i) & 3) * 64 + c * 16) | 0x0100u;
-  unsigned char *const wr_base = lds + bhi * 16 * 256 + bz * 64 + c * 16;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) coloff[h][i] = (uint32_t)((4 * (h ^ sw) + ((r4 + i) & 3)) * 32 + c * 16) | 0x0100u;
+  unsigned char *const wr_base = lds + bhi * 16 * 256 + bz * 32 + c * 16;
 
   uint32_t acc[RG][4];
 #pragma unroll
   for (int t = 0; t < RG; ++t) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0u; }
 
-  const int q_begin = ks * p.chunks_per_split;
+  const int ns      = nq / 2;  // stages
+  const int q_begin = ks * p.chunks_per_split;  // in stages
   int q_end         = q_begin + p.chunks_per_split;
-  if (q_end > nq) q_end = nq;
+  if (q_end > ns) q_end = ns;
 
   // B rows of the table this thread helps to build: rows 4..7 of the 8 (-> base) and rows 0..3
   // (-> Gray chain).  Columns outside the matrix may hold a neighbour's bits when B is a window;
@@ -209,12 +204,15 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     *reinterpret_cast<uint4 *>(wr_base + buf * 65536 + gcode * 256) = make_uint4(cur[0], cur[1], cur[2], cur[3]);
   };
 
-  // the A dwords of the next 16 rows (a whole stage would cost the registers the pipeline needs)
-  uint32_t areg[AR_MAX];
-  auto load_a4 = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[4*slot ..]
-    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  a_rsrc, (int)(a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u), 0, 0));
-    areg[slot * 4 + 0] = v.x; areg[slot * 4 + 1] = v.y; areg[slot * 4 + 2] = v.z; areg[slot * 4 + 3] = v.w;
+  // the A dwords of the next 8 rows: areg[h][row % 8], h = dword slot of the stage's word
+  uint32_t areg[2][AR_MAX];
+  auto load_a4 = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[.][4*slot ..], both dwords
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    a_rsrc, (int)(a_lane + ((uint32_t)q * 2u + (uint32_t)h) * a_qs + (uint32_t)g * 16u), 0, 0));
+      areg[h][slot * 4 + 0] = v.x; areg[h][slot * 4 + 1] = v.y; areg[h][slot * 4 + 2] = v.z; areg[h][slot * 4 + 3] = v.w;
+    }
   };
 
   // one stage: gather from the four tables of stage s (buffer J = s & 1) while the builder waves
@@ -225,40 +223,43 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     // builder, on entry: cur = base of this thread's table of stage s+1 (made late in the previous
     // stage), blo_rows = its chain rows, bhi_rows = the base rows of stage s+2
     // pipeline depth: rows whose gathers are in flight ahead of the XORs
-    constexpr int PD = BUILDER ? K8Q_PD_BUILDER : K8Q_PD_OTHER;
-    constexpr int AR = BUILDER ? K8_AR : K8Q_AR_OTHER;  // rows of A held ahead in this role
+    // the pipeline's unit is a HALF row: the four gathers of one dword slot (unit u = 2*row + h)
+    constexpr int PD = BUILDER ? K8O_PD_BUILDER : K8O_PD_OTHER;
+    constexpr int NU = 2 * RG;
+    constexpr int AR = BUILDER ? K8_AR : K8O_AR_OTHER;  // rows of A held ahead in this role
     uint4 tp[PD + 1][4];
-    auto issue = [&](int g) {
+    auto issue = [&](int u) {
+      const int g = u >> 1, h = u & 1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t ad  = __builtin_amdgcn_perm(areg[g % AR], coloff[i], perm_sel(i, J));
-        tp[g % (PD + 1)][i] = *reinterpret_cast<const uint4 *>(lds + ad);
+        const uint32_t ad  = __builtin_amdgcn_perm(areg[h][g % AR], coloff[h][i], perm_sel(i, J));
+        tp[u % (PD + 1)][i] = *reinterpret_cast<const uint4 *>(lds + ad);
       }
     };
 #pragma unroll
-    for (int g = 0; g < PD; ++g) issue(g);
+    for (int u = 0; u < PD; ++u) issue(u);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      const int j = g + PD;  // the row whose gathers go out now
-      if (j < RG) issue(j);
-      if (j < RG && j % 4 == 3) {  // rows 4k..4k+3 have all issued: their ring slot takes the rows 16 ahead
-        const int k = j / 4, ahead = 4 * k + AR;
+    for (int u = 0; u < NU; ++u) {
+      const int j = u + PD;  // the half row whose gathers go out now
+      if (j < NU) issue(j);
+      if (j < NU && j % 8 == 7) {  // rows 4k..4k+3 have all issued: their ring slots take the rows 8 ahead
+        const int k = j / 8, ahead = 4 * k + AR;
         load_a4(k % (AR / 4), (ahead % RG) / 4, s + ahead / RG);
       }
       if constexpr (BUILDER) {
-        // the 16 table entries go out with the first 16 rows, so the chain rows are dead early and
-        // their successors (first needed two rows into the next stage) get half a stage to arrive
-        if (g < 16) put_entry(g, J ^ 1);
-        if (g == 17) load_lo(s + 2);
-        if (g == 21) {
+        // the 16 table entries go out with the first 32 half rows (every other one), so the chain
+        // rows are dead early and their successors get a third of a stage to arrive
+        if (u < 32 && u % 2 == 0) put_entry(u / 2, J ^ 1);
+        if (u == 34) load_lo(s + 2);
+        if (u == 42) {
           make_base();     // base of stage s+2's table (its entries are written during stage s+1)
           load_hi(s + 3);  // and the base rows after that: a whole stage of latency budget
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      uint32_t *a     = acc[g];
-      const uint4 *tt = tp[g % (PD + 1)];
+      uint32_t *a     = acc[u >> 1];
+      const uint4 *tt = tp[u % (PD + 1)];
       a[0] = xor3(xor3(a[0], tt[0].x, tt[1].x), tt[2].x, tt[3].x);
       a[1] = xor3(xor3(a[1], tt[0].y, tt[1].y), tt[2].y, tt[3].y);
       a[2] = xor3(xor3(a[2], tt[0].z, tt[1].z), tt[2].z, tt[3].z);
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // the gather-only waves carry no B rows at all
   auto run = [&](auto btag) {
     constexpr bool BUILDER = decltype(btag)::value;
-    constexpr int AR       = BUILDER ? K8_AR : K8Q_AR_OTHER;
+    constexpr int AR       = BUILDER ? K8_AR : K8O_AR_OTHER;
 #pragma unroll
-    for (int g = 0; g < AR / 4; ++g) load_a4(g, g, q_begin);  // q = stage here: one dword of A per stage
+    for (int g = 0; g < AR / 4; ++g) load_a4(g, g, q_begin);
     if constexpr (BUILDER) {
       // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
       load_hi(q_begin);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     }
   };
   if (q_begin < q_end) {
-    if (__builtin_amdgcn_readfirstlane(tid >> 8) == K8Q_BUILDER_HALF) run(std::true_type{});
+    if (__builtin_amdgcn_readfirstlane(tid >> 8) == K8O_BUILDER_HALF) run(std::true_type{});
     else run(std::false_type{});
   }
 
@@ -334,31 +335,32 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
 }  // namespace
 
-// Host launcher.  A must already be packed chunk-major WITH the byte rotation (gf2_launch_a4_pack_rot
-// of m4rm8_leaf.hip, rot = 1, or gf2_launch_winograd_down2_pack) into `a4_ws`.  Tiles are 4096 rows
-// x 512 columns.
-extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws) {
+// Host launcher.  A must already be packed chunk-major with generation 5's twists
+// (gf2_launch_a4_pack_rot of m4rm8_leaf.hip with rot = 2, or the fused Winograd passes) into `a4_ws`.
+// Tiles are 8192 rows x 256 columns.
+extern "C" hipError_t gf2_launch_m4rm8o(hipStream_t stream, LeafArgs a, word *a4_ws) {
   a.wn        = (int32_t)words_of(a.n);
   a.tiles_m   = (a.m + K8_R - 1) / K8_R;
   a.tiles_n   = (a.wn + K8_TW - 1) / K8_TW;
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0 || a.l <= 0) return hipSuccess;
   const int64_t nq    = 2 * (((int64_t)a.l + 63) / 64);
+  const int64_t ns    = nq / 2;  // 64-bit stages
   const int64_t m_pad = ((int64_t)a.m + 3) & ~(int64_t)3;
   a.Apk        = reinterpret_cast<const uint32_t *>(a4_ws);
   a.apk_stride = m_pad;
   a.apk_bs     = m_pad * nq;
   if ((uint64_t)m_pad * (uint64_t)nq * 4 >= (1ull << 32)) return hipErrorInvalidValue;
   if (a.ksplit < 1) a.ksplit = 1;
-  int cps = (int)((nq + a.ksplit - 1) / a.ksplit);
+  int cps = (int)((ns + a.ksplit - 1) / a.ksplit);
   cps     = (cps + 1) & ~1;  // even: a split starts in table buffer 0
   if (cps < 2) cps = 2;
-  a.chunks_per_split = cps;
-  a.ksplit           = (int)((nq + cps - 1) / cps);
+  a.chunks_per_split = cps;  // in stages
+  a.ksplit           = (int)((ns + cps - 1) / cps);
   if (a.ksplit > 1 && a.mode == 0) return hipErrorInvalidValue;  // caller must pre-zero C and pass mode 1
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
-  if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<false>), grid, block, 0, stream, a);
-  else             hipLaunchKernelGGL((m4rm8q_kernel<true>), grid, block, 0, stream, a);
+  if (a.mode == 0) hipLaunchKernelGGL((m4rm8o_kernel<false>), grid, block, 0, stream, a);
+  else             hipLaunchKernelGGL((m4rm8o_kernel<true>), grid, block, 0, stream, a);
   return hipGetLastError();
 }

@@ -3,7 +3,7 @@
 // ragged/batched/strided shapes, then times the bench-sized launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp \
 //         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/m4rm7_leaf.hip m4ri_amd/csrc/m4rm8_leaf.hip \
-//         m4ri_amd/csrc/m4rm8q_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
+//         m4ri_amd/csrc/m4rm8q_leaf.hip tools/experiments/m4rm8o_leaf.hip tools/experiments/m4rm_leaf_db.hip -o build/leaf_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +22,7 @@ extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
 extern "C" hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
+extern "C" hipError_t gf2_launch_m4rm8o(hipStream_t stream, LeafArgs a, word *a4_ws);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -29,6 +30,12 @@ static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 // through LDS); 9 = the double-buffered experiment
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 9) return gf2_launch_m4rm_leaf_db(0, a, rg, ug);
+  if (pipe == 13) {  // generation 5: 8-bit tables, 32-byte entries, 8192 x 256 tiles
+    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
+    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
+    CK(gf2_launch_a4_pack_rot(0, a, g_a7, 2));
+    return gf2_launch_m4rm8o(0, a, g_a7);
+  }
   if (pipe == 11) {  // generation 4: 8-bit tables, 64-byte entries, 4096 x 512 tiles
     const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
@@ -164,7 +171,7 @@ int main(int argc, char **argv) {
   sm_state = 12345;
   int fails = 0;
   const int rgs[3] = {32, 24, 16};
-  if (!(argc > 1 && (!strcmp(argv[1], "--one") || !strcmp(argv[1], "--v4"))))
+  if (!(argc > 1 && (!strcmp(argv[1], "--one") || !strcmp(argv[1], "--v4") || !strcmp(argv[1], "--shape"))))
   for (int rg : rgs) {
     fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0, 4, 0);
     fails += check(1000, 777, 1234, 1, 1, 0, rg, 1, 4, 0);
@@ -176,12 +183,16 @@ int main(int argc, char **argv) {
     fails += check(193, 65, 65, 1, 2, 1, rg, 0, 4, 0);
   }
   if (argc > 1 && !strcmp(argv[1], "--check-only")) return fails != 0;
+  if (argc > 6 && !strcmp(argv[1], "--shape")) {  // --shape m l n batch pipe : time one variant on one shape
+    timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), 1, 32, 3, 1, atoi(argv[6]));
+    return 0;
+  }
   if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch : profile a single variant
     timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), 3, atoi(argv[3]), atoi(argv[4]));
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--v4")) {  // generation 4 alone (build with -DK8Q_BUILDER_HALF=1 for the control experiment)
-    const int v[][3] = {{32, 1, 11}};
+    const int v[][3] = {{32, 1, 11}, {32, 1, 13}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
