@@ -104,6 +104,24 @@ def lds_model(gen, m, l, n, products, launch_ms):
             "tile": [tr, tc], "bits_per_stage": bits, "clock_hz": PEAK_CLOCK_HZ}
 
 
+def measured_copy_gbs():
+    """On-box HBM copy rate (GB/s, read + write bytes) of a 1 GiB device-to-device copy: the practical
+    peak SURVEY.md 8(d) asks to report beside the vendor 8 TB/s."""
+    import torch
+    src = torch.empty(1 << 27, dtype=torch.int64, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return 2.0 * src.numel() * 8 / (best * 1e-3) / 1e9
+
+
 def leaf_traffic(n, world):
     """HBM bytes of one leaf launch from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
     correction + WRITE_SIZE, MI355X_MICROARCH.md HBM section) -- counters cannot be read from inside
@@ -232,11 +250,16 @@ def main():
         step()
     fence()
     m4ri_amd.set_profiling(True)
+    # per-step marks on the stream the products run on (no synchronisation inside the timed region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        marks[k].record()
         step()
+    marks[args.steps].record()
     fence()
     t1 = time.perf_counter()
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     stats = m4ri_amd.get_stats()  # last step's schedule + its leaf launch durations (HIP events)
     m4ri_amd.set_profiling(False)
     elapsed = t1 - t0
@@ -318,7 +341,9 @@ def main():
                         "prices the launch against the LDS-array cycles it needs (DESIGN.md 3.1)",
             },
         }
+        out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
         if args.workload == "mul":
+            copy_gbs = measured_copy_gbs()
             # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
             # this rank's block product / step time); the compulsory bytes beside it
             pm, pl, pn = r1 - r0, k1 - k0, c1 - c0
@@ -330,8 +355,10 @@ def main():
                 "achieved": bs / (ms_per_step * 1e-3) / 1e9,
                 "frac": bs / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
+                "copy_peak": copy_gbs, "frac_of_copy_peak": bs / (ms_per_step * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
                 "note": "unfused reference schedule bytes (15 quadrant adds/level) over the measured step time; "
-                        "our fused down/up passes move fewer bytes (11 quadrant transfers per pass)",
+                        "our fused three-level passes move far fewer bytes; copy_peak = this GPU's measured "
+                        "device-to-device copy rate (read + write bytes)",
             }
         if world == 1 and not args.no_cpu_baseline:
             try:

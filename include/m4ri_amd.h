@@ -136,6 +136,21 @@ int m4ri_amd_set_max_fuse(int levels);
 /* Release the engine's workspace (device memory pool). */
 void m4ri_amd_release_workspace(void);
 
+/* ---- part 3: residency (device-resident matrix handles) -----------------------------
+ * Opt-in, for programs that chain products (TRSM / PLE Schur complements: triangular.c:100,348,439,
+ * 503, ple.c:126 call mzd_addmul on windows of the same few matrices).  A pinned matrix keeps a device
+ * copy in the host layout; the M4RI-named entry points of part 1 then read pinned operands -- and
+ * windows (mzd_init_window) into them -- where they are, and leave a pinned result on the device: no
+ * PCIe traffic at all when everything is pinned.  The host copy of a pinned matrix that received a
+ * result is STALE until m4ri_amd_sync or m4ri_amd_unpin; the host must not modify a pinned matrix
+ * without telling (m4ri_amd_host_modified).  Unpin before mzd_free.  All return 0 on success, -1 if
+ * M is NULL / a window / empty (pin) or not pinned (the others). */
+int m4ri_amd_pin(mzd_t *M);            /* M owns its block (not a window): upload it now               */
+int m4ri_amd_sync(mzd_t *M);           /* bring the host copy up to date (M or a window into it)        */
+int m4ri_amd_host_modified(mzd_t *M);  /* the host wrote into M: refresh the device copy               */
+int m4ri_amd_unpin(mzd_t *M);          /* sync, then drop the device copy                               */
+int m4ri_amd_is_pinned(const mzd_t *M);/* 0 no, 1 yes and host copy current, 2 yes and host copy stale  */
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,11 @@ SYMBOLS = {
     "m4ri_amd_mask_tail_dev": (_I, [_P, _I64, _I64, _I64, _P]),
     "m4ri_amd_set_profiling": (None, [_I]),
     "m4ri_amd_set_max_fuse": (_I, [_I]),
+    "m4ri_amd_pin": (_I, [MzdPtr]),
+    "m4ri_amd_sync": (_I, [MzdPtr]),
+    "m4ri_amd_host_modified": (_I, [MzdPtr]),
+    "m4ri_amd_unpin": (_I, [MzdPtr]),
+    "m4ri_amd_is_pinned": (_I, [MzdPtr]),
     "m4ri_amd_get_stats": (_I, [ctypes.POINTER(Stats)]),
     "m4ri_amd_release_workspace": (None, []),
 }
@@ -176,6 +181,33 @@ def xor_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int,
 
 def fill_dev(M: int, stride: int, rows: int, ncols: int, seed: int, stream: int = 0) -> None:
     _check(lib().m4ri_amd_fill_dev(M, stride, rows, ncols, seed, stream), "m4ri_amd_fill_dev")
+
+
+# ---- residency (include/m4ri_amd.h part 3) --------------------------------------------------------
+def pin(M: Mzd) -> None:
+    """Keep a device copy of M (which must own its block); products then read it, and windows into it,
+    in place and leave results there.  The host copy is stale after a product wrote into it until sync()."""
+    if lib().m4ri_amd_pin(M.ptr) != 0:
+        raise ValueError("m4ri_amd_pin: matrix is a window, empty or NULL")
+
+
+def sync(M: Mzd) -> None:
+    if lib().m4ri_amd_sync(M.ptr) != 0:
+        raise ValueError("m4ri_amd_sync: matrix is not pinned")
+
+
+def host_modified(M: Mzd) -> None:
+    if lib().m4ri_amd_host_modified(M.ptr) != 0:
+        raise ValueError("m4ri_amd_host_modified: matrix is not pinned")
+
+
+def unpin(M: Mzd) -> None:
+    if lib().m4ri_amd_unpin(M.ptr) != 0:
+        raise ValueError("m4ri_amd_unpin: matrix is not pinned")
+
+
+def is_pinned(M: Mzd) -> int:
+    return int(lib().m4ri_amd_is_pinned(M.ptr))
 
 
 def set_max_fuse(levels: int) -> int:

@@ -197,6 +197,22 @@ __global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *__restrict__
   }
 }
 
+// C = A on strided views, the last word of every row merged under `mask` (bits outside it keep C's
+// value): the device twin of mzd_copy's masked last word (mzd.c:1363-1382), used to put a result into
+// a window of a device-resident parent without touching the parent's other columns
+__global__ __launch_bounds__(AUX_THREADS) void copy_masked_kernel(word *__restrict__ C, int64_t cs,
+                                                                  const word *__restrict__ A, int64_t as,
+                                                                  int64_t rows, int64_t w, word mask) {
+  const int64_t total  = rows * w;
+  const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / w, k = i - r * w;
+    const word v = A[r * as + k];
+    word *c      = C + r * cs + k;
+    *c           = (k == w - 1) ? ((*c & ~mask) | (v & mask)) : v;
+  }
+}
+
 // zero the bits at column >= ncols of the last valid word of every row (establishes the engine's
 // "zero excess" invariant for operands uploaded from windows, mzd.h:117-123)
 __global__ __launch_bounds__(AUX_THREADS) void mask_tail_kernel(word *__restrict__ M, int64_t stride,
@@ -300,6 +316,15 @@ extern "C" hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t
                                          int64_t as, const word *B, int64_t bs, int64_t rows, int64_t w) {
   if (rows * w == 0) return hipSuccess;
   hipLaunchKernelGGL(rowwise_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, B, bs, rows, w, op);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_copy_masked(hipStream_t s, word *C, int64_t cs, const word *A, int64_t as, int64_t rows,
+                                             int64_t ncols) {
+  if (rows == 0 || ncols == 0) return hipSuccess;
+  const int64_t w = words_of(ncols);
+  const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
+  hipLaunchKernelGGL(copy_masked_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, rows, w, mask);
   return hipGetLastError();
 }
 

@@ -8,8 +8,10 @@
 //   mzd_mul_mp, mzd_addmul_mp                                            m4ri/mp.h:47,62
 //
 // Each call: upload A and B (hipMemcpy2D straight out of the caller's rows, so windows cost
-// nothing extra), zero the excess bits on the device, run the engine, and copy C back touching only
-// the words and bits the reference would touch (mzd.h:117-123).  There is NO CPU fallback: a HIP
+// nothing extra) into a grow-only staging arena, zero the excess bits on the device, run the engine,
+// and copy C back touching only the words and bits the reference would touch (mzd.h:117-123).
+// Matrices pinned with m4ri_amd_pin (part 3 of the header) are not moved at all: operands are read
+// from, and results left in, their device copy -- windows into a pinned parent included.  There is NO CPU fallback: a HIP
 // failure is fatal, like every other error on this path (misc.c:36-42).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -51,20 +53,46 @@ mzd_t *result_init(rci_t r, rci_t c) {
   return host_init ? host_init(r, c) : m4ri_amd_mzd_init(r, c);
 }
 
-struct DevMat {
-  word *p       = nullptr;
-  int64_t stride = 0;
-  ~DevMat() { if (p) (void)hipFree(p); }
-};
+extern "C" hipError_t gf2_launch_copy_masked(hipStream_t s, word *C, int64_t cs, const word *A, int64_t as, int64_t rows, int64_t ncols);
 
-void dev_alloc(DevMat &d, int64_t rows, int64_t ncols) {
-  int64_t w = words_of(ncols);
-  d.stride  = (w + 1) & ~(int64_t)1;  // even: rows stay 16-byte aligned
-  size_t bytes = (size_t)(rows > 0 ? rows : 1) * (size_t)(d.stride > 0 ? d.stride : 2) * 8;
-  HIPDIE(hipMalloc(reinterpret_cast<void **>(&d.p), bytes));
+// ---- staging arena ------------------------------------------------------------------------------
+// Device copies of host operands live in ONE grow-only buffer that is re-carved on every call: no
+// hipMalloc/hipFree per product (they cost more than a small product itself).
+struct Arena {
+  word *base  = nullptr;
+  size_t cap  = 0;  // words
+  size_t used = 0;
+} g_arena;
+
+void arena_reserve(size_t words) {
+  g_arena.used = 0;
+  if (words <= g_arena.cap) return;
+  HIPDIE(hipDeviceSynchronize());
+  if (g_arena.base) HIPDIE(hipFree(g_arena.base));
+  g_arena.base = nullptr; g_arena.cap = 0;
+  HIPDIE(hipMalloc(reinterpret_cast<void **>(&g_arena.base), words * 8));
+  g_arena.cap = words;
 }
 
-// host rows -> fresh device matrix with zero excess
+struct DevMat {
+  word *p        = nullptr;
+  int64_t stride = 0;
+};
+
+size_t dev_words(int64_t rows, int64_t ncols) {
+  const int64_t w = words_of(ncols), st = (w + 1) & ~(int64_t)1;
+  return (((size_t)(rows > 0 ? rows : 1) * (size_t)(st > 0 ? st : 2)) + 31) & ~(size_t)31;  // 256-byte granules
+}
+
+void dev_alloc(DevMat &d, int64_t rows, int64_t ncols) {
+  const int64_t w = words_of(ncols);
+  d.stride        = (w + 1) & ~(int64_t)1;  // even: rows stay 16-byte aligned
+  d.p             = g_arena.base + g_arena.used;
+  g_arena.used += dev_words(rows, ncols);
+  if (g_arena.used > g_arena.cap) die("m4ri_amd: staging arena overrun (internal error)\n");
+}
+
+// host rows -> device matrix with zero excess
 void upload(DevMat &d, const mzd_t *M) {
   dev_alloc(d, M->nrows, M->ncols);
   if (M->nrows == 0 || M->width == 0) return;
@@ -97,6 +125,43 @@ void download(const DevMat &d, mzd_t *C) {
   }
 }
 
+// ---- residency table (include/m4ri_amd.h part 3) ------------------------------------
+// A pinned matrix keeps a device copy with the host layout (same rowstride), so any window into it
+// is the same offset into the device copy.  Products read pinned operands where they are and leave a
+// pinned result on the device (the host copy is stale until m4ri_amd_sync / m4ri_amd_unpin).
+struct Pin {
+  const word *hbase;  // host block
+  size_t words;       // nrows * rowstride
+  int64_t rowstride;
+  rci_t nrows, ncols;
+  word *dbase;
+  bool dev_newer;
+  mzd_t *owner;
+};
+std::vector<Pin> g_pins;
+
+Pin *find_pin(const mzd_t *M) {
+  if (!M || !M->data) return nullptr;
+  for (Pin &p : g_pins)
+    if (M->data >= p.hbase && M->data < p.hbase + p.words && M->rowstride == p.rowstride) return &p;
+  return nullptr;
+}
+
+// device view of a host operand: inside its pinned parent, or a staged upload (copy == false: space only)
+DevMat operand(const mzd_t *M, bool copy, Pin **pin_out = nullptr) {
+  DevMat d;
+  Pin *p = find_pin(M);
+  if (pin_out) *pin_out = p;
+  if (p) {
+    d.p      = p->dbase + (M->data - p->hbase);
+    d.stride = p->rowstride;
+    return d;
+  }
+  if (copy) upload(d, M);
+  else dev_alloc(d, M->nrows, M->ncols);
+  return d;
+}
+
 int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
   if (cutoff < 0) die("%s: cutoff must be >= 0.\n", who);
   return cutoff;  // 0 = engine default; >0 normalised inside m4ri_amd_mul_dev
@@ -109,21 +174,64 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
-  DevMat dA, dB, dC;
-  upload(dA, A);
   const bool same = (A == B);
-  if (!same) upload(dB, B);
-  const word *pB      = same ? dA.p : dB.p;
-  const int64_t sB    = same ? dA.stride : dB.stride;
-  if (add) upload(dC, C);
-  else dev_alloc(dC, C->nrows, C->ncols);
+  Pin *pinC = find_pin(C);
+  // a pinned C whose last word is shared with other columns of its parent is computed in staging and
+  // merged under the column mask; otherwise the engine writes straight into the parent
+  const bool c_staged = !pinC || (C->ncols % 64 != 0 && C->ncols != pinC->ncols);
+  arena_reserve((find_pin(A) ? 0 : dev_words(A->nrows, A->ncols)) + ((same || find_pin(B)) ? 0 : dev_words(B->nrows, B->ncols)) +
+                (c_staged ? dev_words(C->nrows, C->ncols) : 0));
+  const DevMat dA = operand(A, true);
+  const DevMat dB = same ? dA : operand(B, true);
+  DevMat dC;
+  if (!c_staged) dC = operand(C, false);
+  else if (!pinC) { if (add) upload(dC, C); else dev_alloc(dC, C->nrows, C->ncols); }
+  else {
+    dev_alloc(dC, C->nrows, C->ncols);
+    if (add) {
+      const DevMat src = operand(C, false);
+      HIPDIE(hipMemcpy2DAsync(dC.p, (size_t)dC.stride * 8, src.p, (size_t)src.stride * 8, (size_t)C->width * 8, (size_t)C->nrows,
+                              hipMemcpyDeviceToDevice, nullptr));
+      HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, C->nrows, C->ncols, nullptr));
+    }
+  }
   if (strassen)
-    HIPDIE(m4ri_amd_mul_dev(dC.p, dC.stride, dA.p, dA.stride, pB, sB, A->nrows, A->ncols, B->ncols, add, cutoff, nullptr));
+    HIPDIE(m4ri_amd_mul_dev(dC.p, dC.stride, dA.p, dA.stride, dB.p, dB.stride, A->nrows, A->ncols, B->ncols, add, cutoff, nullptr));
   else
-    HIPDIE(m4ri_amd_m4rm_dev(dC.p, dC.stride, dA.p, dA.stride, pB, sB, A->nrows, A->ncols, B->ncols, add, 0, nullptr));
-  download(dC, C);
+    HIPDIE(m4ri_amd_m4rm_dev(dC.p, dC.stride, dA.p, dA.stride, dB.p, dB.stride, A->nrows, A->ncols, B->ncols, add, 0, nullptr));
+  // a B that is a window of a pinned parent carries its neighbours' bits in the last word, and they
+  // land in C's excess columns: clear them before the result leaves the staging buffer
+  if (c_staged) HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, C->nrows, C->ncols, nullptr));
+  if (pinC) {
+    if (c_staged) {
+      const DevMat dst = operand(C, false);
+      HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, dC.p, dC.stride, C->nrows, C->ncols));
+    }
+    pinC->dev_newer = true;  // the host copy is stale until m4ri_amd_sync / m4ri_amd_unpin
+  } else {
+    download(dC, C);
+  }
   HIPDIE(hipDeviceSynchronize());
   return C;
+}
+
+void pin_download(Pin &p) {
+  if (!p.dev_newer) return;
+  const int64_t width = words_of(p.ncols);
+  if (p.nrows && width)
+    HIPDIE(hipMemcpy2D(const_cast<word *>(p.hbase), (size_t)p.rowstride * 8, p.dbase, (size_t)p.rowstride * 8, (size_t)width * 8,
+                       (size_t)p.nrows, hipMemcpyDeviceToHost));
+  p.dev_newer = false;
+}
+
+void pin_upload(Pin &p) {
+  const int64_t width = words_of(p.ncols);
+  if (p.nrows && width) {
+    HIPDIE(hipMemcpy(p.dbase, p.hbase, p.words * 8, hipMemcpyHostToDevice));  // padding words included: same layout
+    HIPDIE(m4ri_amd_mask_tail_dev(p.dbase, p.rowstride, p.nrows, p.ncols, nullptr));
+    HIPDIE(hipDeviceSynchronize());
+  }
+  p.dev_newer = false;
 }
 
 }  // namespace
@@ -201,6 +309,56 @@ mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // br
 mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear) {  // brilliantrussian.c:1032
   (void)k;
   return run(C, A, B, clear == 0, false, 0);
+}
+
+// ---- part 3: residency ----------------------------------------------------------------------------
+int m4ri_amd_pin(mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  if (!M || (M->flags & FLAG_WINDOW)) return -1;  // pin the owner of the block; windows into it follow
+  if (find_pin(M)) return 0;
+  if (M->nrows == 0 || M->ncols == 0 || !M->data) return -1;
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  Pin p{};
+  p.hbase = M->data; p.words = (size_t)M->nrows * (size_t)M->rowstride; p.rowstride = M->rowstride;
+  p.nrows = M->nrows; p.ncols = M->ncols; p.owner = M;
+  HIPDIE(hipMalloc(reinterpret_cast<void **>(&p.dbase), p.words * 8));
+  pin_upload(p);
+  g_pins.push_back(p);
+  return 0;
+}
+
+int m4ri_amd_sync(mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  Pin *p = find_pin(M);
+  if (!p) return -1;
+  pin_download(*p);
+  return 0;
+}
+
+int m4ri_amd_host_modified(mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  Pin *p = find_pin(M);
+  if (!p) return -1;
+  pin_upload(*p);
+  return 0;
+}
+
+int m4ri_amd_unpin(mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  Pin *p = find_pin(M);
+  if (!p) return -1;
+  pin_download(*p);
+  HIPDIE(hipFree(p->dbase));
+  g_pins.erase(g_pins.begin() + (p - g_pins.data()));
+  return 0;
+}
+
+int m4ri_amd_is_pinned(const mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  Pin *p = find_pin(M);
+  return p ? (p->dev_newer ? 2 : 1) : 0;
 }
 
 mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mzd_mul(C, A, B, cutoff); }        // mp.c:277-297
