@@ -64,6 +64,61 @@ static int window_case(rci_t M, rci_t N, rci_t m, rci_t n) {
   return bad;
 }
 
+/* The reference's own L4 routines: their internal mzd_addmul / _mzd_addmul calls on WINDOWS
+ * (triangular.c:100,348,439,503, ple.c:126, solve.c:89) go through the PLT and land on the GPU too.
+ * Checked by the defining identities with the reference's naive CPU product. */
+static long long interposed_products(void) {
+  typedef int (*stats_fn)(void *);
+  stats_fn st = (stats_fn)dlsym(RTLD_DEFAULT, "m4ri_amd_get_stats");
+  struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d; } s;
+  return (st && st(&s) == 0) ? s.leaf_launches : -1;
+}
+
+static int l4_case(rci_t n, rci_t m, int cutoff) {
+  int bad = 0;
+  /* U: random unit upper triangular, L = U^T-shaped lower triangular */
+  mzd_t *U = mzd_init(n, n), *L = mzd_init(n, n);
+  mzd_randomize(U);
+  mzd_randomize(L);
+  for (rci_t i = 0; i < n; ++i) {
+    for (rci_t j = 0; j < i; ++j) mzd_write_bit(U, i, j, 0);
+    for (rci_t j = i + 1; j < n; ++j) mzd_write_bit(L, i, j, 0);
+    mzd_write_bit(U, i, i, 1);
+    mzd_write_bit(L, i, i, 1);
+  }
+  mzd_t *B0 = mzd_init(n, m);
+  mzd_randomize(B0);
+  mzd_t *X = mzd_copy(NULL, B0);
+  mzd_trsm_upper_left(U, X, cutoff);                 /* U X = B0 */
+  mzd_t *Chk = mzd_mul_naive(NULL, U, X);
+  bad |= !mzd_equal(Chk, B0);
+  mzd_free(Chk);
+  mzd_copy(X, B0);
+  mzd_trsm_lower_left(L, X, cutoff);                 /* L X = B0 */
+  Chk = mzd_mul_naive(NULL, L, X);
+  bad |= !mzd_equal(Chk, B0);
+  mzd_free(Chk);
+  /* solve A X = B0 with A = L*U (invertible): PLE + both TRSMs inside */
+  mzd_t *A = mzd_mul_naive(NULL, L, U), *A0 = mzd_copy(NULL, A);
+  mzd_copy(X, B0);
+  bad |= mzd_solve_left(A, X, cutoff, 0) != 0;
+  Chk = mzd_mul_naive(NULL, A0, X);
+  bad |= !mzd_equal(Chk, B0);
+  mzd_free(Chk);
+  /* PLE of a rank-deficient matrix: rank must match naive Gaussian elimination */
+  mzd_t *R = mzd_init(n, n);
+  mzd_randomize(R);
+  for (rci_t i = n / 2; i < n; ++i) mzd_copy_row(R, i, R, i - n / 2);   /* rank <= n/2 */
+  mzd_t *R2 = mzd_copy(NULL, R);
+  mzp_t *P = mzp_init(n), *Q = mzp_init(n);
+  const rci_t r1 = mzd_ple(R, P, Q, cutoff), r2 = mzd_echelonize_naive(R2, 0);
+  bad |= r1 != r2;
+  printf("  L4 n=%d m=%d cutoff=%d (trsm upper/lower, solve_left, ple rank %d/%d) : %s\n", n, m, cutoff, r1, r2, bad ? "FAILED" : "ok");
+  mzp_free(P); mzp_free(Q);
+  mzd_free(U); mzd_free(L); mzd_free(B0); mzd_free(X); mzd_free(A); mzd_free(A0); mzd_free(R); mzd_free(R2);
+  return bad;
+}
+
 int main(void) {
   int status = 0;
   srandom(17);
@@ -83,6 +138,9 @@ int main(void) {
   status += window_case(1024, 1024, 513, 511);
   status += window_case(1024, 1024, 512, 768 + 30);
   status += window_case(2048, 2048, 1024, 1024);
+  status += l4_case(2048, 1000, 0);
+  status += l4_case(3000, 3000, 512);
+  if (interposed_products() >= 0) printf("dropin_driver: the L4 cases ended on an interposed product (%lld leaf launch(es))\n", interposed_products());
   if (st) {
     struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d; } s;
     if (st(&s) == 0) printf("dropin_driver: last interposed call used %d leaf launch(es)\n", s.leaf_launches);

@@ -29,3 +29,5 @@ def test_ld_preload_drop_in():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "interposed: yes" in r.stdout and "ALL OK" in r.stdout and "FAILED" not in r.stdout
     assert "leaf launch" in r.stdout
+    # the reference's own TRSM / solve / PLE ran with their internal addmul calls on the GPU
+    assert r.stdout.count("  L4 n=") == 2 and "the L4 cases ended on an interposed product" in r.stdout
