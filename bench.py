@@ -154,7 +154,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=65536, help="n of the n x n x n product")
-    ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384"])
+    ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384", "rect131072"],
+                    help="mul: n^3 mzd_mul (the headline, configs[2]/[3]); leaf16384: configs[1]; "
+                         "rect131072: 131072 x 8192 x 131072 (configs[4]), rows of A/C split over the ranks")
     ap.add_argument("--cutoff", type=int, default=0)
     ap.add_argument("--grid", default="", help="gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
     ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
@@ -192,15 +194,18 @@ def main():
         n = 16384
     else:
         n = args.size
-    w = n // 64
     assert n % 64 == 0
+    M, L, N = (131072, 8192, 131072) if args.workload == "rect131072" else (n, n, n)
+    wl, w = L // 64, N // 64  # words per row of A, and of B / C
 
     # ---- operands, resident in HBM (every rank generates the same A and B; it uses views) ----
-    A = torch.empty((n, w), dtype=torch.int64, device="cuda")
-    B = torch.empty((n, w), dtype=torch.int64, device="cuda")
-    m4ri_amd.fill_dev(A.data_ptr(), w, n, n, 3, stream)
-    m4ri_amd.fill_dev(B.data_ptr(), w, n, n, 4, stream)
-    plan = sharding.make_plan(world, rank, n, n, n, grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None)
+    A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
+    B = torch.empty((L, w), dtype=torch.int64, device="cuda")
+    seeds = (5, 6) if args.workload == "rect131072" else (3, 4)
+    m4ri_amd.fill_dev(A.data_ptr(), wl, M, L, seeds[0], stream)
+    m4ri_amd.fill_dev(B.data_ptr(), w, L, N, seeds[1], stream)
+    grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else ((world, 1, 1) if args.workload == "rect131072" else None)
+    plan = sharding.make_plan(world, rank, M, L, N, grid=grid)
     r0, r1 = plan.row_range()
     c0, c1 = plan.col_range()
     k0, k1 = plan.inner_range()
@@ -211,12 +216,12 @@ def main():
     recv_buf = torch.empty((cuts[plan.h + 1] - cuts[plan.h], pw), dtype=torch.int64, device="cuda") if gh > 1 else None
 
     def multiply(r0, r1, k0, k1, c0, c1):
-        a_ptr = A.data_ptr() + 8 * (r0 * w + k0 // 64)
+        a_ptr = A.data_ptr() + 8 * (r0 * wl + k0 // 64)
         b_ptr = B.data_ptr() + 8 * (k0 * w + c0 // 64)
         if args.workload == "leaf16384":
-            m4ri_amd.m4rm_dev(P.data_ptr(), pw, a_ptr, w, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, 0, stream)
+            m4ri_amd.m4rm_dev(P.data_ptr(), pw, a_ptr, wl, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, 0, stream)
         else:
-            m4ri_amd.mul_dev(P.data_ptr(), pw, a_ptr, w, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, args.cutoff, stream)
+            m4ri_amd.mul_dev(P.data_ptr(), pw, a_ptr, wl, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, args.cutoff, stream)
 
     def send_recv(partner, send_rows, recv_rows):
         if args.backend == "gloo":  # host-staged (development only)
@@ -268,15 +273,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    ops = float(n) ** 3  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
+    ops = float(M) * L * N  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
     value = ops * args.steps / elapsed
 
     if args.check:
         # recompute the whole product on this rank's GPU and compare the region this rank owns
         region = sharding.run_sharded(plan, multiply, xor_rows, send_recv)
         torch.cuda.synchronize()
-        full = torch.empty((n, w), dtype=torch.int64, device="cuda")
-        m4ri_amd.mul_dev(full.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, False, 0, stream)
+        full = torch.empty((M, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.mul_dev(full.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, 0, stream)
         torch.cuda.synchronize()
         rr0, rr1, cc0, cc1 = region
         mine = P[rr0 - r0:rr1 - r0, :]
@@ -310,8 +315,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves"
-                             if args.workload == "mul" else f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])"),
-                "m": n, "l": n, "n": n,
+                             if args.workload == "mul" else
+                             f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4]), rows of A/C over the ranks" if args.workload == "rect131072"
+                             else f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])"),
+                "m": M, "l": L, "n": N,
                 "ops_counted": "m*l*n bit multiply-accumulates (one AND+XOR = 1 op), classical count credited to Strassen",
                 "input": "splitmix64 seeds 3 (A), 4 (B), uniform bits, resident in HBM",
                 "grid": list(plan.grid),
@@ -328,7 +335,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": leaf_traffic(n, world),
+                "traffic": leaf_traffic(n, world) if args.workload == "mul" else None,
                 "launch_ms": leaf_launch_ms,
                 "launches_per_step": int(stats.leaf_launches),
                 "algorithmic_bytes_per_launch": leaf_launch_bytes,
@@ -342,7 +349,7 @@ def main():
             },
         }
         out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
-        if args.workload == "mul":
+        if args.workload != "leaf16384":
             copy_gbs = measured_copy_gbs()
             # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
             # this rank's block product / step time); the compulsory bytes beside it
