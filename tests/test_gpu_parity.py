@@ -349,3 +349,41 @@ def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
             assert to_host(C, m, n).equal(want), f"max_fuse={fuse}"
     finally:
         m4ri_amd.set_max_fuse(old)
+
+
+def test_randomized_shapes_windows_cutoffs(oracle):
+    """Seeded fuzz through the C ABI: random shapes, cutoffs, mul/addmul, operands and results that are
+    windows of larger parents (column offsets on word boundaries, mzd.c:161), checked word for word
+    against the oracle INCLUDING the parents' bits outside the result window."""
+    rng = np.random.default_rng(20260928)
+    for case in range(80):
+        m, l, n = (int(x) for x in rng.integers(1, 1400, 3))
+        if case % 9 == 0:
+            m, l, n = (int(x) for x in rng.integers(1, 90, 3))          # tiny: the reference's naive fallbacks
+        if case % 13 == 0:
+            l = int(rng.integers(1, 5)) * 64 * 8                         # multiples of 64*2^L: no strips
+        cutoff = int(rng.choice([0, 64, 128, 256, 512, 1024]))
+        add = bool(rng.integers(0, 2))
+
+        def operand(rows, cols, seed):
+            if rng.integers(0, 2):
+                return Mzd.random(rows, cols, seed), None
+            pr, pc = rows + int(rng.integers(0, 70)), cols + int(rng.integers(0, 200))
+            parent = Mzd.random(pr, pc, seed)
+            lowr, lowc = int(rng.integers(0, pr - rows + 1)), int(rng.integers(0, (pc - cols) // 64 + 1)) * 64
+            return parent.window(lowr, lowc, lowr + rows, lowc + cols), parent
+
+        A, _ = operand(m, l, 1000 + case)
+        B, _ = operand(l, n, 2000 + case)
+        C, Cp = operand(m, n, 3000 + case)
+        Ch = (Cp.copy() if Cp is not None else C.copy())
+        Cw = Ch if Cp is None else Ch.window((C.offset - Cp.offset) // Cp.rowstride, ((C.offset - Cp.offset) % Cp.rowstride) * 64,
+                                             (C.offset - Cp.offset) // Cp.rowstride + m, ((C.offset - Cp.offset) % Cp.rowstride) * 64 + n)
+        if add:
+            m4ri_amd.mzd_addmul(C, A, B, cutoff)
+            oracle.addmul(Cw, A, B, cutoff)
+        else:
+            m4ri_amd.mzd_mul(C, A, B, cutoff)
+            oracle.mul(Cw, A, B, cutoff)
+        got, want = (Cp if Cp is not None else C), Ch
+        assert np.array_equal(got.buf, want.buf), (case, m, l, n, cutoff, add, Cp is not None)
