@@ -213,6 +213,21 @@ __global__ __launch_bounds__(AUX_THREADS) void copy_masked_kernel(word *__restri
   }
 }
 
+// zero the C tiles [tile_base, tile_base + ntiles) of a batched leaf launch (linear tile order:
+// tile_m fastest, then tile_n, then batch member): what an inner-dimension split of only SOME tiles
+// needs before its atomic XORs.  One workgroup per tile, rows x tw words each.
+__global__ __launch_bounds__(AUX_THREADS) void zero_tiles_kernel(word *__restrict__ C, int64_t cs, int64_t cbs, int64_t m,
+                                                                 int64_t wn, int64_t tile_rows, int64_t tw, int64_t tiles_m,
+                                                                 int64_t tiles_n, int64_t tile_base) {
+  int64_t t = tile_base + blockIdx.x;
+  const int64_t tm = t % tiles_m; t /= tiles_m;
+  const int64_t tn = t % tiles_n; t /= tiles_n;
+  word *base        = C + t * cbs + tm * tile_rows * cs + tn * tw;
+  const int64_t rows = (m - tm * tile_rows) < tile_rows ? (m - tm * tile_rows) : tile_rows;
+  const int64_t w    = (wn - tn * tw) < tw ? (wn - tn * tw) : tw;
+  for (int64_t i = threadIdx.x; i < rows * w; i += AUX_THREADS) base[(i / w) * cs + (i % w)] = 0;
+}
+
 // zero the bits at column >= ncols of the last valid word of every row (establishes the engine's
 // "zero excess" invariant for operands uploaded from windows, mzd.h:117-123)
 __global__ __launch_bounds__(AUX_THREADS) void mask_tail_kernel(word *__restrict__ M, int64_t stride,
@@ -325,6 +340,15 @@ extern "C" hipError_t gf2_launch_copy_masked(hipStream_t s, word *C, int64_t cs,
   const int64_t w = words_of(ncols);
   const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
   hipLaunchKernelGGL(copy_masked_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, rows, w, mask);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_zero_tiles(hipStream_t s, word *C, int64_t cs, int64_t cbs, int64_t m, int64_t wn,
+                                            int64_t tile_rows, int64_t tw, int64_t tiles_m, int64_t tiles_n,
+                                            int64_t tile_base, int64_t ntiles) {
+  if (ntiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_tiles_kernel, dim3((unsigned)ntiles), dim3(AUX_THREADS), 0, s, C, cs, cbs, m, wn, tile_rows, tw,
+                     tiles_m, tiles_n, tile_base);
   return hipGetLastError();
 }
 

@@ -50,6 +50,8 @@ hipError_t gf2_launch_winograd_down2(hipStream_t s, int bside, const word *gpare
                                      word *gchild, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_up2(hipStream_t s, int acc, const word *prod, word *gparent, int64_t o_stride,
                                    int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_zero_tiles(hipStream_t s, word *C, int64_t cs, int64_t cbs, int64_t m, int64_t wn, int64_t tile_rows, int64_t tw,
+                                 int64_t tiles_m, int64_t tiles_n, int64_t tile_base, int64_t ntiles);
 hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A, int64_t as,
                               const word *B, int64_t bs, int64_t rows, int64_t w);
 hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols);
@@ -177,6 +179,8 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   const int64_t sbits  = kind.gen == 4 ? 32 : kind.gen == 2 ? 14 : 16;  // inner bits per stage (barrier to barrier)
   const int64_t stages = (l + sbits - 1) / sbits;
   int ksplit = ksplit_req;
+  int64_t tail_tiles = 0;  // generation 4, hybrid plan: the last tail_tiles tiles go in a second launch ...
+  int tail_ksplit    = 1;  // ... with this inner-dimension split
   if (ksplit <= 0) {
     // One workgroup per CU is resident at a time (LDS), so a launch runs in ceil(workgroups / CUs)
     // rounds and a short last round idles most of the chip: 784 tiles on 256 CUs take 4 rounds for
@@ -196,6 +200,17 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     double best_cost = cost(1) * 0.97;
     for (int64_t ks = 2; ks <= cap; ++ks)
       if (cost(ks) < best_cost) { best_cost = cost(ks); ksplit = (int)ks; }
+    // Generation 4 can also run the FULL rounds unsplit and only the tiles of the short last round
+    // split (two launches over disjoint tile ranges): the remainder pays for atomics, nobody else
+    if (kind.gen == 4 && tiles > e->cus && tiles % e->cus != 0) {
+      const int64_t rem = tiles % e->cus, full_rounds = tiles / e->cus;
+      for (int64_t ks = 2; ks <= cap; ++ks) {
+        const int64_t rounds = (rem * ks + e->cus - 1) / e->cus;
+        const double c = (double)full_rounds * ((double)stages + fixed) + (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + atomic);
+        if (c < best_cost * 0.99) { best_cost = c; tail_tiles = rem; tail_ksplit = (int)ks; }
+      }
+      if (tail_tiles) ksplit = 1;
+    }
   }
   if (l == 0 || (ksplit > 1 && !add)) {  // empty inner dimension, or atomics need a zeroed C
     if (!add) {
@@ -232,7 +247,17 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk));
+  if (kind.gen == 4 && tail_tiles > 0) {
+    LeafArgs head = a, tail = a;
+    head.tile_base = 0; head.tile_count = tiles - tail_tiles;
+    tail.tile_base = tiles - tail_tiles; tail.tile_count = tail_tiles;
+    tail.ksplit = tail_ksplit; tail.mode = 1;
+    if (!add)  // the split tiles are combined by atomic XOR: they start from zero
+      HIPTRY(gf2_launch_zero_tiles(st, C, cs, cbs, m, wn, kind.rows, tw, (m + kind.rows - 1) / kind.rows, (wn + tw - 1) / tw,
+                                   tail.tile_base, tail_tiles));
+    HIPTRY(gf2_launch_m4rm8q(st, head, e->apk));
+    HIPTRY(gf2_launch_m4rm8q(st, tail, e->apk));
+  } else if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk));
   else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
   else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));

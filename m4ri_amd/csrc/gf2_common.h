@@ -54,4 +54,8 @@ struct LeafArgs {
   int32_t chunks_per_split;               // double-buffered kernel: 32-bit A chunks per split
   int32_t batch;
   int32_t mode;                           // 0: C = A*B (plain store), 1: C ^= A*B (no-return atomic xor)
+  // generation 4 only: the launch covers the tiles [tile_base, tile_base + tile_count) of the
+  // batch's linear tile order (tile_m fastest, then tile_n, then batch member); tile_count == 0
+  // means all of them.  Lets the engine run the full rounds and a finer-split tail as two launches.
+  int64_t tile_base, tile_count;
 };

@@ -100,17 +100,19 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const int bz   = (tid >> 2) & 3;   // table 0..3 of the stage
   const int bhi  = (tid >> 4) & 15;  // bits 4..7 of the 16 entries this thread writes
 
-  // block -> (batch, tile_n, ksplit, tile_m); consecutive logical ids share a B panel, and the XCD
-  // remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8 XCDs)
+  // block -> (tile, inner split); tile -> (batch, tile_n, tile_m).  Consecutive tiles share a B
+  // panel, and the XCD remap keeps them on one XCD's L2 (blocks are dispatched round-robin over 8
+  // XCDs)
   uint32_t lid = blockIdx.x;
   {
     const uint32_t nwg = gridDim.x;
     if ((nwg & 7u) == 0u) lid = (lid & 7u) * (nwg >> 3) + (lid >> 3);
   }
-  const int tile_m = lid % p.tiles_m; lid /= p.tiles_m;
-  const int ks     = lid % p.ksplit;  lid /= p.ksplit;
-  const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
-  const int64_t bat = lid;
+  const int ks = lid % p.ksplit;
+  int64_t t    = p.tile_base + lid / p.ksplit;
+  const int tile_m = (int)(t % p.tiles_m); t /= p.tiles_m;
+  const int tile_n = (int)(t % p.tiles_n); t /= p.tiles_n;
+  const int64_t bat = t;
 
   const uint32_t *Apkb = p.Apk + bat * p.apk_bs;
   const word *Bb      = p.B + bat * p.b_bs;
@@ -355,7 +357,10 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   a.chunks_per_split = cps;
   a.ksplit           = (int)((nq + cps - 1) / cps);
   if (a.ksplit > 1 && a.mode == 0) return hipErrorInvalidValue;  // caller must pre-zero C and pass mode 1
-  const long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit * a.batch;
+  const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.batch;
+  if (a.tile_count == 0) { a.tile_base = 0; a.tile_count = ntiles; }
+  if (a.tile_base < 0 || a.tile_base + a.tile_count > ntiles) return hipErrorInvalidValue;
+  const long long nwg = (long long)a.tile_count * a.ksplit;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
   if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<false>), grid, block, 0, stream, a);

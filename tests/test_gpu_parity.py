@@ -387,3 +387,22 @@ def test_randomized_shapes_windows_cutoffs(oracle):
             oracle.mul(Cw, A, B, cutoff)
         got, want = (Cp if Cp is not None else C), Ch
         assert np.array_equal(got.buf, want.buf), (case, m, l, n, cutoff, add, Cp is not None)
+
+
+@pytest.mark.parametrize("add", [False, True])
+def test_leaf_full_rounds_plus_split_tail_matches_plain_launch(add):
+    """300 tiles on 256 CUs: the automatic plan runs one full round unsplit and the 44 remaining tiles
+    with their inner dimension split (two launches, atomics only in the tail; engine.hip launch_leaf).
+    Same bits as the plain single launch (ksplit = 1)."""
+    m, l, n = 3 * 4096, 4096, 100 * 512
+    A, B = dev_random(m, l, 81), dev_random(l, n, 82)
+    C0 = dev_random(m, n, 83)
+    w, wl = n // 64, l // 64
+    out = []
+    for ksplit in (0, 1):
+        C = C0.clone()
+        m4ri_amd.m4rm_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, ksplit=ksplit)
+        torch.cuda.synchronize()
+        out.append(C)
+    assert torch.equal(out[0], out[1])
+    assert not torch.equal(out[0], C0)

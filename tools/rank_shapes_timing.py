@@ -31,9 +31,14 @@ for name, (m, l, k) in SHAPES.items():
         m4ri_amd.mul_dev(C.data_ptr(), wk, A.data_ptr(), wl, B.data_ptr(), wk, m, l, k)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
+    m4ri_amd.set_profiling(True)
+    m4ri_amd.mul_dev(C.data_ptr(), wk, A.data_ptr(), wl, B.data_ptr(), wk, m, l, k)
+    torch.cuda.synchronize()
     st = m4ri_amd.get_stats()
+    m4ri_amd.set_profiling(False)
     out[name] = {"shape": [m, l, k], "ms": ms, "levels": st.levels, "leaf": [st.leaf_m, st.leaf_l, st.leaf_n],
-                 "leaf_products": st.leaf_products, "leaf_gen": st.leaf_gen}
+                 "leaf_products": st.leaf_products, "leaf_gen": st.leaf_gen, "leaf_ms": st.leaf_ms,
+                 "pass_GB": st.aux_bytes / 1e9}
     print(name, out[name], flush=True)
     del A, B, C
     m4ri_amd.lib().m4ri_amd_release_workspace()
