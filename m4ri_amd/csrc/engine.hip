@@ -61,6 +61,9 @@ hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int6
 namespace {
 
 constexpr int MAX_LEVELS      = 6;
+#ifndef LEAF_MIN_SPLIT_BITS
+#define LEAF_MIN_SPLIT_BITS 512  // fewest inner bits one split of a leaf launch may get
+#endif
 int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
 constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
 constexpr int DEFAULT_CUTOFF_M = 4096; // ... and m/2 >= this (one generation-4 tile row)
@@ -186,14 +189,16 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     // rounds and a short last round idles most of the chip: 784 tiles on 256 CUs take 4 rounds for
     // 3.06 rounds of work.  Splitting the inner dimension trades that for more, shorter workgroups
     // (combined by atomic XOR into a zeroed C).  Cost in stages: rounds x (stages per split +
-    // prologue/epilogue, + the atomic epilogue when split); keep >= 64 stages per split so the C
-    // tile traffic stays amortised, and take a split only when it pays >= 3 %.
-    const double fixed = 128.0 / (double)sbits, atomic = 192.0 / (double)sbits;  // measured on generation 4, in inner bits
+    // prologue/epilogue, + the atomic epilogue when split); at least LEAF_MIN_SPLIT_BITS inner bits
+    // per split, and a split only when it pays >= 3 %.
+    // per-workgroup overheads in inner bits, calibrated on generation 4 (tools/small_sizes_timing.py):
+    // prologue + epilogue ~ 192 bits of stage time, the atomic epilogue of a split ~ 512 more
+    const double fixed = 192.0 / (double)sbits, atomic = 512.0 / (double)sbits;
     auto cost = [&](int64_t ks) {
       const int64_t rounds = (tiles * ks + e->cus - 1) / e->cus;
       return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? atomic : 0.0));
     };
-    int64_t cap = stages * sbits / 2048;  // >= 2048 inner bits per split
+    int64_t cap = stages * sbits / LEAF_MIN_SPLIT_BITS;  // inner bits per split: see the constant
     if (cap < 1) cap = 1;
     if (cap > 32) cap = 32;
     ksplit           = 1;
