@@ -133,7 +133,8 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out);
    out-of-range arguments only query. */
 int m4ri_amd_set_max_fuse(int levels);
 
-/* Release the engine's workspace (device memory pool). */
+/* Release the engine's workspace (device memory pool) and the host entry points' staging arena;
+   pinned matrices keep their device copies. */
 void m4ri_amd_release_workspace(void);
 
 /* ---- part 3: residency (device-resident matrix handles) -----------------------------

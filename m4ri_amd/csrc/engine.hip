@@ -542,13 +542,17 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out) {
   return 0;
 }
 
+void gf2_release_staging(void);  // mzd_api.hip: the host entry points' staging arena
+
 void m4ri_amd_release_workspace(void) {
+  gf2_release_staging();
   std::lock_guard<std::mutex> lk(g_mu);
   Engine *e = engine_for_current_device();
   if (!e || !e->ws) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(e->ws);
   e->ws = nullptr; e->ws_cap = 0; e->ws_used = 0;
+  e->apk = nullptr; e->apk_words = 0;
 }
 
 }  // extern "C"

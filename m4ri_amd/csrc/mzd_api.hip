@@ -311,6 +311,14 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
   return run(C, A, B, clear == 0, false, 0);
 }
 
+void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  if (!g_arena.base) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(g_arena.base);
+  g_arena = Arena{};
+}
+
 // ---- part 3: residency ----------------------------------------------------------------------------
 int m4ri_amd_pin(mzd_t *M) {
   std::lock_guard<std::mutex> lk(g_api_mu);
