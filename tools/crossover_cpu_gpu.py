@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Where does the drop-in pay off?  mzd_mul on host matrices: the reference on the host cores
+(sequential SSE2 build, and mzd_mul_mp of the OpenMP build on all hardware threads) next to
+libm4ri_amd.so through the same entry point (PCIe inclusive) and with the operands pinned.
+Run on the GPU box (needs oracle/_ref/*.so, built by oracle/Makefile in the build container)."""
+import os
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
+import cpu_libs
+
+import m4ri_amd
+from m4ri_amd.mzd import Mzd
+
+
+def best(fn, reps):
+    fn()
+    b = 1e30
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        b = min(b, time.perf_counter() - t)
+    return b
+
+
+m4ri_amd.init(0)
+ref, omp = cpu_libs.reference(), cpu_libs.reference(openmp=True)
+print(f"{'n':>6} | {'ref seq ms':>10} {'ref omp ms':>10} | {'gpu host ms':>11} {'gpu pinned ms':>13} | speedup vs best cpu (host / pinned)")
+for n in (512, 1024, 2048, 4096, 8192, 16384, 32768):
+    A, B, C = Mzd.random(n, n, 3), Mzd.random(n, n, 4), Mzd.init(n, n)
+    reps = 3 if n <= 8192 else 1
+    t_seq = best(lambda: ref.mul(C, A, B, 0), reps) if ref else float("nan")
+    t_omp = best(lambda: omp.mul_mp(C, A, B, 0), reps) if (omp and omp.has_mp) else float("nan")
+    want = C.copy()
+    t_gpu = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 5)
+    assert C.equal(want)
+    for M in (A, B, C):
+        m4ri_amd.pin(M)
+    t_pin = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 5)
+    for M in (A, B, C):
+        m4ri_amd.unpin(M)
+    assert C.equal(want)
+    cpu = min(t_seq, t_omp)
+    print(f"{n:6d} | {t_seq * 1e3:10.3f} {t_omp * 1e3:10.3f} | {t_gpu * 1e3:11.3f} {t_pin * 1e3:13.3f} | {cpu / t_gpu:8.1f}x / {cpu / t_pin:8.1f}x", flush=True)
