@@ -2,14 +2,16 @@
 """Where does the drop-in pay off?  mzd_mul on host matrices: the reference on the host cores
 (sequential SSE2 build, and mzd_mul_mp of the OpenMP build on all hardware threads) next to
 libm4ri_amd.so through the same entry point (PCIe inclusive) and with the operands pinned.
-Run on the GPU box (needs oracle/_ref/*.so, built by oracle/Makefile in the build container)."""
+Run on the GPU box (needs oracle/_ref/*.so, built by oracle/Makefile in the build container).
+Lives under tests/ because it executes the reference checker (nothing outside tests/, smoke() and
+bench.py's cpu_baseline leg may); it is a measurement script, not a pytest module."""
 import os
 import sys
 import time
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
 import cpu_libs
 
