@@ -389,15 +389,18 @@ def test_randomized_shapes_windows_cutoffs(oracle):
         assert np.array_equal(got.buf, want.buf), (case, m, l, n, cutoff, add, Cp is not None)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("add", [False, True])
-def test_leaf_full_rounds_plus_split_tail_matches_plain_launch(add):
+def test_leaf_full_rounds_plus_split_tail_matches_plain_launch(add, ragged):
     """300 tiles on 256 CUs: the automatic plan runs one full round unsplit and the 44 remaining tiles
     with their inner dimension split (two launches, atomics only in the tail; engine.hip launch_leaf).
     Same bits as the plain single launch (ksplit = 1)."""
     m, l, n = 3 * 4096, 4096, 100 * 512
+    if ragged:  # partial last row tile and last column tile, inner dimension off the word grid
+        m, l, n = m - 100, l - 37, n - 77
     A, B = dev_random(m, l, 81), dev_random(l, n, 82)
     C0 = dev_random(m, n, 83)
-    w, wl = n // 64, l // 64
+    w, wl = (n + 63) // 64, (l + 63) // 64
     out = []
     for ksplit in (0, 1):
         C = C0.clone()
