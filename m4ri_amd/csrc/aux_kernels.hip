@@ -213,6 +213,37 @@ __global__ __launch_bounds__(AUX_THREADS) void copy_masked_kernel(word *__restri
   }
 }
 
+// fold the slabs of an inner-dimension split (leaf mode 2) into C: tile t of the launch has ks dense
+// slabs of tile_rows x tw words at Cpart + ((t - tile_base) * ks + k) * tile_rows * tw; C (^)= their
+// XOR, clipped to the matrix.  RP_CHUNKS workgroups per tile (a tile alone is too few workgroups to
+// pull bandwidth: a split launch has at most a few hundred tiles).
+constexpr int RP_CHUNKS = 32;
+template <bool ACC>
+__global__ __launch_bounds__(AUX_THREADS) void reduce_partials_kernel(word *__restrict__ C, int64_t cs, int64_t cbs, int64_t m,
+                                                                      int64_t wn, int64_t tile_rows, int64_t tw, int64_t tiles_m,
+                                                                      int64_t tiles_n, int64_t tile_base, int ks,
+                                                                      const word *__restrict__ Cpart) {
+  const int64_t lt = blockIdx.x / RP_CHUNKS, chunk = blockIdx.x % RP_CHUNKS;
+  int64_t t = tile_base + lt;
+  const int64_t tm = t % tiles_m; t /= tiles_m;
+  const int64_t tn = t % tiles_n; t /= tiles_n;
+  word *base        = C + t * cbs + tm * tile_rows * cs + tn * tw;
+  const int64_t rows = (m - tm * tile_rows) < tile_rows ? (m - tm * tile_rows) : tile_rows;
+  const int64_t w    = (wn - tn * tw) < tw ? (wn - tn * tw) : tw;
+  const int64_t slab = tile_rows * tw;
+  const word *src    = Cpart + lt * ks * slab;
+  const int64_t per  = (tile_rows / RP_CHUNKS) * tw;  // words of the tile this workgroup folds
+  const int64_t end  = (chunk + 1) * per < rows * tw ? (chunk + 1) * per : rows * tw;
+  for (int64_t i = chunk * per + threadIdx.x; i < end; i += AUX_THREADS) {
+    const int64_t r = i / tw, k = i - r * tw;
+    if (k >= w) continue;
+    word x = 0;
+    for (int j = 0; j < ks; ++j) x ^= src[(int64_t)j * slab + i];
+    word *c = base + r * cs + k;
+    *c      = ACC ? (*c ^ x) : x;
+  }
+}
+
 // zero the C tiles [tile_base, tile_base + ntiles) of a batched leaf launch (linear tile order:
 // tile_m fastest, then tile_n, then batch member): what an inner-dimension split of only SOME tiles
 // needs before its atomic XORs.  One workgroup per tile, rows x tw words each.
@@ -340,6 +371,19 @@ extern "C" hipError_t gf2_launch_copy_masked(hipStream_t s, word *C, int64_t cs,
   const int64_t w = words_of(ncols);
   const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
   hipLaunchKernelGGL(copy_masked_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, rows, w, mask);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_reduce_partials(hipStream_t s, int acc, word *C, int64_t cs, int64_t cbs, int64_t m, int64_t wn,
+                                                 int64_t tile_rows, int64_t tw, int64_t tiles_m, int64_t tiles_n,
+                                                 int64_t tile_base, int64_t ntiles, int ks, const word *Cpart) {
+  if (ntiles <= 0) return hipSuccess;
+  if (acc)
+    hipLaunchKernelGGL((reduce_partials_kernel<true>), dim3((unsigned)(ntiles * RP_CHUNKS)), dim3(AUX_THREADS), 0, s, C, cs, cbs, m, wn, tile_rows,
+                       tw, tiles_m, tiles_n, tile_base, ks, Cpart);
+  else
+    hipLaunchKernelGGL((reduce_partials_kernel<false>), dim3((unsigned)(ntiles * RP_CHUNKS)), dim3(AUX_THREADS), 0, s, C, cs, cbs, m, wn, tile_rows,
+                       tw, tiles_m, tiles_n, tile_base, ks, Cpart);
   return hipGetLastError();
 }
 

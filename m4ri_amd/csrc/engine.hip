@@ -40,6 +40,7 @@ hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *anc, int64_
 hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
+int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
@@ -50,6 +51,9 @@ hipError_t gf2_launch_winograd_down2(hipStream_t s, int bside, const word *gpare
                                      word *gchild, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_up2(hipStream_t s, int acc, const word *prod, word *gparent, int64_t o_stride,
                                    int64_t o_bs, int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_reduce_partials(hipStream_t s, int acc, word *C, int64_t cs, int64_t cbs, int64_t m, int64_t wn, int64_t tile_rows,
+                                      int64_t tw, int64_t tiles_m, int64_t tiles_n, int64_t tile_base, int64_t ntiles, int ks,
+                                      const word *Cpart);
 hipError_t gf2_launch_zero_tiles(hipStream_t s, word *C, int64_t cs, int64_t cbs, int64_t m, int64_t wn, int64_t tile_rows, int64_t tw,
                                  int64_t tiles_m, int64_t tiles_n, int64_t tile_base, int64_t ntiles);
 hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A, int64_t as,
@@ -61,6 +65,10 @@ hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int6
 namespace {
 
 constexpr int MAX_LEVELS      = 6;
+constexpr int64_t PART_SLABS  = 768;  // slabs (256 KiB each) a split generation-4 launch may use: 192 MiB of the workspace
+#ifndef LEAF_SPLIT_COST_BITS
+#define LEAF_SPLIT_COST_BITS 128
+#endif
 #ifndef LEAF_MIN_SPLIT_BITS
 #define LEAF_MIN_SPLIT_BITS 512  // fewest inner bits one split of a leaf launch may get
 #endif
@@ -83,6 +91,7 @@ struct Engine {
   size_t ws_used        = 0;
   word *apk             = nullptr;  // packed-A scratch of the current call (inside ws)
   size_t apk_words      = 0;
+  word *part            = nullptr;  // slabs of split leaf launches (inside ws, PART_SLABS tiles)
   bool profiling        = false;
   m4ri_amd_stats stats  = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
@@ -193,7 +202,8 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     // per split, and a split only when it pays >= 3 %.
     // per-workgroup overheads in inner bits, calibrated on generation 4 (tools/small_sizes_timing.py):
     // prologue + epilogue ~ 192 bits of stage time, the atomic epilogue of a split ~ 512 more
-    const double fixed = 192.0 / (double)sbits, atomic = 512.0 / (double)sbits;
+    // (generation 4 writes slabs instead and pays one reduce pass: LEAF_SPLIT_COST_BITS)
+    const double fixed = 192.0 / (double)sbits, atomic = (kind.gen == 4 ? (double)LEAF_SPLIT_COST_BITS : 512.0) / (double)sbits;
     auto cost = [&](int64_t ks) {
       const int64_t rounds = (tiles * ks + e->cus - 1) / e->cus;
       return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? atomic : 0.0));
@@ -217,7 +227,16 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
       if (tail_tiles) ksplit = 1;
     }
   }
-  if (l == 0 || (ksplit > 1 && !add)) {  // empty inner dimension, or atomics need a zeroed C
+  if (kind.gen == 4) {  // the kernel rounds splits to whole stage pairs: work with the counts it will use
+    ksplit      = gf2_m4rm8q_effective_ksplit(l, ksplit);
+    tail_ksplit = gf2_m4rm8q_effective_ksplit(l, tail_ksplit);
+  }
+  // generation 4 combines the splits through per-split slabs + one reduce pass when they fit the
+  // workspace's slab region (no atomics, no zeroing); otherwise, and in the older kernels, by atomic
+  // XOR into a zeroed C
+  const bool slabs = kind.gen == 4 && e->part != nullptr && packed_a_fits(e, kind, m, l, batch) &&
+                     (tail_tiles > 0 ? tail_tiles * tail_ksplit : (ksplit > 1 ? tiles * ksplit : PART_SLABS + 1)) <= PART_SLABS;
+  if (l == 0 || (ksplit > 1 && !add && !slabs)) {  // empty inner dimension, or atomics need a zeroed C
     if (!add) {
       if (cs == wn && (batch == 1 || cbs == m * wn))  // one contiguous block
         HIPTRY(hipMemsetAsync(C, 0, (size_t)batch * m * wn * 8, st));
@@ -233,7 +252,8 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   a.a_bs = abs_; a.b_bs = bbs; a.c_bs = cbs;
   a.m = (int32_t)m; a.l = (int32_t)l; a.n = (int32_t)n;
   a.batch = (int32_t)batch; a.ksplit = ksplit;
-  a.mode  = (add || ksplit > 1) ? 1 : 0;
+  a.mode  = (ksplit > 1 && slabs) ? 2 : (add || ksplit > 1) ? 1 : 0;
+  a.Cpart = e->part;
   // generations 2 and 3 consume A in a packed, chunk-major form (one streaming pass into the call's
   // scratch first); they need that scratch and 32-bit offsets inside one packed operand
   if (a_prepacked) {
@@ -256,13 +276,19 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
     LeafArgs head = a, tail = a;
     head.tile_base = 0; head.tile_count = tiles - tail_tiles;
     tail.tile_base = tiles - tail_tiles; tail.tile_count = tail_tiles;
-    tail.ksplit = tail_ksplit; tail.mode = 1;
-    if (!add)  // the split tiles are combined by atomic XOR: they start from zero
-      HIPTRY(gf2_launch_zero_tiles(st, C, cs, cbs, m, wn, kind.rows, tw, (m + kind.rows - 1) / kind.rows, (wn + tw - 1) / tw,
-                                   tail.tile_base, tail_tiles));
+    tail.ksplit = tail_ksplit; tail.mode = slabs ? 2 : 1;
+    const int64_t tm = (m + kind.rows - 1) / kind.rows, tn = (wn + tw - 1) / tw;
+    if (!add && !slabs)  // the split tiles are combined by atomic XOR: they start from zero
+      HIPTRY(gf2_launch_zero_tiles(st, C, cs, cbs, m, wn, kind.rows, tw, tm, tn, tail.tile_base, tail_tiles));
     HIPTRY(gf2_launch_m4rm8q(st, head, e->apk));
     HIPTRY(gf2_launch_m4rm8q(st, tail, e->apk));
-  } else if (kind.gen == 4) HIPTRY(gf2_launch_m4rm8q(st, a, e->apk));
+    if (slabs) HIPTRY(gf2_launch_reduce_partials(st, add ? 1 : 0, C, cs, cbs, m, wn, kind.rows, tw, tm, tn, tail.tile_base, tail_tiles, tail_ksplit, e->part));
+  } else if (kind.gen == 4) {
+    HIPTRY(gf2_launch_m4rm8q(st, a, e->apk));
+    if (a.mode == 2)
+      HIPTRY(gf2_launch_reduce_partials(st, add ? 1 : 0, C, cs, cbs, m, wn, kind.rows, tw, (m + kind.rows - 1) / kind.rows, (wn + tw - 1) / tw,
+                                        0, tiles, ksplit, e->part));
+  }
   else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
   else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
@@ -281,9 +307,10 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
 
 int reserve_apk(Engine *e, size_t words) {
   words = (words + 31) & ~(size_t)31;
-  if (int rc = ws_reserve(e, words)) return rc;
+  if (int rc = ws_reserve(e, words + (size_t)PART_SLABS * LEAF_PART_WORDS)) return rc;
   e->apk = ws_take(e, words);
   e->apk_words = words;
+  e->part = ws_take(e, (size_t)PART_SLABS * LEAF_PART_WORDS);
   return 0;
 }
 
@@ -346,9 +373,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     if (a7_bfs > a7_extra) a7_extra = a7_bfs;
   }
   a7_extra = pad(a7_extra);
-  if (int rc = ws_reserve(e, need + a7_extra)) return rc;
+  if (int rc = ws_reserve(e, need + a7_extra + (size_t)PART_SLABS * LEAF_PART_WORDS)) return rc;
   e->apk = ws_take(e, a7_extra);
   e->apk_words = a7_extra;
+  e->part = ws_take(e, (size_t)PART_SLABS * LEAF_PART_WORDS);
   std::vector<word *> Al(L + 1, nullptr), Bl(L + 1, nullptr), Pl(L + 1, nullptr);
   if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, ipow7(L))) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
   for (int d = 1; d <= L; ++d) {
@@ -552,7 +580,7 @@ void m4ri_amd_release_workspace(void) {
   (void)hipDeviceSynchronize();
   (void)hipFree(e->ws);
   e->ws = nullptr; e->ws_cap = 0; e->ws_used = 0;
-  e->apk = nullptr; e->apk_words = 0;
+  e->apk = nullptr; e->apk_words = 0; e->part = nullptr;
 }
 
 }  // extern "C"

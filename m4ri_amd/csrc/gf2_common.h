@@ -53,9 +53,13 @@ struct LeafArgs {
   int32_t stages_per_split;               // two-phase kernel: LEAF_STAGE-bit stages per split
   int32_t chunks_per_split;               // double-buffered kernel: 32-bit A chunks per split
   int32_t batch;
-  int32_t mode;                           // 0: C = A*B (plain store), 1: C ^= A*B (no-return atomic xor)
+  int32_t mode;                           // 0: C = A*B (plain store), 1: C ^= A*B (no-return atomic xor),
+                                          // 2 (generation 4): every (tile, split) stores its whole tile into its
+                                          //    own slab of Cpart; gf2_launch_reduce_partials folds them into C
   // generation 4 only: the launch covers the tiles [tile_base, tile_base + tile_count) of the
   // batch's linear tile order (tile_m fastest, then tile_n, then batch member); tile_count == 0
   // means all of them.  Lets the engine run the full rounds and a finer-split tail as two launches.
   int64_t tile_base, tile_count;
+  word *Cpart;                            // mode 2: slab (tile - tile_base) * ksplit + split, LEAF_PART_WORDS words each
 };
+#define LEAF_PART_WORDS 32768             // one generation-4 tile: 4096 rows x 8 words, dense

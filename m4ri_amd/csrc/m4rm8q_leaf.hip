@@ -109,6 +109,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     if ((nwg & 7u) == 0u) lid = (lid & 7u) * (nwg >> 3) + (lid >> 3);
   }
   const int ks = lid % p.ksplit;
+  const uint32_t slab = lid;  // (tile - tile_base) * ksplit + split: this workgroup's slab in mode 2
   int64_t t    = p.tile_base + lid / p.ksplit;
   const int tile_m = (int)(t % p.tiles_m); t /= p.tiles_m;
   const int tile_n = (int)(t % p.tiles_n); t /= p.tiles_n;
@@ -310,9 +311,15 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
   // epilogue: C tile out.  One running row pointer (pinned, so hipcc cannot hoist RG 64-bit row
   // addresses above the main loop); the column guards are loop-invariant per lane.
-  if (v0) {
-    word *cp       = Cb + (int64_t)row0 * p.c_stride + w0;
-    const int rows = (p.m - row0) < RG ? (p.m - row0) : RG;  // may be <= 0
+  // Mode 2 (an inner-dimension split without atomics): the whole tile, padding included, goes
+  // into this workgroup's own dense slab; gf2_launch_reduce_partials folds the slabs into C.
+  const bool to_slab = !XOR_OUT && p.mode == 2;
+  if (v0 || to_slab) {
+    word *cp         = to_slab ? p.Cpart + (int64_t)slab * LEAF_PART_WORDS + (int64_t)rgrp * RG * K8_TW + c * 2
+                               : Cb + (int64_t)row0 * p.c_stride + w0;
+    const int64_t cst = to_slab ? (int64_t)K8_TW : p.c_stride;
+    const int rows    = to_slab ? RG : ((p.m - row0) < RG ? (p.m - row0) : RG);  // may be <= 0
+    const bool s1     = to_slab || v1;
 #pragma unroll
     for (int t = 0; t < RG; ++t) {
       if (t < rows) {
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
         const word x1 = (word)acc[t][2] | ((word)acc[t][3] << 32);
         if constexpr (!XOR_OUT) {
           cp[0] = x0;
-          if (v1) cp[1] = x1;
+          if (s1) cp[1] = x1;
         } else {
           // C ^= tile: a no-return L2 atomic needs no destination registers and is what makes
           // inner-dimension splits (ksplit > 1) race-free; XOR is exact, so order is moot
@@ -328,13 +335,25 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
           if (v1) atomicXor(reinterpret_cast<unsigned long long *>(cp + 1), (unsigned long long)x1);
         }
       }
-      cp += p.c_stride;
+      cp += cst;
       asm volatile("" : "+v"(cp));
     }
   }
 }
 
 }  // namespace
+
+// The split count a launch with inner dimension l really uses when asked for `ksplit`: every split
+// takes an even number of stages (it starts in table buffer 0), so the count can come out smaller.
+// The engine sizes and folds the mode-2 slabs with this number.
+extern "C" int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit) {
+  const int64_t nq = 2 * ((l + 63) / 64);
+  if (ksplit < 1) ksplit = 1;
+  int64_t cps = (nq + ksplit - 1) / ksplit;
+  cps         = (cps + 1) & ~(int64_t)1;
+  if (cps < 2) cps = 2;
+  return (int)((nq + cps - 1) / cps);
+}
 
 // Host launcher.  A must already be packed chunk-major WITH the byte rotation (gf2_launch_a4_pack_rot
 // of m4rm8_leaf.hip, rot = 1, or gf2_launch_winograd_down2_pack) into `a4_ws`.  Tiles are 4096 rows
@@ -356,14 +375,15 @@ extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4
   if (cps < 2) cps = 2;
   a.chunks_per_split = cps;
   a.ksplit           = (int)((nq + cps - 1) / cps);
-  if (a.ksplit > 1 && a.mode == 0) return hipErrorInvalidValue;  // caller must pre-zero C and pass mode 1
+  if (a.ksplit > 1 && a.mode == 0) return hipErrorInvalidValue;  // splits combine by atomics (1) or slabs (2)
+  if (a.mode == 2 && a.Cpart == nullptr) return hipErrorInvalidValue;
   const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.batch;
   if (a.tile_count == 0) { a.tile_base = 0; a.tile_count = ntiles; }
   if (a.tile_base < 0 || a.tile_base + a.tile_count > ntiles) return hipErrorInvalidValue;
   const long long nwg = (long long)a.tile_count * a.ksplit;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(LEAF_THREADS);
-  if (a.mode == 0) hipLaunchKernelGGL((m4rm8q_kernel<false>), grid, block, 0, stream, a);
+  if (a.mode != 1) hipLaunchKernelGGL((m4rm8q_kernel<false>), grid, block, 0, stream, a);
   else             hipLaunchKernelGGL((m4rm8q_kernel<true>), grid, block, 0, stream, a);
   return hipGetLastError();
 }

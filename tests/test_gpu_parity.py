@@ -409,3 +409,23 @@ def test_leaf_full_rounds_plus_split_tail_matches_plain_launch(add, ragged):
         out.append(C)
     assert torch.equal(out[0], out[1])
     assert not torch.equal(out[0], C0)
+
+
+@pytest.mark.parametrize("add", [False, True])
+def test_inner_dimension_splits_fold_to_the_same_bits(add):
+    """Explicit inner-dimension splits of a generation-4 launch (slabs + reduce pass; the kernel rounds
+    the split count to whole stage pairs, e.g. 32 requested -> 29 used at l = 16453) against ksplit = 1."""
+    m, l, n = 2 * 4096 - 11, 16453, 139
+    A, B = dev_random(m, l, 91), dev_random(l, n, 92)
+    C0 = dev_random(m, n, 93)
+    w, wl = (n + 63) // 64, (l + 63) // 64
+    ref = None
+    for ksplit in (1, 2, 3, 5, 7, 16, 32, 64):
+        C = C0.clone()
+        m4ri_amd.m4rm_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, ksplit=ksplit)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = C
+            assert m4ri_amd.get_stats().leaf_gen == 4
+        else:
+            assert torch.equal(ref, C), f"ksplit={ksplit}"
