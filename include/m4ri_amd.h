@@ -128,6 +128,13 @@ typedef struct m4ri_amd_stats {
 void m4ri_amd_set_profiling(int on);
 int m4ri_amd_get_stats(m4ri_amd_stats *out);
 
+/* Strassen-Winograd levels the engine uses for an m x l x n product and this cutoff (pure host
+   logic, callable without a GPU): cutoff > 0 follows the reference's rule (strassen.c:39,51 --
+   halve while no dimension satisfies 3*dim < 4*cutoff, cutoff rounded down to a multiple of 64),
+   cutoff == 0 the engine's own default (split while m/2 >= 4096, l/2 >= 8192, n/2 >= 4096); both
+   capped so that every level still halves whole words. */
+int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
+
 /* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..3, default 3;
    a scheduling knob: results are bit-identical for every value).  Returns the previous value;
    out-of-range arguments only query. */

@@ -68,6 +68,7 @@ SYMBOLS = {
     "m4ri_amd_mask_tail_dev": (_I, [_P, _I64, _I64, _I64, _P]),
     "m4ri_amd_set_profiling": (None, [_I]),
     "m4ri_amd_set_max_fuse": (_I, [_I]),
+    "m4ri_amd_plan_levels": (_I, [_I64, _I64, _I64, _I]),
     "m4ri_amd_pin": (_I, [MzdPtr]),
     "m4ri_amd_sync": (_I, [MzdPtr]),
     "m4ri_amd_host_modified": (_I, [MzdPtr]),
@@ -208,6 +209,11 @@ def unpin(M: Mzd) -> None:
 
 def is_pinned(M: Mzd) -> int:
     return int(lib().m4ri_amd_is_pinned(M.ptr))
+
+
+def plan_levels(m: int, l: int, n: int, cutoff: int = 0) -> int:
+    """Strassen-Winograd levels the engine would use (host logic only, no GPU needed)."""
+    return int(lib().m4ri_amd_plan_levels(m, l, n, cutoff))
 
 
 def set_max_fuse(levels: int) -> int:

@@ -537,6 +537,12 @@ int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols,
   return (int)gf2_launch_mask_tail((hipStream_t)stream, M, stride, rows, ncols);
 }
 
+int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {  // pure host logic: no device needed
+  if (m <= 0 || l <= 0 || n <= 0 || cutoff < 0) return 0;
+  if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
+  return plan_levels(m, l, n, cutoff);
+}
+
 int m4ri_amd_set_max_fuse(int levels) {
   std::lock_guard<std::mutex> lk(g_mu);
   const int old = g_max_fuse;
