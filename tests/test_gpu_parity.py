@@ -355,9 +355,10 @@ def test_randomized_shapes_windows_cutoffs(oracle):
     """Seeded fuzz through the C ABI: random shapes, cutoffs, mul/addmul, operands and results that are
     windows of larger parents (column offsets on word boundaries, mzd.c:161), checked word for word
     against the oracle INCLUDING the parents' bits outside the result window."""
-    rng = np.random.default_rng(20260928)
-    for case in range(80):
-        m, l, n = (int(x) for x in rng.integers(1, 1400, 3))
+    rng = np.random.default_rng(int(os.environ.get("M4RI_AMD_FUZZ_SEED", "20260928")))
+    hi = int(os.environ.get("M4RI_AMD_FUZZ_MAXDIM", "1400"))
+    for case in range(int(os.environ.get("M4RI_AMD_FUZZ_CASES", "80"))):  # soak runs: raise via the environment
+        m, l, n = (int(x) for x in rng.integers(1, hi, 3))
         if case % 9 == 0:
             m, l, n = (int(x) for x in rng.integers(1, 90, 3))          # tiny: the reference's naive fallbacks
         if case % 13 == 0:
