@@ -222,9 +222,25 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
   // one stage: gather from the four tables of stage s (buffer J = s & 1) while the builder waves
   // write those of stage s+1 into buffer J^1
-  auto stage = [&](auto jtag, auto btag, int s) {
+  auto stage = [&](auto jtag, auto btag, auto atag, int s) {
     constexpr int J        = decltype(jtag)::value;
     constexpr bool BUILDER = decltype(btag)::value;
+    constexpr bool ACTIVE  = decltype(atag)::value;  // false: every row of this wave lies below the matrix
+    if constexpr (!ACTIVE) {
+      // a wave of padding rows gathers nothing (a partly filled last row tile then costs the LDS
+      // array only its real rows); a builder still delivers its share of the next tables
+      if constexpr (BUILDER) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) put_entry(i, J ^ 1);
+        load_lo(s + 2);
+        make_base();
+        load_hi(s + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     // builder, on entry: cur = base of this thread's table of stage s+1 (made late in the previous
     // stage), blo_rows = its chain rows, bhi_rows = the base rows of stage s+2
     // pipeline depth: rows whose gathers are in flight ahead of the XORs
@@ -277,11 +293,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
 
   // the two roles are two loops (wave-uniform branch), so each gets its own register allocation:
   // the gather-only waves carry no B rows at all
-  auto run = [&](auto btag) {
+  auto run = [&](auto btag, auto atag) {
     constexpr bool BUILDER = decltype(btag)::value;
+    constexpr bool ACTIVE  = decltype(atag)::value;
     constexpr int AR       = BUILDER ? K8_AR : K8Q_AR_OTHER;
+    if constexpr (ACTIVE) {
 #pragma unroll
-    for (int g = 0; g < AR / 4; ++g) load_a4(g, g, q_begin);  // q = stage here: one dword of A per stage
+      for (int g = 0; g < AR / 4; ++g) load_a4(g, g, q_begin);  // q = stage here: one dword of A per stage
+    }
     if constexpr (BUILDER) {
       // prologue: tables of the first stage (buffer 0: q_begin is even), then the rows for the second
       load_hi(q_begin);
@@ -300,13 +319,16 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     // two stages per trip so the buffer parity is a compile-time constant; an odd tail runs one
     // extra stage whose B rows and A dwords lie past the end and read as 0
     for (int q = q_begin; q < q_end; q += 2) {
-      stage(std::integral_constant<int, 0>{}, btag, q);
-      stage(std::integral_constant<int, 1>{}, btag, q + 1);
+      stage(std::integral_constant<int, 0>{}, btag, atag, q);
+      stage(std::integral_constant<int, 1>{}, btag, atag, q + 1);
     }
   };
   if (q_begin < q_end) {
-    if (__builtin_amdgcn_readfirstlane(tid >> 8) == K8Q_BUILDER_HALF) run(std::true_type{});
-    else run(std::false_type{});
+    // a wave owns 512 consecutive rows of the tile; in the last row tile some waves own only padding
+    const bool active  = __builtin_amdgcn_readfirstlane(tile_m * K8_R + (tid >> 6) * (16 * RG)) < p.m;
+    const bool builder = __builtin_amdgcn_readfirstlane(tid >> 8) == K8Q_BUILDER_HALF;
+    if (builder) { if (active) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+    else         { if (active) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
   }
 
   // epilogue: C tile out.  One running row pointer (pinned, so hipcc cannot hoist RG 64-bit row
