@@ -368,6 +368,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
     need += (prepack && d == L ? 0 : pad((size_t)cnt * md * wl)) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
+  // C += A*B through a three-level up pass: the pass writes a temporary and one XOR pass folds it into
+  // C (the accumulating three-level kernel needs > 256 registers per lane and runs at a quarter of the rate)
+  const bool acc_via_tmp = add && fuse == 3 && L == 3;
+  if (acc_via_tmp) need += pad((size_t)m * (n / 64));
   {
     const size_t a7_bfs = packed_a_words(m >> L, l >> L, ipow7(L));
     if (a7_bfs > a7_extra) a7_extra = a7_bfs;
@@ -386,6 +390,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
   }
+  word *acc_tmp = acc_via_tmp ? ws_take(e, (size_t)m * (n / 64)) : nullptr;
   e->stats.workspace_bytes = (double)e->ws_cap * 8.0;
   // down passes: level d -> d+1, and d -> L for the fused pass at the bottom
   for (int d = 0; d < L;) {
@@ -431,7 +436,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
     const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
-    if (step == 3) {
+    if (step == 3 && acc && acc_tmp) {
+      HIPTRY(gf2_launch_winograd_up3(st, 0, Pl[d], acc_tmp, n / 64, 0, cnt, cm, cn / 64));
+      HIPTRY(gf2_launch_rowwise(st, 0, C.p, C.stride, C.p, C.stride, acc_tmp, n / 64, m, n / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * 407.0 + 8.0 * 3.0 * (double)m * (n / 64);
+    } else if (step == 3) {
       HIPTRY(gf2_launch_winograd_up3(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (acc ? 471.0 : 407.0);
     } else if (step == 2) {
