@@ -4,14 +4,16 @@
 // Replaces the reference's recursive, memory-frugal Strassen-Winograd driver
 //   _mzd_mul_even / _mzd_addmul_even      /root/reference m4ri/strassen.c:41-208, :367-526
 // by a BREADTH-FIRST schedule sized for 288 GB of HBM: for L levels
-//   L "down" passes per operand  (each parent -> its 7 Winograd operand combinations, fused),
-//   ONE batched M4RM leaf launch (all 7^L products at once: >> 256 workgroups, one launch),
-//   L "up" passes                (7 products -> the 4 quadrants of the parent, fused; the last one
-//                                 writes, or XORs into, the caller's C).
+//   "down" passes per operand    (a parent -> its Winograd operand combinations; the deepest
+//                                 min(L, 3) levels in ONE fused pass, the A side written straight
+//                                 into the leaf's packed form),
+//   ONE batched M4RM leaf launch (all 7^L products at once: >> 256 workgroups),
+//   "up" passes                  (products -> the quadrants of the parent, fused the same way; the
+//                                 last one writes, or XORs into, the caller's C).
 // The depth-first reference needs 2-3 quadrant temporaries per level and runs 7^L small leaves one
 // after another; on a GPU that starves the chip (a 4096^3 leaf is 8 workgroups).  Breadth-first
-// keeps (7/4)^d copies of the operands per level -- 15.6 GiB at n = 65536, L = 3 -- which is
-// nothing here, and turns the whole product into 3L+1 large launches on one stream.
+// keeps the 7^L leaf operands and products -- 8.4 GiB at n = 65536, L = 3, intermediate levels never
+// materialised -- and turns the whole product into four large launches on one stream.
 // Remainders that do not fit the even 2^L split are peeled with direct leaf launches exactly like
 // strassen.c:170-204.
 #include <hip/hip_runtime.h>
