@@ -1,13 +1,16 @@
-// aux_kernels.hip -- the HBM-bound helpers around the M4RM leaf: the two fused Strassen-Winograd
-// passes, strided XOR / copy, tail masking and the deterministic fill.
+// aux_kernels.hip -- the HBM-bound helpers around the M4RM leaf: the fused Strassen-Winograd passes
+// (one, two or three levels per pass; the A side optionally written straight into the leaf's packed
+// form), strided XOR / copy / masked copy, the fold of split leaf launches, tail masking and the
+// deterministic fill.
 //
-// They replace the reference's 15 separate quadrant additions per recursion node
+// The passes replace the reference's 15 separate quadrant additions per recursion node
 // (_mzd_add, /root/reference m4ri/mzd.c:1471-1583, called from m4ri/strassen.c:111-150) by one
-// "down" pass per operand and one "up" pass per level: every operand word is read once and every
-// result word written once per level (33 quadrant transfers per node instead of 45).
+// "down" pass per operand and one "up" pass: every operand word is read once and every result word
+// written once per PASS (33 quadrant transfers per node instead of 45 with single-level passes;
+// multi-level passes skip the intermediate levels altogether).
 //
-// All of these are pure streaming kernels: one 64-bit word (or a 16-byte pair) per lane, rows
-// contiguous, grid-stride -- bounded by HBM bandwidth, nothing to tile.
+// All of these are streaming kernels: one 64-bit word (or a 16-byte pair) per lane, rows
+// contiguous -- bounded by HBM bandwidth; only the packed-output passes tile (an LDS transpose).
 #include <hip/hip_runtime.h>
 #include "gf2_common.h"
 
