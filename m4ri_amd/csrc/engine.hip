@@ -178,9 +178,9 @@ bool packed_a_fits(const Engine *e, const LeafKind &kind, int64_t m, int64_t l, 
 
 // a_prepacked: the engine's packed-A scratch already holds A in the form the picked kernel reads
 // (written by the fused down pass); A itself is then not touched.
-int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
-                const word *B, int64_t bs, int64_t bbs, int64_t m, int64_t l, int64_t n, int64_t batch,
-                bool add, int ksplit_req, bool a_prepacked = false) {
+int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
+                    const word *B, int64_t bs, int64_t bbs, int64_t m, int64_t l, int64_t n, int64_t batch,
+                    bool add, int ksplit_req, bool a_prepacked) {
   if (m == 0 || n == 0 || batch == 0) return 0;
   if (m > INT32_MAX || l > INT32_MAX || n > INT32_MAX) return (int)hipErrorInvalidValue;
   // 32-bit byte offsets inside one operand (raw buffer addressing)
@@ -305,6 +305,37 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
   e->stats.leaf_gen = kind.gen;
   e->stats.leaf_bytes += 8.0 * (double)batch * ((double)m * words_of(l) + (double)l * wn + (double)m * wn * (add ? 2 : 1));
   return 0;
+}
+
+// The kernels address one operand of one product through a raw buffer descriptor: 32-bit byte
+// offsets, so A (m rows) and B (l rows) of a single product must each stay below 4 GiB.  Strassen
+// leaves always do; a direct product on huge operands (a remainder strip against a 262144-row A, an
+// unsplit 8 GiB matrix) is cut into row chunks of A/C and inner-dimension chunks of A/B here.
+int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, const word *A, int64_t as, int64_t abs_,
+                const word *B, int64_t bs, int64_t bbs, int64_t m, int64_t l, int64_t n, int64_t batch,
+                bool add, int ksplit_req, bool a_prepacked = false) {
+  constexpr uint64_t LIMIT = (1ull << 32) - (1ull << 20);
+  if (batch == 1 && !a_prepacked) {
+    if ((uint64_t)m * (uint64_t)as * 8 >= LIMIT && m > 4096) {  // rows of A and C: multiples of a tile
+      int64_t m1 = (int64_t)(LIMIT / ((uint64_t)as * 8)) / 4096 * 4096;
+      if (m1 < 4096) m1 = 4096;
+      for (int64_t r0 = 0; r0 < m; r0 += m1) {
+        const int64_t mr = (m - r0) < m1 ? (m - r0) : m1;
+        if (int rc = launch_leaf(e, st, C + r0 * cs, cs, 0, A + r0 * as, as, 0, B, bs, 0, mr, l, n, 1, add, ksplit_req)) return rc;
+      }
+      return 0;
+    }
+    if ((uint64_t)l * (uint64_t)bs * 8 >= LIMIT && l > 4096) {  // inner dimension: word-aligned slabs, later ones accumulate
+      int64_t l1 = (int64_t)(LIMIT / ((uint64_t)bs * 8)) / 4096 * 4096;
+      if (l1 < 4096) l1 = 4096;
+      for (int64_t k0 = 0; k0 < l; k0 += l1) {
+        const int64_t lk = (l - k0) < l1 ? (l - k0) : l1;
+        if (int rc = launch_leaf(e, st, C, cs, 0, A + k0 / 64, as, 0, B + k0 * bs, bs, 0, m, lk, n, 1, add || k0 > 0, ksplit_req)) return rc;
+      }
+      return 0;
+    }
+  }
+  return launch_leaf_one(e, st, C, cs, cbs, A, as, abs_, B, bs, bbs, m, l, n, batch, add, ksplit_req, a_prepacked);
 }
 
 int reserve_apk(Engine *e, size_t words) {
@@ -457,10 +488,34 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   return 0;
 }
 
+// upper bound of the words bfs_product reserves for an L-level schedule (level-L operands and products,
+// packed A, the materialised upper levels, slabs, the accumulate temporary)
+size_t bfs_words_bound(int64_t m, int64_t l, int64_t n, int L) {
+  const int fuse = L < g_max_fuse ? L : g_max_fuse;
+  size_t w = 0;
+  for (int d = 1; d <= L; ++d) {
+    if (!(d <= L - fuse || d == L)) continue;
+    const size_t md = (size_t)(m >> d), wl = (size_t)((l >> d) / 64), ld = (size_t)(l >> d), wn = (size_t)((n >> d) / 64);
+    w += (size_t)ipow7(d) * (md * wl + ld * wn + md * wn) + 96;
+  }
+  w += packed_a_words(m >> L, l >> L, ipow7(L)) + packed_a_words(m, l, 1) + (size_t)PART_SLABS * LEAF_PART_WORDS;
+  w += (size_t)m * (size_t)(n / 64 + 1);
+  return w;
+}
+
 int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
   if (m == 0 || n == 0) return 0;
   int L = plan_levels(m, l, n, cutoff);
+  if (L > 0) {
+    // the breadth-first schedule keeps 3 * (7/4)^L operand sizes resident: take fewer levels when
+    // that does not fit what the device has left (the workspace we already hold counts as free)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double budget = 0.92 * ((double)free_b + (double)e->ws_cap * 8.0);
+      while (L > 0 && (double)bfs_words_bound(m, l, n, L) * 8.0 > budget) --L;
+    }
+  }
   e->stats.levels = L;
   if (L == 0) {
     if (int rc = reserve_apk(e, packed_a_words(m, l, 1))) return rc;

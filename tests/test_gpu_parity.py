@@ -430,3 +430,60 @@ def test_inner_dimension_splits_fold_to_the_same_bits(add):
             assert m4ri_amd.get_stats().leaf_gen == 4
         else:
             assert torch.equal(ref, C), f"ksplit={ksplit}"
+
+
+def test_operands_beyond_4_gib_are_chunked():
+    """One operand of a direct (no Strassen level) product larger than the 4 GiB a raw buffer descriptor
+    can address: the engine cuts rows of A/C, or the inner dimension, into chunks (engine.hip launch_leaf).
+    Checked against the same product assembled from hand-made pieces that are each below the limit."""
+    # (a) A = 70000 x 524288 bits = 4.3 GiB, thin B
+    m, l, n = 70000, 524288, 512
+    A, B = dev_random(m, l, 101), dev_random(l, n, 102)
+    wl, w = l // 64, n // 64
+    C = torch.empty((m, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n)
+    assert m4ri_amd.get_stats().levels == 0
+    D = torch.empty_like(C)
+    h = 32768
+    m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, h, l, n)
+    m4ri_amd.mul_dev(D.data_ptr() + 8 * h * w, w, A.data_ptr() + 8 * h * wl, wl, B.data_ptr(), w, m - h, l, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C, D)
+    del A, B, C, D
+    # (b) B = 524288 x 65536 bits = 4 GiB: inner-dimension chunks, the later ones accumulate
+    m, l, n = 4096, 524288, 65536
+    A, B = dev_random(m, l, 103), dev_random(l, n, 104)
+    wl, w = l // 64, n // 64
+    C = torch.empty((m, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n)
+    assert m4ri_amd.get_stats().levels == 0
+    D = torch.empty_like(C)
+    h = 262144
+    m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, h, n)
+    m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr() + 8 * (h // 64), wl, B.data_ptr() + 8 * h * w, w, m, l - h, n, add=True)
+    torch.cuda.synchronize()
+    assert torch.equal(C, D)
+
+
+def test_strassen_depth_shrinks_to_the_memory_that_is_left():
+    """The breadth-first schedule needs ~9 GiB of workspace for 65536^3 at 3 levels; with most of the HBM
+    taken it must take fewer levels (engine.hip engine_mul) and still give the same bits."""
+    n = 32768
+    w = n // 64
+    A, B = dev_random(n, n, 111), dev_random(n, n, 112)
+    C = torch.empty((n, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
+    torch.cuda.synchronize()
+    assert m4ri_amd.get_stats().levels == 2
+    m4ri_amd.lib().m4ri_amd_release_workspace()
+    free, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (900 << 20)), dtype=torch.uint8, device="cuda")  # leave ~0.9 GiB
+    try:
+        D = torch.empty((n, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
+        torch.cuda.synchronize()
+        assert m4ri_amd.get_stats().levels < 2
+        assert torch.equal(C, D)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
