@@ -5,11 +5,11 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, m4ri_amd
 m4ri_amd.init(0)
-n = 131072; w = n // 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072; w = n // 64
 A = torch.empty((n, w), dtype=torch.int64, device="cuda"); B = torch.empty_like(A)
 m4ri_amd.fill_dev(A.data_ptr(), w, n, n, 3); m4ri_amd.fill_dev(B.data_ptr(), w, n, n, 4)
 outs = []
-for cutoff, fuse in ((0, 3), (16384, 2)):
+for cutoff, fuse in ((0, 3), (n // 8, 2)):
     m4ri_amd.set_max_fuse(fuse)
     C = torch.empty_like(A)
     m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, cutoff=cutoff)
@@ -18,6 +18,6 @@ for cutoff, fuse in ((0, 3), (16384, 2)):
     m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, cutoff=cutoff)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     st = m4ri_amd.get_stats()
-    print(f"131072^3 cutoff={cutoff} fuse={fuse}: levels {st.levels}, leaf {st.leaf_m}x{st.leaf_l}x{st.leaf_n} x{st.leaf_products}, {dt*1e3:.1f} ms, {n**3/dt:.3e} bit-op/s, ws {st.workspace_bytes/2**30:.1f} GiB", flush=True)
+    print(f"{n}^3 cutoff={cutoff} fuse={fuse}: levels {st.levels}, leaf {st.leaf_m}x{st.leaf_l}x{st.leaf_n} x{st.leaf_products}, {dt*1e3:.1f} ms, {n**3/dt:.3e} bit-op/s, ws {st.workspace_bytes/2**30:.1f} GiB", flush=True)
     outs.append(C)
 print("schedules agree:", bool(torch.equal(outs[0], outs[1])))
