@@ -5,6 +5,8 @@ import ctypes
 import os
 import re
 import subprocess
+
+import pytest
 import sys
 
 import m4ri_amd
@@ -89,3 +91,31 @@ def test_product_path_never_touches_the_oracle():
                 if re.search(r"gf2_oracle|liboracle|oracle/|cpu_libs|libm4ri_ref", t):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/m4ri_amd.h is the contract a C program (or M4RI itself) compiles against: it must be
+    valid C99 on its own, and -- with M4RI_AMD_NO_MZD_T -- next to M4RI's own mzd_t."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "uses_header.c"
+    src.write_text('#include <m4ri_amd.h>\n'
+                   'int main(void) { mzd_t *A = m4ri_amd_mzd_init(8, 8); mzd_t *C = mzd_mul(0, A, A, 0);\n'
+                   '  m4ri_amd_pin(A); m4ri_amd_unpin(A); m4ri_amd_mzd_free(A); m4ri_amd_mzd_free(C);\n'
+                   '  return m4ri_amd_plan_levels(65536, 65536, 65536, 0) != 3; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref_inc = "/root/reference"
+    if os.path.exists(os.path.join(ref_inc, "m4ri", "mzd.h")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "inc_seq")):
+        src2 = tmp_path / "next_to_m4ri.c"
+        src2.write_text('#include <m4ri/m4ri.h>\n#define M4RI_AMD_NO_MZD_T\n#include <m4ri_amd.h>\n'
+                        'int main(void) { return sizeof(mzd_t) != 64; }\n')
+        cfg = os.path.join(ROOT, "oracle", "_ref", "inc_seq")
+        r = subprocess.run([gcc, "-std=gnu99", "-Wall", "-fsyntax-only", "-I", inc, "-I", cfg, "-I", os.path.join(cfg, "m4ri"),
+                            "-I", ref_inc, str(src2)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
