@@ -5,9 +5,9 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
-import sys
 
 import m4ri_amd
 from m4ri_amd.mzd import Mzd, MzdStruct
