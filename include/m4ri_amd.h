@@ -135,6 +135,11 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out);
    capped so that every level still halves whole words. */
 int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
 
+/* Bytes the breadth-first schedule's workspace may take (0 = automatic: what the device has left).
+   Levels that do not fit run depth-first, one sub-product after the other, like the reference's
+   recursion -- same bits.  Returns the previous value; negative arguments only query. */
+int64_t m4ri_amd_set_workspace_budget(int64_t bytes);
+
 /* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..3, default 3;
    a scheduling knob: results are bit-identical for every value).  Returns the previous value;
    out-of-range arguments only query. */

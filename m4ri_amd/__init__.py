@@ -69,6 +69,7 @@ SYMBOLS = {
     "m4ri_amd_set_profiling": (None, [_I]),
     "m4ri_amd_set_max_fuse": (_I, [_I]),
     "m4ri_amd_plan_levels": (_I, [_I64, _I64, _I64, _I]),
+    "m4ri_amd_set_workspace_budget": (_I64, [_I64]),
     "m4ri_amd_pin": (_I, [MzdPtr]),
     "m4ri_amd_sync": (_I, [MzdPtr]),
     "m4ri_amd_host_modified": (_I, [MzdPtr]),
@@ -214,6 +215,11 @@ def is_pinned(M: Mzd) -> int:
 def plan_levels(m: int, l: int, n: int, cutoff: int = 0) -> int:
     """Strassen-Winograd levels the engine would use (host logic only, no GPU needed)."""
     return int(lib().m4ri_amd_plan_levels(m, l, n, cutoff))
+
+
+def set_workspace_budget(nbytes: int) -> int:
+    """Bytes the breadth-first workspace may take (0 = automatic); returns the previous value."""
+    return int(lib().m4ri_amd_set_workspace_budget(int(nbytes)))
 
 
 def set_max_fuse(levels: int) -> int:

@@ -503,20 +503,18 @@ size_t bfs_words_bound(int64_t m, int64_t l, int64_t n, int L) {
   return w;
 }
 
-int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
+int64_t g_ws_budget = 0;  // bytes the breadth-first workspace may take; 0 = what the device has left (m4ri_amd_set_workspace_budget)
+
+double workspace_budget(const Engine *e) {
+  if (g_ws_budget > 0) return (double)g_ws_budget;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1e30;
+  return 0.92 * ((double)free_b + (double)e->ws_cap * 8.0);  // the workspace we already hold counts as free
+}
+
+// the breadth-first product with its remainder strips (strassen.c:170-204): L levels fit the memory
+int bfs_with_strips(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
-  if (m == 0 || n == 0) return 0;
-  int L = plan_levels(m, l, n, cutoff);
-  if (L > 0) {
-    // the breadth-first schedule keeps 3 * (7/4)^L operand sizes resident: take fewer levels when
-    // that does not fit what the device has left (the workspace we already hold counts as free)
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double budget = 0.92 * ((double)free_b + (double)e->ws_cap * 8.0);
-      while (L > 0 && (double)bfs_words_bound(m, l, n, L) * 8.0 > budget) --L;
-    }
-  }
-  e->stats.levels = L;
   if (L == 0) {
     if (int rc = reserve_apk(e, packed_a_words(m, l, 1))) return rc;
     return launch_leaf(e, st, C.p, C.stride, 0, A.p, A.stride, 0, B.p, B.stride, 0, m, l, n, 1, add, 0);
@@ -532,7 +530,7 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
     if (s3 > a7_strips) a7_strips = s3;
   }
   if (int rc = bfs_product(e, st, dview(C, 0, 0, me, ne), dview(A, 0, 0, me, le), dview(B, 0, 0, le, ne), add, L, a7_strips)) return rc;
-  // remainder strips (strassen.c:170-204): right columns, bottom rows, trailing inner slab
+  // remainder strips: right columns, bottom rows, trailing inner slab
   if (n > ne)
     if (int rc = launch_leaf(e, st, C.p + ne / 64, C.stride, 0, A.p, A.stride, 0, B.p + ne / 64, B.stride, 0, m, l, n - ne, 1, add, 0)) return rc;
   if (m > me)
@@ -540,6 +538,74 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
   if (l > le)
     if (int rc = launch_leaf(e, st, C.p, C.stride, 0, A.p + le / 64, A.stride, 0, B.p + le * B.stride, B.stride, 0, me, l - le, ne, 1, true, 0)) return rc;
   return 0;
+}
+
+// C (+)= A*B with L Strassen-Winograd levels.  The breadth-first schedule keeps 3 * (7/4)^L operand
+// sizes resident; when that does not fit, the TOP level runs depth-first like the reference
+// (strassen.c:111-150, in the product form of winograd_scatter): seven sub-products one after the
+// other, each through this function again with L - 1 levels, three quarter-size temporaries.
+int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) {
+  const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  if (L == 0 || (double)bfs_words_bound(m, l, n, L) * 8.0 <= workspace_budget(e)) return bfs_with_strips(e, st, C, A, B, add, L);
+  const int64_t me = m - m % 2, le = l - l % 128, ne = n - n % 128;  // halves on rows / whole words
+  if (me == 0 || le == 0 || ne == 0) return bfs_with_strips(e, st, C, A, B, add, 0);
+  const int64_t hm = me / 2, hl = le / 2, hn = ne / 2, wl = hl / 64, wn = hn / 64;
+  word *tmp = nullptr;  // X (hm x hl), Y (hl x hn), P (hm x hn): outside the workspace, which the sub-products re-carve
+  const size_t xw = (size_t)hm * wl, yw = (size_t)hl * wn, pw = (size_t)hm * wn;
+  HIPTRY(hipMalloc(reinterpret_cast<void **>(&tmp), (xw + yw + pw) * 8));
+  DMat X{tmp, hm, hl, wl}, Y{tmp + xw, hl, hn, wn}, P{tmp + xw + yw, hm, hn, wn};
+  auto qa = [&](int i, int j) { return dview(A, i * hm, j * hl, hm, hl); };
+  auto qb = [&](int i, int j) { return dview(B, i * hl, j * hn, hl, hn); };
+  auto qc = [&](int i, int j) { return dview(C, i * hm, j * hn, hm, hn); };
+  auto xor3v = [&](DMat D, DMat U, DMat V) { return (int)gf2_launch_rowwise(st, 0, D.p, D.stride, U.p, U.stride, V.p, V.stride, D.nrows, words_of(D.ncols)); };
+  auto copyv = [&](DMat D, DMat U) { return (int)gf2_launch_rowwise(st, 1, D.p, D.stride, U.p, U.stride, nullptr, 0, D.nrows, words_of(D.ncols)); };
+  int rc = 0;
+  bool touched[2][2] = {{add, add}, {add, add}};  // has this quadrant of C received its first term?
+  for (int j = 0; j < 7 && rc == 0; ++j) {
+    // operand combinations of winograd_child: [A11, A12, S4, A22, S1, S2, S3] x [B11, B21, B22, T4, T1, T2, T3]
+    DMat a = X, b = Y;
+    switch (j) {
+      case 0: a = qa(0, 0); b = qb(0, 0); break;
+      case 1: a = qa(0, 1); b = qb(1, 0); break;
+      case 2: rc = xor3v(X, qa(1, 0), qa(1, 1)); if (!rc) rc = xor3v(X, X, qa(0, 0)); if (!rc) rc = xor3v(X, X, qa(0, 1)); b = qb(1, 1); break;
+      case 3: a = qa(1, 1);
+              rc = xor3v(Y, qb(1, 1), qb(0, 1)); if (!rc) rc = xor3v(Y, Y, qb(0, 0)); if (!rc) rc = xor3v(Y, Y, qb(1, 0)); break;
+      case 4: rc = xor3v(X, qa(1, 0), qa(1, 1)); if (!rc) rc = xor3v(Y, qb(0, 1), qb(0, 0)); break;
+      case 5: rc = xor3v(X, qa(1, 0), qa(1, 1)); if (!rc) rc = xor3v(X, X, qa(0, 0));
+              if (!rc) rc = xor3v(Y, qb(1, 1), qb(0, 1)); if (!rc) rc = xor3v(Y, Y, qb(0, 0)); break;
+      default: rc = xor3v(X, qa(0, 0), qa(1, 0)); if (!rc) rc = xor3v(Y, qb(1, 1), qb(0, 1)); break;
+    }
+    if (rc) break;
+    rc = product(e, st, P, a, b, false, L - 1);
+    if (rc) break;
+    // product j goes to the quadrants winograd_scatter names
+    static const int targets[7][4] = {{1, 1, 1, 1}, {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 1, 0, 1}, {0, 1, 1, 1}, {0, 0, 1, 1}};
+    for (int q = 0; q < 4 && rc == 0; ++q) {
+      if (!targets[j][q]) continue;
+      DMat cq = qc(q >> 1, q & 1);
+      rc = touched[q >> 1][q & 1] ? xor3v(cq, cq, P) : copyv(cq, P);
+      touched[q >> 1][q & 1] = true;
+    }
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);  // the temporaries go away below
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  // remainder strips of THIS level, by direct (chunked) leaf products like strassen.c:170-204
+  if (n > ne) { if ((rc = reserve_apk(e, packed_a_words(m, l, 1)))) return rc;
+                if ((rc = launch_leaf(e, st, C.p + ne / 64, C.stride, 0, A.p, A.stride, 0, B.p + ne / 64, B.stride, 0, m, l, n - ne, 1, add, 0))) return rc; }
+  if (m > me) { if ((rc = reserve_apk(e, packed_a_words(m - me, l, 1)))) return rc;
+                if ((rc = launch_leaf(e, st, C.p + me * C.stride, C.stride, 0, A.p + me * A.stride, A.stride, 0, B.p, B.stride, 0, m - me, l, ne, 1, add, 0))) return rc; }
+  if (l > le) { if ((rc = reserve_apk(e, packed_a_words(me, l - le, 1)))) return rc;
+                if ((rc = launch_leaf(e, st, C.p, C.stride, 0, A.p + le / 64, A.stride, 0, B.p + le * B.stride, B.stride, 0, me, l - le, ne, 1, true, 0))) return rc; }
+  return 0;
+}
+
+int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
+  const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  if (m == 0 || n == 0) return 0;
+  const int L = plan_levels(m, l, n, cutoff);
+  e->stats.levels = L;
+  return product(e, st, C, A, B, add, L);
 }
 
 void reset_stats(Engine *e) {
@@ -607,6 +673,13 @@ int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {  // pure
   if (m <= 0 || l <= 0 || n <= 0 || cutoff < 0) return 0;
   if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
   return plan_levels(m, l, n, cutoff);
+}
+
+int64_t m4ri_amd_set_workspace_budget(int64_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int64_t old = g_ws_budget;
+  if (bytes >= 0) g_ws_budget = bytes;
+  return old;
 }
 
 int m4ri_amd_set_max_fuse(int levels) {

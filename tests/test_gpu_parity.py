@@ -465,9 +465,10 @@ def test_operands_beyond_4_gib_are_chunked():
     assert torch.equal(C, D)
 
 
-def test_strassen_depth_shrinks_to_the_memory_that_is_left():
-    """The breadth-first schedule needs ~9 GiB of workspace for 65536^3 at 3 levels; with most of the HBM
-    taken it must take fewer levels (engine.hip engine_mul) and still give the same bits."""
+def test_schedule_adapts_to_the_memory_that_is_left():
+    """The breadth-first schedule of 32768^3 wants ~1.7 GiB of workspace; with all but 0.9 GiB of the HBM
+    taken the automatic budget (hipMemGetInfo) sends the top level depth-first (engine.hip product):
+    same depth, same bits, no allocation failure."""
     n = 32768
     w = n // 64
     A, B = dev_random(n, n, 111), dev_random(n, n, 112)
@@ -482,8 +483,34 @@ def test_strassen_depth_shrinks_to_the_memory_that_is_left():
         D = torch.empty((n, w), dtype=torch.int64, device="cuda")
         m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
         torch.cuda.synchronize()
-        assert m4ri_amd.get_stats().levels < 2
+        assert m4ri_amd.get_stats().levels == 2 and m4ri_amd.get_stats().leaf_launches >= 7
         assert torch.equal(C, D)
     finally:
         del hog
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("m,l,n,cutoff,add,budget_mib", [
+    (16384, 16384, 16384, 0, False, 64),      # 1 level wanted, its 168 MiB do not fit: depth-first top level
+    (8192 + 37, 8192 + 64 + 5, 8192 + 128 + 11, 1024, True, 48),  # 3 levels, ragged, accumulate: depth-first twice
+    (32768, 16384, 16384, 0, False, 700),     # rectangular; the sub-products fit breadth-first
+])
+def test_depth_first_top_levels_when_the_workspace_does_not_fit(m, l, n, cutoff, add, budget_mib):
+    """engine.hip product(): levels whose breadth-first workspace exceeds the budget run depth-first (seven
+    sub-products one after the other, like strassen.c:111-150); same bits as the all-breadth-first run."""
+    wl, w = (l + 63) // 64, (n + 63) // 64
+    A, B, C0 = dev_random(m, l, 121), dev_random(l, n, 122), dev_random(m, n, 123)
+    ref = C0.clone()
+    m4ri_amd.mul_dev(ref.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=cutoff)
+    torch.cuda.synchronize()
+    levels, launches = m4ri_amd.get_stats().levels, m4ri_amd.get_stats().leaf_launches
+    old = m4ri_amd.set_workspace_budget(budget_mib << 20)
+    try:
+        C = C0.clone()
+        m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=cutoff)
+        torch.cuda.synchronize()
+        st = m4ri_amd.get_stats()
+        assert st.levels == levels and st.leaf_launches >= launches + 6  # seven sub-products instead of one batch
+        assert torch.equal(C, ref)
+    finally:
+        m4ri_amd.set_workspace_budget(old)
