@@ -93,7 +93,10 @@ int m4ri_amd_device_count(void);
 
 /* C (+)= A*B on the device: Strassen-Winograd levels over batched M4RM leaves.
  * C: m x n, A: m x l, B: l x n.  add != 0 accumulates.  cutoff: 0 = engine default, otherwise the
- * reference's meaning (recurse until 3*dim < 4*cutoff for some dim, strassen.c:39,51). */
+ * reference's meaning (recurse until 3*dim < 4*cutoff for some dim, strassen.c:39,51).
+ * Asynchronous on `stream`.  The engine has ONE workspace per device, so a product issued on another
+ * stream than the previous one first waits (on the device) for that one to finish; several host
+ * threads may call concurrently (the host side is serialised). */
 int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int cutoff,
                      void *stream);

@@ -100,6 +100,9 @@ struct Engine {
   std::vector<hipEvent_t> event_pool;
   hipStream_t pending_stream = nullptr;
   int cus               = 0;        // compute units of the device (workgroups resident at once: one per CU)
+  hipStream_t last_stream = nullptr;  // stream of the previous product: the workspace is shared, so a product
+  hipEvent_t last_done    = nullptr;  // on ANOTHER stream first waits for this event (recorded after every product)
+  bool have_last          = false;
 };
 
 std::mutex g_mu;
@@ -619,6 +622,20 @@ void reset_stats(Engine *e) {
 
 }  // namespace
 
+// One workspace per device: products issued on different streams are ordered against each other
+// (a product on the same stream as the previous one is ordered by the stream itself).
+int order_after_previous(Engine *e, hipStream_t st) {
+  if (e->have_last && e->last_stream != st && e->last_done) HIPTRY(hipStreamWaitEvent(st, e->last_done, 0));
+  return 0;
+}
+int mark_done(Engine *e, hipStream_t st) {
+  if (!e->last_done) HIPTRY(hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming));
+  HIPTRY(hipEventRecord(e->last_done, st));
+  e->last_stream = st;
+  e->have_last   = true;
+  return 0;
+}
+
 // ================================ C ABI (part 2 of include/m4ri_amd.h) ==========================
 extern "C" {
 
@@ -643,7 +660,9 @@ int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride,
   reset_stats(e);
   if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
   DMat dC{C, m, n, c_stride}, dA{const_cast<word *>(A), m, l, a_stride}, dB{const_cast<word *>(B), l, n, b_stride};
-  return engine_mul(e, (hipStream_t)stream, dC, dA, dB, add != 0, cutoff);
+  if (int rc = order_after_previous(e, (hipStream_t)stream)) return rc;
+  if (int rc = engine_mul(e, (hipStream_t)stream, dC, dA, dB, add != 0, cutoff)) return rc;
+  return mark_done(e, (hipStream_t)stream);
 }
 
 int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
@@ -652,8 +671,10 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
   Engine *e = engine_for_current_device();
   if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
+  if (int rc = order_after_previous(e, (hipStream_t)stream)) return rc;
   if (int rc = reserve_apk(e, packed_a_words(m, l, 1))) return rc;
-  return launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit);
+  if (int rc = launch_leaf(e, (hipStream_t)stream, C, c_stride, 0, A, a_stride, 0, B, b_stride, 0, m, l, n, 1, add != 0, ksplit)) return rc;
+  return mark_done(e, (hipStream_t)stream);
 }
 
 int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,

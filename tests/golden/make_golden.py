@@ -126,8 +126,23 @@ def fingerprints_xl():
                         fp=np.array([r[8] for r in rows], dtype=np.uint64))
 
 
+def fingerprints_xxl():
+    """131072^3 (four Strassen levels on the GPU side): ~half an hour of reference CPU time, ~10 GiB of RAM."""
+    op, m, l, n, par, sa, sb = "mul", 131072, 131072, 131072, 0, 7, 8
+    t = time.time()
+    A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
+    C = ref.mul(None, A, B, par)
+    fp = orc.fingerprint(C)
+    print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fingerprints_xxl.npz"), ops=np.array([op]),
+                        meta=np.array([[m, l, n, par]], dtype=np.int64), seeds=np.array([[sa, sb, 0]], dtype=np.uint64),
+                        fp=np.array([fp], dtype=np.uint64))
+
+
 if __name__ == "__main__":
-    if "--xl" in sys.argv:
+    if "--xxl" in sys.argv:
+        fingerprints_xxl()
+    elif "--xl" in sys.argv:
         fingerprints_xl()
     else:
         kat_small()

@@ -514,3 +514,52 @@ def test_depth_first_top_levels_when_the_workspace_does_not_fit(m, l, n, cutoff,
         assert torch.equal(C, ref)
     finally:
         m4ri_amd.set_workspace_budget(old)
+
+
+def test_131072_cubed_vs_reference_fingerprint(oracle):
+    """131072^3 (four Strassen levels, 2401 leaves, ~70 GiB of workspace; seeds 7, 8) against the real
+    reference's fingerprint (tests/golden/fingerprints_xxl.npz, half an hour of reference CPU time) and
+    Freivalds' identity; the depth-first top level gives the same bits."""
+    xxl = os.path.join(GOLD, "fingerprints_xxl.npz")
+    if not os.path.exists(xxl):
+        pytest.skip("tests/golden/fingerprints_xxl.npz not generated (make_golden.py --xxl)")
+    z = np.load(xxl)
+    m, l, n = (int(x) for x in z["meta"][0][:3])
+    sa, sb = int(z["seeds"][0][0]), int(z["seeds"][0][1])
+    A, B = dev_random(m, l, sa), dev_random(l, n, sb)
+    C = torch.empty((m, n // 64), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
+    assert m4ri_amd.get_stats().levels == 4
+    hC = to_host(C, m, n)
+    assert oracle.fingerprint(hC) == int(z["fp"][0])
+    assert freivalds(oracle, to_host(A, m, l), to_host(B, l, n), hC, m, l, n, 79)
+    old = m4ri_amd.set_workspace_budget(20 << 30)  # 4 levels want ~70 GiB: the top level goes depth-first
+    try:
+        D = torch.empty_like(C)
+        m4ri_amd.mul_dev(D.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
+        assert torch.equal(C, D)
+    finally:
+        m4ri_amd.set_workspace_budget(old)
+
+
+def test_products_on_different_streams_share_the_workspace_safely():
+    """Two streams, products issued alternately without any host synchronisation: the engine orders them on
+    the device (one workspace per device), so every result equals the single-stream one."""
+    n = 16384
+    w = n // 64
+    A, B = dev_random(n, n, 131), dev_random(n, n, 132)
+    A2, B2 = dev_random(n, n, 133), dev_random(n, n, 134)
+    ref1, ref2 = torch.empty((n, w), dtype=torch.int64, device="cuda"), torch.empty((n, w), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(ref1.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
+    m4ri_amd.mul_dev(ref2.data_ptr(), w, A2.data_ptr(), w, B2.data_ptr(), w, n, n, n)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(6):
+        C = torch.empty((n, w), dtype=torch.int64, device="cuda")
+        st, (a, b) = ((s1, (A, B)) if k % 2 == 0 else (s2, (A2, B2)))
+        m4ri_amd.mul_dev(C.data_ptr(), w, a.data_ptr(), w, b.data_ptr(), w, n, n, n, stream=st.cuda_stream)
+        outs.append(C)
+    torch.cuda.synchronize()
+    for k, C in enumerate(outs):
+        assert torch.equal(C, ref1 if k % 2 == 0 else ref2), k
