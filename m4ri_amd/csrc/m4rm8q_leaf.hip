@@ -30,6 +30,12 @@
 //     = 4 slots x 4 tables of ONE entry index = one whole bank row per ds_write service group, so
 //     the table writes are conflict-free as well.
 //
+//   * A launch covers a RANGE of the batch's tiles (LeafArgs::tile_base/tile_count) and may split the
+//     inner dimension (ksplit); the engine uses both to run full rounds of 256 workgroups unsplit and
+//     only the short last round split.  Splits combine without atomics: mode 2 stores every
+//     (tile, split) into its own dense slab and gf2_launch_reduce_partials folds the slabs into C.
+//   * Waves whose 512 rows all lie below the matrix (last row tile of a ragged m) skip their gathers.
+//
 // Everything else is generation 3's: C-stationary tile in VGPRs (128 dwords per lane), one
 // v_perm_b32 per lookup address, one v_bitop3_b32 per dword folds two lookups, Gray-code table
 // build, chunk-major A, range-checked buffer descriptors, one barrier per stage.

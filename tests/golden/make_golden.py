@@ -126,21 +126,24 @@ def fingerprints_xl():
                         fp=np.array([r[8] for r in rows], dtype=np.uint64))
 
 
-def fingerprints_xxl():
-    """131072^3 (four Strassen levels on the GPU side): ~half an hour of reference CPU time, ~10 GiB of RAM."""
-    op, m, l, n, par, sa, sb = "mul", 131072, 131072, 131072, 0, 7, 8
+def fingerprints_xxl(n=131072, sa=7, sb=8, name="fingerprints_xxl.npz"):
+    """131072^3 (four Strassen levels on the GPU side): 13 minutes of reference CPU time, ~10 GiB of RAM.
+    With --huge: 262144^3 (8 GiB per matrix, ~1.5 h, ~40 GiB of RAM) -> fingerprints_huge.npz."""
+    op, m, l, par = "mul", n, n, 0
     t = time.time()
     A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
     C = ref.mul(None, A, B, par)
     fp = orc.fingerprint(C)
     print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)
-    np.savez_compressed(os.path.join(HERE, "fingerprints_xxl.npz"), ops=np.array([op]),
+    np.savez_compressed(os.path.join(HERE, name), ops=np.array([op]),
                         meta=np.array([[m, l, n, par]], dtype=np.int64), seeds=np.array([[sa, sb, 0]], dtype=np.uint64),
                         fp=np.array([fp], dtype=np.uint64))
 
 
 if __name__ == "__main__":
-    if "--xxl" in sys.argv:
+    if "--huge" in sys.argv:
+        fingerprints_xxl(262144, 9, 10, "fingerprints_huge.npz")
+    elif "--xxl" in sys.argv:
         fingerprints_xxl()
     elif "--xl" in sys.argv:
         fingerprints_xl()

@@ -563,3 +563,19 @@ def test_products_on_different_streams_share_the_workspace_safely():
     torch.cuda.synchronize()
     for k, C in enumerate(outs):
         assert torch.equal(C, ref1 if k % 2 == 0 else ref2), k
+
+
+@pytest.mark.skipif(os.environ.get("M4RI_AMD_HUGE", "") == "", reason="8 GiB per matrix, minutes of host time: set M4RI_AMD_HUGE=1")
+def test_262144_cubed_vs_reference_fingerprint(oracle):
+    """262144^3 (8 GiB per matrix; five Strassen levels, the top two depth-first; seeds 9, 10) against the
+    real reference's fingerprint (tests/golden/fingerprints_huge.npz, make_golden.py --huge)."""
+    huge = os.path.join(GOLD, "fingerprints_huge.npz")
+    if not os.path.exists(huge):
+        pytest.skip("tests/golden/fingerprints_huge.npz not generated")
+    z = np.load(huge)
+    m, l, n = (int(x) for x in z["meta"][0][:3])
+    A, B = dev_random(m, l, int(z["seeds"][0][0])), dev_random(l, n, int(z["seeds"][0][1]))
+    C = torch.empty((m, n // 64), dtype=torch.int64, device="cuda")
+    m4ri_amd.mul_dev(C.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
+    assert m4ri_amd.get_stats().levels == 5
+    assert oracle.fingerprint(to_host(C, m, n)) == int(z["fp"][0])
