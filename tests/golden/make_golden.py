@@ -140,8 +140,30 @@ def fingerprints_xxl(n=131072, sa=7, sb=8, name="fingerprints_xxl.npz"):
                         fp=np.array([fp], dtype=np.uint64))
 
 
+def fingerprints_ragged_xl():
+    """Large shapes off every grid (remainder strips at all three places, partly filled tiles, an inner
+    dimension that is not a multiple of 64) -- minutes of reference CPU time each."""
+    rows = []
+    for (op, m, l, n, par, sa, sb, sc) in [("mul", 100003, 50021, 70017, 0, 21, 22, 0), ("mul", 40000, 131071, 9999, 0, 23, 24, 0),
+                                           ("addmul", 65537, 65601, 32897, 0, 25, 26, 27)]:
+        t = time.time()
+        A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
+        C = ref.mul(None, A, B, par) if op == "mul" else ref.addmul(Mzd.random(m, n, sc), A, B, par)
+        fp = orc.fingerprint(C)
+        rows.append((op, m, l, n, par, sa, sb, sc, fp))
+        print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)
+        del A, B, C
+    np.savez_compressed(os.path.join(HERE, "fingerprints_ragged_xl.npz"),
+                        ops=np.array([r[0] for r in rows]),
+                        meta=np.array([r[1:5] for r in rows], dtype=np.int64),
+                        seeds=np.array([r[5:8] for r in rows], dtype=np.uint64),
+                        fp=np.array([r[8] for r in rows], dtype=np.uint64))
+
+
 if __name__ == "__main__":
-    if "--huge" in sys.argv:
+    if "--ragged-xl" in sys.argv:
+        fingerprints_ragged_xl()
+    elif "--huge" in sys.argv:
         fingerprints_xxl(262144, 9, 10, "fingerprints_huge.npz")
     elif "--xxl" in sys.argv:
         fingerprints_xxl()

@@ -579,3 +579,22 @@ def test_262144_cubed_vs_reference_fingerprint(oracle):
     m4ri_amd.mul_dev(C.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
     assert m4ri_amd.get_stats().levels == 5
     assert oracle.fingerprint(to_host(C, m, n)) == int(z["fp"][0])
+
+
+def test_large_ragged_shapes_vs_reference_fingerprints(oracle):
+    """Large products off every grid (all three remainder strips, partly filled tiles, an inner dimension
+    that is not a multiple of 64, one accumulate) against the real reference's fingerprints
+    (tests/golden/fingerprints_ragged_xl.npz, make_golden.py --ragged-xl)."""
+    path = os.path.join(GOLD, "fingerprints_ragged_xl.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fingerprints_ragged_xl.npz not generated")
+    z = np.load(path)
+    for op, (m, l, n, par), (sa, sb, sc), fp in zip(z["ops"], z["meta"], z["seeds"], z["fp"]):
+        m, l, n, par = int(m), int(l), int(n), int(par)
+        wl, w = (l + 63) // 64, (n + 63) // 64
+        A, B = dev_random(m, l, int(sa)), dev_random(l, n, int(sb))
+        add = str(op) == "addmul"
+        C = dev_random(m, n, int(sc)) if add else torch.empty((m, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=par)
+        assert oracle.fingerprint(to_host(C, m, n)) == int(fp), (str(op), m, l, n)
+        del A, B, C
