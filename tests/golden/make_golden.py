@@ -145,10 +145,14 @@ def fingerprints_ragged_xl():
     dimension that is not a multiple of 64) -- minutes of reference CPU time each."""
     rows = []
     for (op, m, l, n, par, sa, sb, sc) in [("mul", 100003, 50021, 70017, 0, 21, 22, 0), ("mul", 40000, 131071, 9999, 0, 23, 24, 0),
-                                           ("addmul", 65537, 65601, 32897, 0, 25, 26, 27)]:
+                                           ("addmul", 65537, 65601, 32897, 0, 25, 26, 27),
+                                           ("mul", 32768, 32768, 32768, 1024, 28, 29, 0),   # caller cutoff: 5 levels on the GPU
+                                           ("m4rm", 20000, 30011, 10007, 0, 30, 31, 0),     # one leaf launch, no Strassen
+                                           ("mul", 8191, 65535, 8193, 0, 32, 33, 0)]:
         t = time.time()
         A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
-        C = ref.mul(None, A, B, par) if op == "mul" else ref.addmul(Mzd.random(m, n, sc), A, B, par)
+        C = (ref.mul(None, A, B, par) if op == "mul" else ref.mul_m4rm(None, A, B, par) if op == "m4rm"
+             else ref.addmul(Mzd.random(m, n, sc), A, B, par))
         fp = orc.fingerprint(C)
         rows.append((op, m, l, n, par, sa, sb, sc, fp))
         print(op, m, l, n, par, hex(fp), f"{time.time() - t:.1f}s", flush=True)

@@ -595,6 +595,9 @@ def test_large_ragged_shapes_vs_reference_fingerprints(oracle):
         A, B = dev_random(m, l, int(sa)), dev_random(l, n, int(sb))
         add = str(op) == "addmul"
         C = dev_random(m, n, int(sc)) if add else torch.empty((m, w), dtype=torch.int64, device="cuda")
-        m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=par)
+        if str(op) == "m4rm":
+            m4ri_amd.m4rm_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n)
+        else:
+            m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=par)
         assert oracle.fingerprint(to_host(C, m, n)) == int(fp), (str(op), m, l, n)
         del A, B, C
