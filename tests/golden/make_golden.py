@@ -164,8 +164,42 @@ def fingerprints_ragged_xl():
                         fp=np.array([r[8] for r in rows], dtype=np.uint64))
 
 
+WINDOW_XL = dict(pa=(30000, 30000, 41), pb=(30000, 30000, 42), pc=(30000, 30000, 43),
+                 a=(100, 64, 20100, 16448 + 37), b=(7, 128, 7 + 16384 + 37, 128 + 21000 + 5), c=(9000, 6400, 29000, 6400 + 21000 + 5))
+
+
+def fingerprint_window_xl():
+    """C_window += A_window * B_window on windows of three 30000 x 30000 parents (row offsets anywhere,
+    column offsets on word boundaries, widths off the word grid): fingerprint of the WHOLE parent of C.
+
+    The expected value is the reference's product of CLEAN COPIES of the windows, written back into the
+    parent under the column mask.  The reference applied to the windows themselves gives different bits in
+    the last word column (21005 columns leave a 13-column strip, which goes through the < 54-column
+    fallback of _mzd_mul_m4rm, brilliantrussian.c:1063; that path mishandles a windowed B whose excess
+    bits are not zero -- DESIGN.md 5).  Both fingerprints are stored; the tests require the first."""
+    W = WINDOW_XL
+    Pa, Pb, Pc = (Mzd.random(*W[k]) for k in ("pa", "pb", "pc"))
+    A, B, C = Pa.window(*W["a"]), Pb.window(*W["b"]), Pc.window(*W["c"])
+    t = time.time()
+    clean = ref.addmul(C.copy(), A.copy(), B.copy(), 0)
+    Pw = Pc.copy()
+    ref.addmul(Pw.window(*W["c"]), A, B, 0)       # the reference on the windows themselves
+    fp_on_windows = orc.fingerprint(Pw)
+    rows, wd = C.rows(), C.width
+    rows[:, :wd - 1] = clean.rows()[:, :wd - 1]
+    mask = np.uint64((1 << (C.ncols % 64)) - 1) if C.ncols % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    rows[:, wd - 1] = (rows[:, wd - 1] & ~mask) | (clean.rows()[:, wd - 1] & mask)
+    fp = orc.fingerprint(Pc)
+    print("window addmul", A.nrows, A.ncols, B.ncols, hex(fp), "(reference on the windows:", hex(fp_on_windows), ")",
+          f"{time.time() - t:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fingerprint_window_xl.npz"), fp=np.array([fp], dtype=np.uint64),
+                        fp_reference_on_windows=np.array([fp_on_windows], dtype=np.uint64))
+
+
 if __name__ == "__main__":
-    if "--ragged-xl" in sys.argv:
+    if "--window-xl" in sys.argv:
+        fingerprint_window_xl()
+    elif "--ragged-xl" in sys.argv:
         fingerprints_ragged_xl()
     elif "--huge" in sys.argv:
         fingerprints_xxl(262144, 9, 10, "fingerprints_huge.npz")

@@ -601,3 +601,31 @@ def test_large_ragged_shapes_vs_reference_fingerprints(oracle):
             m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=par)
         assert oracle.fingerprint(to_host(C, m, n)) == int(fp), (str(op), m, l, n)
         del A, B, C
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_large_windowed_addmul_vs_reference_parent_fingerprint(oracle, pinned):
+    """C_window += A_window * B_window on windows of three 30000 x 30000 parents (tests/golden/make_golden.py
+    WINDOW_XL): the fingerprint of the WHOLE parent of C must be that of the reference's product of clean
+    copies of the windows, merged under the column mask -- through the host entry point from host memory,
+    and with the three parents pinned (windows used in place on the device).  (The reference applied to the
+    windows themselves differs in the last word column: its < 54-column fallback mishandles a windowed B
+    with non-zero excess; that fingerprint is stored too and must NOT be what we produce.)"""
+    path = os.path.join(GOLD, "fingerprint_window_xl.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fingerprint_window_xl.npz not generated")
+    W = dict(pa=(30000, 30000, 41), pb=(30000, 30000, 42), pc=(30000, 30000, 43),
+             a=(100, 64, 20100, 16448 + 37), b=(7, 128, 7 + 16384 + 37, 128 + 21000 + 5), c=(9000, 6400, 29000, 6400 + 21000 + 5))
+    Pa, Pb, Pc = (Mzd.random(*W[k]) for k in ("pa", "pb", "pc"))
+    A, B, C = Pa.window(*W["a"]), Pb.window(*W["b"]), Pc.window(*W["c"])
+    if pinned:
+        for P in (Pa, Pb, Pc):
+            m4ri_amd.pin(P)
+    m4ri_amd.mzd_addmul(C, A, B, 0)
+    if pinned:
+        for P in (Pa, Pb, Pc):
+            m4ri_amd.unpin(P)
+    z = np.load(path)
+    got = oracle.fingerprint(Pc)
+    assert got == int(z["fp"][0])
+    assert got != int(z["fp_reference_on_windows"][0])
