@@ -119,3 +119,7 @@ def test_header_is_plain_c99(tmp_path):
         r = subprocess.run([gcc, "-std=gnu99", "-Wall", "-fsyntax-only", "-I", inc, "-I", cfg, "-I", os.path.join(cfg, "m4ri"),
                             "-I", ref_inc, str(src2)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+        # the binding hunk INTEGRATION.md shows a maintainer, as a compilable unit
+        r = subprocess.run([gcc, "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-I", cfg, "-I", os.path.join(cfg, "m4ri"),
+                            "-I", ref_inc, os.path.join(ROOT, "tests", "integration_stub.c")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
