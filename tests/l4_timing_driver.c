@@ -1,0 +1,50 @@
+/* tests/l4_timing_driver.c -- what LD_PRELOAD=libm4ri_amd.so does to M4RI's own L4 routines (our own client
+ * code against M4RI's public API; linked against the interposable reference build like dropin_driver.c):
+ * times mzd_trsm_upper_left, mzd_ple and mzd_solve_left at one size.  Run it with and without the preload;
+ * the internal mzd_addmul / _mzd_addmul calls of those routines then run on the GPU or on the CPU. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <m4ri/m4ri.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+static double now(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+int main(int argc, char **argv) {
+  const rci_t n = argc > 1 ? atoi(argv[1]) : 16384;
+  srandom(17);
+  printf("l4_timing_driver n=%d, m4ri_amd interposed: %s\n", n, dlsym(RTLD_DEFAULT, "m4ri_amd_get_stats") ? "yes" : "no");
+  mzd_t *U = mzd_init(n, n), *B = mzd_init(n, n), *A = mzd_init(n, n);
+  mzd_randomize(U);
+  mzd_randomize(B);
+  mzd_randomize(A);
+  for (rci_t i = 0; i < n; ++i) {
+    mzd_row(U, i)[i / 64] |= (word)1 << (i % 64);
+    for (wi_t w = 0; w < i / 64; ++w) mzd_row(U, i)[w] = 0;
+    if (i % 64) mzd_row(U, i)[i / 64] &= ~(((word)1 << (i % 64)) - 1);
+  }
+  mzd_t *X = mzd_copy(NULL, B);
+  double t = now();
+  mzd_trsm_upper_left(U, X, 0);
+  printf("  mzd_trsm_upper_left %d x %d : %.3f s\n", n, n, now() - t);
+  mzd_t *A2 = mzd_copy(NULL, A);
+  mzp_t *P = mzp_init(n), *Q = mzp_init(n);
+  t = now();
+  rci_t r = mzd_ple(A2, P, Q, 0);
+  printf("  mzd_ple             %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
+  mzd_t *A3 = mzd_copy(NULL, A), *Y = mzd_copy(NULL, B);
+  t = now();
+  int st = mzd_solve_left(A3, Y, 0, 0);
+  printf("  mzd_solve_left      %d x %d : %.3f s (status %d)\n", n, n, now() - t, st);
+  /* fingerprints so that the two runs can be compared */
+  word f1 = 0, f2 = 0;
+  for (rci_t i = 0; i < n; ++i)
+    for (wi_t w = 0; w < X->width; ++w) { f1 = f1 * 1099511628211ull ^ mzd_row(X, i)[w]; f2 = f2 * 1099511628211ull ^ mzd_row(A2, i)[w]; }
+  printf("  fingerprints: trsm %016llx ple %016llx\n", (unsigned long long)f1, (unsigned long long)f2);
+  return 0;
+}

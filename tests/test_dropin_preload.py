@@ -31,3 +31,21 @@ def test_ld_preload_drop_in():
     assert "leaf launch" in r.stdout
     # the reference's own TRSM / solve / PLE ran with their internal addmul calls on the GPU
     assert r.stdout.count("  L4 n=") == 2 and "the L4 cases ended on an interposed product" in r.stdout
+
+
+L4 = os.path.join(ROOT, "oracle", "_ref", "l4_timing_driver")
+
+
+@pytest.mark.gpu
+def test_l4_routines_give_identical_results_under_the_preload():
+    """tests/l4_timing_driver.c (M4RI's own mzd_trsm_upper_left / mzd_ple / mzd_solve_left at n = 6000): the
+    fingerprints of the TRSM solution and of the PLE decomposition are the same with the products on the
+    GPU (preload) as with the reference alone."""
+    if not os.path.exists(L4):
+        pytest.skip("oracle/_ref/l4_timing_driver not built (needs /root/reference)")
+    plain = subprocess.run([L4, "6000"], capture_output=True, text=True, timeout=600)
+    pre = subprocess.run([L4, "6000"], capture_output=True, text=True, timeout=600, env=dict(os.environ, LD_PRELOAD=m4ri_amd.LIB_PATH))
+    assert plain.returncode == 0 and pre.returncode == 0, plain.stderr[-2000:] + pre.stderr[-2000:]
+    assert "interposed: no" in plain.stdout and "interposed: yes" in pre.stdout
+    fp = [ln for ln in plain.stdout.splitlines() if "fingerprints:" in ln]
+    assert fp and fp == [ln for ln in pre.stdout.splitlines() if "fingerprints:" in ln]
