@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <vector>
 #include "gf2_common.h"
@@ -30,6 +31,19 @@ constexpr uint8_t FLAG_EXCESS = 0x2;  // mzd.h:144
 constexpr uint8_t FLAG_WINDOW = 0x4;  // mzd.h:150
 
 std::mutex g_api_mu;
+
+// M4RI_AMD_STATS=1: at exit, print how many products went through the host entry points, the time
+// spent in them (transfers included) and the bytes moved over PCIe -- for judging what an LD_PRELOAD
+// run of a larger program (PLE, TRSM) spends where
+struct ApiStats {
+  double seconds = 0, h2d = 0, d2h = 0;
+  long calls = 0;
+  ~ApiStats() {
+    if (calls && getenv("M4RI_AMD_STATS"))
+      fprintf(stderr, "m4ri_amd: %ld products through the host entry points, %.3f s inside them, %.2f GiB up, %.2f GiB down\n",
+              calls, seconds, h2d / 1073741824.0, d2h / 1073741824.0);
+  }
+} g_api_stats;
 
 [[noreturn]] void die(const char *fmt, ...) {  // misc.c:36-42
   va_list ap;
@@ -100,6 +114,7 @@ void upload(DevMat &d, const mzd_t *M) {
     HIPDIE(hipMemsetAsync(d.p, 0, (size_t)M->nrows * d.stride * 8, 0));  // but keep it deterministic)
   HIPDIE(hipMemcpy2D(d.p, (size_t)d.stride * 8, M->data, (size_t)M->rowstride * 8, (size_t)M->width * 8,
                      (size_t)M->nrows, hipMemcpyHostToDevice));
+  g_api_stats.h2d += (double)M->width * 8.0 * (double)M->nrows;
   HIPDIE(m4ri_amd_mask_tail_dev(d.p, d.stride, M->nrows, M->ncols, nullptr));
 }
 
@@ -107,6 +122,7 @@ void upload(DevMat &d, const mzd_t *M) {
 // inside high_bitmask when C is a window with excess
 void download(const DevMat &d, mzd_t *C) {
   if (C->nrows == 0 || C->width == 0) return;
+  g_api_stats.d2h += (double)C->width * 8.0 * (double)C->nrows;
   const bool dangerous = (C->flags & FLAG_WINDOW) && (C->ncols % 64 != 0);
   if (!dangerous) {
     HIPDIE(hipMemcpy2D(C->data, (size_t)C->rowstride * 8, d.p, (size_t)d.stride * 8, (size_t)C->width * 8,
@@ -171,6 +187,11 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff) {
   std::lock_guard<std::mutex> lk(g_api_mu);
   if (C->nrows == 0 || C->ncols == 0) return C;  // strassen.c:44
+  struct Timer {
+    timespec t0;
+    Timer() { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~Timer() { timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); g_api_stats.seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); g_api_stats.calls += 1; }
+  } timer;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
