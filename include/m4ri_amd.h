@@ -68,8 +68,11 @@ mzd_t *_mzd_addsqr_even(mzd_t *C, mzd_t const *A, int cutoff);
 mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
 mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
 mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear);
-/* OpenMP block-parallel entry points, m4ri/mp.h:47, :62: same results; here they run the same
- * single-GPU schedule (the GPU grid replaces the omp sections). */
+/* OpenMP block-parallel entry points, m4ri/mp.h:47, :62 (mp.c:277-324): same results.  With several
+ * devices configured (part 4: every visible GPU by default) and min(m, l, n) at or above the multi-device
+ * threshold, the sub-products of the top Strassen-Winograd level(s) are spread over the devices; otherwise
+ * -- one GPU, small products, pinned operands -- they run the single-GPU schedule (where the GPU grid
+ * replaces the omp sections). */
 mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
 mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
 
@@ -77,6 +80,9 @@ mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
  * same layout rules as mzd_init/mzd_free (mzd.c:142-157,179-185). */
 mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c);
 void m4ri_amd_mzd_free(mzd_t *A);
+/* Frees a C == NULL result with the allocator it came from (the host program's mzd_free when its
+ * mzd_init produced it, m4ri_amd_mzd_free otherwise) -- for bindings that cannot call mzd_free. */
+void m4ri_amd_result_free(mzd_t *A);
 
 /* =================================================================================================
  * Part 2 -- device-resident API.  Matrices live in HBM in the same bit-packed row-major layout:
@@ -104,7 +110,9 @@ int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride,
 int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                       int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit,
                       void *stream);
-/* C = A ^ B on rows x ncols bits (the device twin of _mzd_add, mzd.c:1471; in-place allowed). */
+/* C = A ^ B on rows x ncols bits: the device twin of _mzd_add (mzd.c:1471-1583).  In-place allowed,
+ * operands may have different strides; the last word of every row is written under the column mask
+ * and the other bits of C's last word are kept (mzd.c:1489). */
 int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t rows, int64_t ncols, void *stream);
 /* Deterministic fill: word (r, j) = splitmix64 stream `seed`, output number r*width + j, last word
@@ -166,6 +174,60 @@ int m4ri_amd_sync(mzd_t *M);           /* bring the host copy up to date (M or a
 int m4ri_amd_host_modified(mzd_t *M);  /* the host wrote into M: refresh the device copy               */
 int m4ri_amd_unpin(mzd_t *M);          /* sync, then drop the device copy                               */
 int m4ri_amd_is_pinned(const mzd_t *M);/* 0 no, 1 yes and host copy current, 2 yes and host copy stale  */
+
+/* ---- part 4: one product over several GPUs (m4ri/mp.c:158-324 is the reference's own
+ * block-parallel template) ------------------------------------------------------------------------------
+ * The units handed out are the 7 (levels = 1) or 49 (levels = 2) sub-products of the top
+ * Strassen-Winograd level(s) (strassen.c:111-150).  Layout: with S = 2^levels row blocks per matrix,
+ * rank r of `world` holds rows [cut(r), cut(r+1)) of EVERY block ("slab-cyclic"; cut(r) = rows*r/world),
+ * stacked into a local parent of 1/world of the rows and the same quadrant structure -- so the level's
+ * additions are ordinary local passes and only slabs of sub-product operands (one way) and of products
+ * (the other) cross the links, every rank to every rank.  Dimensions are zero-padded (M, L, N). */
+typedef struct m4ri_amd_shard_plan {
+  int32_t world, levels, nprod, blocks; /* ranks; sharded levels (1|2); 7^levels; 2^levels              */
+  int64_t m, l, n;                      /* the product C (m x n) = A (m x l) * B (l x n)                */
+  int64_t M, L, N;                      /* padded: M % blocks == 0, L and N % (64*blocks) == 0          */
+  int64_t bm, bl;                       /* rows of a sub-product's A operand (= of its result), of its B */
+  int64_t cwl, cwn;                     /* words per row of an A child; of a B child / a product        */
+} m4ri_amd_shard_plan;
+/* One slab of one sub-product operand (side 0: A child, 1: B child) or result (side 2): it lives at
+ * holder_off words into rank `holder`'s child / slab array and at owner_off words into rank `owner`'s
+ * operand / product array; sides 0, 1 travel holder -> owner, side 2 owner -> holder. */
+typedef struct m4ri_amd_shard_piece {
+  int32_t holder, owner;
+  int64_t holder_off, owner_off, words;
+} m4ri_amd_shard_piece;
+enum { M4RI_AMD_SHARD_BUF_LOCAL_A = 0, M4RI_AMD_SHARD_BUF_LOCAL_B, M4RI_AMD_SHARD_BUF_LOCAL_C, /* local parents (stride L/64, N/64, N/64) */
+       M4RI_AMD_SHARD_BUF_CHILD_A, M4RI_AMD_SHARD_BUF_CHILD_B, M4RI_AMD_SHARD_BUF_SLABS_P,      /* nprod slabs each, back to back         */
+       M4RI_AMD_SHARD_BUF_OPER_A, M4RI_AMD_SHARD_BUF_OPER_B, M4RI_AMD_SHARD_BUF_PROD };         /* whole operands/results of owned j's    */
+/* Pure host arithmetic (no GPU needed).  levels: 1, 2 or 0 = automatic.  0 on success. */
+int m4ri_amd_shard_plan_make(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n, int levels);
+int64_t m4ri_amd_shard_cut(int64_t rows, int world, int r);
+int m4ri_amd_shard_owner(const m4ri_amd_shard_plan *p, int j);             /* rank that multiplies sub-product j */
+int64_t m4ri_amd_shard_slab_rows(const m4ri_amd_shard_plan *p, int rank, int which); /* 0: of A/C/products, 1: of B */
+int64_t m4ri_amd_shard_buffer_words(const m4ri_amd_shard_plan *p, int rank, int which);
+int m4ri_amd_shard_piece_of(const m4ri_amd_shard_plan *p, int side, int j, int r, m4ri_amd_shard_piece *out);
+/* Per-rank device steps (asynchronous on `stream`; one process per GPU moves the pieces itself, e.g. with
+ * RCCL send/recv): local parents -> slabs of all children; slabs of all products -> local parent of C.
+ * The sub-products themselves are plain m4ri_amd_mul_dev calls of bm x bl x (64*cwn). */
+int m4ri_amd_shard_down_dev(const m4ri_amd_shard_plan *p, int rank, const word *A_local, int64_t a_stride, const word *B_local,
+                            int64_t b_stride, word *child_a, word *child_b, void *stream);
+int m4ri_amd_shard_up_dev(const m4ri_amd_shard_plan *p, int rank, const word *slabs_p, word *C_local, int64_t c_stride, int add,
+                          void *stream);
+/* Rows [row0, row0 + rows) of the matrix m4ri_amd_fill_dev(seed) would fill, written to M (for filling
+ * local parents of a distributed matrix without materialising the whole). */
+int m4ri_amd_fill_rows_dev(word *M, int64_t stride, int64_t row0, int64_t rows, int64_t ncols, uint64_t seed, void *stream);
+/* One process, several devices, host matrices: C (+)= A*B with every device uploading / downloading its
+ * own slabs and pieces moving by peer copies.  levels as above.  Returns 0 or a hipError_t value. */
+int m4ri_amd_mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int add, int cutoff, int levels);
+/* The devices mzd_mul_mp / m4ri_amd_mul_multi spread a product over.  Default: the comma-separated list in
+ * the environment variable M4RI_AMD_DEVICES, else every visible device.  An id may repeat (several ranks
+ * on one GPU: how the tests exercise the path on a one-GPU box).  n == 0 restores the default. */
+int m4ri_amd_set_devices(int n, const int *ids);
+int m4ri_amd_get_device_list(int *ids, int cap);
+/* Smallest min(m, l, n) that mzd_mul_mp / mzd_addmul_mp spread over several devices (default 16384);
+ * returns the previous value, negative arguments only query. */
+int64_t m4ri_amd_set_multi_threshold(int64_t min_dim);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SYMBOLS = {
     "mzd_addmul_mp": _MULSIG,
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
     "m4ri_amd_mzd_free": (None, [MzdPtr]),
+    "m4ri_amd_result_free": (None, [MzdPtr]),
     "m4ri_amd_init": (_I, [_I]),
     "m4ri_amd_device_count": (_I, []),
     "m4ri_amd_mul_dev": _DEVSIG,
@@ -104,7 +105,7 @@ def _p(m: Mzd | None):
 def _ret(C: Mzd | None, r) -> Mzd:
     if C is not None:
         return C
-    return from_struct_ptr(r, lib().m4ri_amd_mzd_free)
+    return from_struct_ptr(r, lib().m4ri_amd_result_free)
 
 
 # ---- M4RI-named host entry points ---------------------------------------------------------------

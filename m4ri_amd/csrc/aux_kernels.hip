@@ -184,11 +184,12 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up2_kernel(
   }
 }
 
-// C = A ^ B (whole words) on strided views; op 1: C = A (copy); op 2: C = 0
-__global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *__restrict__ C, int64_t cs,
-                                                              const word *__restrict__ A, int64_t as,
-                                                              const word *__restrict__ B, int64_t bs,
-                                                              int64_t rows, int64_t w, int op) {
+// C = A ^ B (whole words) on strided views; op 1: C = A (copy); op 2: C = 0.  The last word of a row
+// is merged under `mask` (bits outside it keep C's value, mzd.c:1489); mask == ~0 writes whole words.
+// C may alias A and/or B (no __restrict__).
+__global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *C, int64_t cs, const word *A, int64_t as,
+                                                              const word *B, int64_t bs,
+                                                              int64_t rows, int64_t w, int op, word mask) {
   const int64_t total  = rows * w;
   const int64_t stride = (int64_t)gridDim.x * AUX_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += stride) {
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(AUX_THREADS) void rowwise_kernel(word *__restrict__
     word v = 0;
     if (op == 0) v = A[r * as + k] ^ B[r * bs + k];
     else if (op == 1) v = A[r * as + k];
-    C[r * cs + k] = v;
+    word *c = C + r * cs + k;
+    if (k == w - 1 && mask != ~(word)0) v = (*c & ~mask) | (v & mask);
+    *c = v;
   }
 }
 
@@ -275,12 +278,12 @@ __global__ __launch_bounds__(AUX_THREADS) void mask_tail_kernel(word *__restrict
 // generator, so device and host fills (m4ri_amd/mzd.py fill_splitmix) are bit-identical.
 __global__ __launch_bounds__(AUX_THREADS) void fill_splitmix_kernel(word *__restrict__ M, int64_t stride,
                                                                     int64_t rows, int64_t w, word mask,
-                                                                    uint64_t seed) {
+                                                                    uint64_t seed, int64_t first) {
   const int64_t total  = rows * w;
   const int64_t gstr   = (int64_t)gridDim.x * AUX_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * AUX_THREADS + threadIdx.x; i < total; i += gstr) {
     const int64_t r = i / w, j = i - r * w;
-    uint64_t z = seed + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+    uint64_t z = seed + (uint64_t)(first + i + 1) * 0x9E3779B97F4A7C15ull;  // first = row0 * w: rows of a larger matrix
     z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
@@ -364,7 +367,18 @@ extern "C" hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word 
 extern "C" hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A,
                                          int64_t as, const word *B, int64_t bs, int64_t rows, int64_t w) {
   if (rows * w == 0) return hipSuccess;
-  hipLaunchKernelGGL(rowwise_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, B, bs, rows, w, op);
+  hipLaunchKernelGGL(rowwise_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, B, bs, rows, w, op, ~(word)0);
+  return hipGetLastError();
+}
+
+// C = A ^ B on rows x ncols BITS with _mzd_add's edge rule (mzd.c:1471-1583, :1489): the last word of
+// every row is written under the column mask, the other bits of C's last word are kept
+extern "C" hipError_t gf2_launch_xor_masked(hipStream_t s, word *C, int64_t cs, const word *A, int64_t as, const word *B,
+                                            int64_t bs, int64_t rows, int64_t ncols) {
+  if (rows <= 0 || ncols <= 0) return hipSuccess;
+  const int64_t w = words_of(ncols);
+  const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
+  hipLaunchKernelGGL(rowwise_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, C, cs, A, as, B, bs, rows, w, 0, mask);
   return hipGetLastError();
 }
 
@@ -407,13 +421,18 @@ extern "C" hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t strid
   return hipGetLastError();
 }
 
-extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int64_t rows,
-                                               int64_t ncols, uint64_t seed) {
+extern "C" hipError_t gf2_launch_fill_splitmix_rows(hipStream_t s, word *M, int64_t stride, int64_t row0, int64_t rows,
+                                                    int64_t ncols, uint64_t seed) {
   if (rows == 0 || ncols == 0) return hipSuccess;
   const int64_t w = words_of(ncols);
   const word mask = (ncols % 64) ? ((~(word)0) >> (64 - ncols % 64)) : ~(word)0;
-  hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, M, stride, rows, w, mask, seed);
+  hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid_for(rows * w)), dim3(AUX_THREADS), 0, s, M, stride, rows, w, mask, seed, row0 * w);
   return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int64_t rows,
+                                               int64_t ncols, uint64_t seed) {
+  return gf2_launch_fill_splitmix_rows(s, M, stride, 0, rows, ncols, seed);
 }
 
 // ---- two levels down on the A side, written straight into the leaf's packed form ------------------

@@ -60,8 +60,11 @@ hipError_t gf2_launch_zero_tiles(hipStream_t s, word *C, int64_t cs, int64_t cbs
                                  int64_t tiles_m, int64_t tiles_n, int64_t tile_base, int64_t ntiles);
 hipError_t gf2_launch_rowwise(hipStream_t s, int op, word *C, int64_t cs, const word *A, int64_t as,
                               const word *B, int64_t bs, int64_t rows, int64_t w);
+hipError_t gf2_launch_xor_masked(hipStream_t s, word *C, int64_t cs, const word *A, int64_t as, const word *B, int64_t bs,
+                                 int64_t rows, int64_t ncols);
 hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols);
 hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed);
+hipError_t gf2_launch_fill_splitmix_rows(hipStream_t s, word *M, int64_t stride, int64_t row0, int64_t rows, int64_t ncols, uint64_t seed);
 }
 
 namespace {
@@ -319,18 +322,20 @@ int launch_leaf(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs, con
                 bool add, int ksplit_req, bool a_prepacked = false) {
   constexpr uint64_t LIMIT = (1ull << 32) - (1ull << 20);
   if (batch == 1 && !a_prepacked) {
-    if ((uint64_t)m * (uint64_t)as * 8 >= LIMIT && m > 4096) {  // rows of A and C: multiples of a tile
-      int64_t m1 = (int64_t)(LIMIT / ((uint64_t)as * 8)) / 4096 * 4096;
-      if (m1 < 4096) m1 = 4096;
+    if ((uint64_t)m * (uint64_t)as * 8 >= LIMIT && m > 1) {  // rows of A and C: whole tiles when the stride allows
+      int64_t m1 = (int64_t)(LIMIT / ((uint64_t)as * 8));     // (a window of a very wide parent may allow fewer)
+      m1 = m1 >= 4096 ? m1 / 4096 * 4096 : m1 >= 32 ? m1 / 32 * 32 : m1;
+      if (m1 < 1) return (int)hipErrorInvalidValue;  // one row of A beyond 4 GiB
       for (int64_t r0 = 0; r0 < m; r0 += m1) {
         const int64_t mr = (m - r0) < m1 ? (m - r0) : m1;
         if (int rc = launch_leaf(e, st, C + r0 * cs, cs, 0, A + r0 * as, as, 0, B, bs, 0, mr, l, n, 1, add, ksplit_req)) return rc;
       }
       return 0;
     }
-    if ((uint64_t)l * (uint64_t)bs * 8 >= LIMIT && l > 4096) {  // inner dimension: word-aligned slabs, later ones accumulate
-      int64_t l1 = (int64_t)(LIMIT / ((uint64_t)bs * 8)) / 4096 * 4096;
-      if (l1 < 4096) l1 = 4096;
+    if ((uint64_t)l * (uint64_t)bs * 8 >= LIMIT && l > 64) {  // inner dimension: word-aligned slabs, later ones accumulate
+      int64_t l1 = (int64_t)(LIMIT / ((uint64_t)bs * 8));
+      l1 = l1 >= 4096 ? l1 / 4096 * 4096 : l1 / 64 * 64;
+      if (l1 < 64) return (int)hipErrorInvalidValue;  // 64 rows of B beyond 4 GiB
       for (int64_t k0 = 0; k0 < l; k0 += l1) {
         const int64_t lk = (l - k0) < l1 ? (l - k0) : l1;
         if (int rc = launch_leaf(e, st, C, cs, 0, A + k0 / 64, as, 0, B + k0 * bs, bs, 0, m, lk, n, 1, add || k0 > 0, ksplit_req)) return rc;
@@ -679,11 +684,15 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
 
 int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t rows, int64_t ncols, void *stream) {
-  return (int)gf2_launch_rowwise((hipStream_t)stream, 0, C, c_stride, A, a_stride, B, b_stride, rows, words_of(ncols));
+  return (int)gf2_launch_xor_masked((hipStream_t)stream, C, c_stride, A, a_stride, B, b_stride, rows, ncols);
 }
 
 int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed, void *stream) {
   return (int)gf2_launch_fill_splitmix((hipStream_t)stream, M, stride, rows, ncols, seed);
+}
+
+int m4ri_amd_fill_rows_dev(word *M, int64_t stride, int64_t row0, int64_t rows, int64_t ncols, uint64_t seed, void *stream) {
+  return (int)gf2_launch_fill_splitmix_rows((hipStream_t)stream, M, stride, row0, rows, ncols, seed);
 }
 
 int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, void *stream) {
@@ -737,9 +746,11 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out) {
 }
 
 void gf2_release_staging(void);  // mzd_api.hip: the host entry points' staging arena
+void gf2_release_multi(void);    // multi.hip: the per-rank arenas of the multi-device path
 
 void m4ri_amd_release_workspace(void) {
   gf2_release_staging();
+  gf2_release_multi();
   std::lock_guard<std::mutex> lk(g_mu);
   Engine *e = engine_for_current_device();
   if (!e || !e->ws) return;

@@ -76,9 +76,17 @@ struct Arena {
   word *base  = nullptr;
   size_t cap  = 0;  // words
   size_t used = 0;
-} g_arena;
+};
+constexpr int ARENA_DEVICES = 16;
+Arena g_arenas[ARENA_DEVICES];  // one per HIP device: run() works on whatever device is current
+int g_arena_dev = 0;
+#define g_arena g_arenas[g_arena_dev]
 
 void arena_reserve(size_t words) {
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  if (dev < 0 || dev >= ARENA_DEVICES) die("m4ri_amd: HIP device %d out of range\n", dev);
+  g_arena_dev = dev;
   g_arena.used = 0;
   if (words <= g_arena.cap) return;
   HIPDIE(hipDeviceSynchronize());
@@ -153,6 +161,7 @@ struct Pin {
   word *dbase;
   bool dev_newer;
   mzd_t *owner;
+  int device;  // HIP device the copy lives on
 };
 std::vector<Pin> g_pins;
 
@@ -169,6 +178,9 @@ DevMat operand(const mzd_t *M, bool copy, Pin **pin_out = nullptr) {
   Pin *p = find_pin(M);
   if (pin_out) *pin_out = p;
   if (p) {
+    int dev = 0;
+    HIPDIE(hipGetDevice(&dev));
+    if (p->device != dev) die("m4ri_amd: matrix pinned on device %d used while device %d is current\n", p->device, dev);
     d.p      = p->dbase + (M->data - p->hbase);
     d.stride = p->rowstride;
     return d;
@@ -222,7 +234,9 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
     HIPDIE(m4ri_amd_m4rm_dev(dC.p, dC.stride, dA.p, dA.stride, dB.p, dB.stride, A->nrows, A->ncols, B->ncols, add, 0, nullptr));
   // a B that is a window of a pinned parent carries its neighbours' bits in the last word, and they
   // land in C's excess columns: clear them before the result leaves the staging buffer
-  if (c_staged) HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, C->nrows, C->ncols, nullptr));
+  // (an unstaged pinned C spans its parent's full width, so its excess bits must be zero anyway:
+  // mzd.h:115-121 -- mask there as well, or sync/unpin would carry the neighbours' bits to the host)
+  if (c_staged || C->ncols % 64 != 0) HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, C->nrows, C->ncols, nullptr));
   if (pinC) {
     if (c_staged) {
       const DevMat dst = operand(C, false);
@@ -332,24 +346,44 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
   return run(C, A, B, clear == 0, false, 0);
 }
 
-void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace
+void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena
   std::lock_guard<std::mutex> lk(g_api_mu);
-  if (!g_arena.base) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) return;
+  Arena &a = g_arenas[dev];
+  if (!a.base) return;
   (void)hipDeviceSynchronize();
-  (void)hipFree(g_arena.base);
-  g_arena = Arena{};
+  (void)hipFree(a.base);
+  a = Arena{};
+}
+
+// Free a result the entry points allocated for C == NULL with the allocator it came from: the host
+// program's mzd_free when result_init used its mzd_init (libm4ri's blocks come from its own caches,
+// free() on them corrupts the heap), m4ri_amd_mzd_free otherwise.
+void m4ri_amd_result_free(mzd_t *A) {
+  typedef void (*free_fn)(mzd_t *);
+  static free_fn host_free = dlsym(RTLD_DEFAULT, "mzd_init") ? reinterpret_cast<free_fn>(dlsym(RTLD_DEFAULT, "mzd_free")) : nullptr;
+  if (host_free) host_free(A);
+  else m4ri_amd_mzd_free(A);
 }
 
 // ---- part 3: residency ----------------------------------------------------------------------------
 int m4ri_amd_pin(mzd_t *M) {
   std::lock_guard<std::mutex> lk(g_api_mu);
   if (!M || (M->flags & FLAG_WINDOW)) return -1;  // pin the owner of the block; windows into it follow
-  if (find_pin(M)) return 0;
+  if (Pin *old = find_pin(M)) {
+    if (old->owner == M && old->hbase == M->data && old->nrows == M->nrows && old->ncols == M->ncols) return 0;
+    // a matrix freed without unpin left this entry behind and the allocator reused its address: the
+    // device copy belongs to a dead matrix -- drop it (without a download) and pin M afresh
+    (void)hipFree(old->dbase);
+    g_pins.erase(g_pins.begin() + (old - g_pins.data()));
+  }
   if (M->nrows == 0 || M->ncols == 0 || !M->data) return -1;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
   Pin p{};
+  p.device = dev;
   p.hbase = M->data; p.words = (size_t)M->nrows * (size_t)M->rowstride; p.rowstride = M->rowstride;
   p.nrows = M->nrows; p.ncols = M->ncols; p.owner = M;
   HIPDIE(hipMalloc(reinterpret_cast<void **>(&p.dbase), p.words * 8));
@@ -390,7 +424,27 @@ int m4ri_amd_is_pinned(const mzd_t *M) {
   return p ? (p->dev_newer ? 2 : 1) : 0;
 }
 
-mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mzd_mul(C, A, B, cutoff); }        // mp.c:277-297
-mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mzd_addmul(C, A, B, cutoff); }  // mp.c:299-324
+int gf2_multi_wanted(int64_t m, int64_t l, int64_t n);  // multi.hip
+
+// mp.c:277-297 / :299-324.  Several devices + a product large enough: the top Strassen-Winograd
+// sub-products go over the devices (multi.hip); else the single-GPU schedule.
+static mzd_t *mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff, bool add, const char *who) {
+  if (A->ncols != B->nrows) die("%s: A ncols (%d) need to match B nrows (%d).\n", who, A->ncols, B->nrows);
+  cutoff = norm_cutoff(cutoff, who);
+  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != B->ncols)
+    die("%s: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", who, C->nrows, C->ncols, A->nrows, B->ncols);
+  if (add && (A->nrows == 0 || A->ncols == 0 || B->ncols == 0)) return C;
+  bool pinned;
+  { std::lock_guard<std::mutex> lk(g_api_mu); pinned = find_pin(A) || find_pin(B) || find_pin(C); }
+  if (!pinned && gf2_multi_wanted(A->nrows, A->ncols, B->ncols)) {
+    const int rc = m4ri_amd_mul_multi(C, A, B, add ? 1 : 0, cutoff, 0);
+    if (rc) die("m4ri_amd: multi-device product failed (hipError_t %d: %s)\n", rc, hipGetErrorString((hipError_t)rc));
+    return C;
+  }
+  return run(C, A, B, add, true, cutoff);
+}
+mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mul_mp(C, A, B, cutoff, false, "mzd_mul_mp"); }
+mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) { return mul_mp(C, A, B, cutoff, true, "mzd_addmul_mp"); }
 
 }  // extern "C"

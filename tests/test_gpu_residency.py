@@ -127,3 +127,42 @@ def test_randomized_chain_on_pinned_parents(oracle):
     for M, H in zip(dev, host):
         m4ri_amd.unpin(M)
         assert np.array_equal(M.buf, H.buf)
+
+
+def test_full_width_ragged_pinned_result_keeps_zero_excess(oracle):
+    """B is a ragged window of a WIDER pinned parent (its last word carries the neighbouring columns), C a
+    pinned non-window matrix with ncols % 64 != 0: the engine writes C in place, and the excess bits of a
+    non-window matrix must be zero afterwards (mzd.h:115-121) -- on the device copy and after sync."""
+    m, l, n, wide = 300, 257, 131, 400
+    A = Mzd.random(m, l, 21)
+    PB = Mzd.random(l, wide, 22)
+    Bw = PB.window(0, 0, l, n)                # columns 131..399 of the parent are B's "excess"
+    C = Mzd.init(m, n)
+    want = oracle.mul(None, A, Bw.copy(), 0)
+    for M in (A, PB, C):
+        m4ri_amd.pin(M)
+    m4ri_amd.mzd_mul(C, A, Bw, 0)
+    m4ri_amd.sync(C)
+    assert C.equal(want)
+    assert not (C.valid_words()[:, -1] & ~np.uint64(C.high_bitmask)).any(), "excess bits of a non-window result must be 0"
+    # accumulate through the same path, then a host-side word-wise consumer sees clean words
+    want2 = oracle.addmul(want.copy(), A, Bw.copy(), 0)
+    m4ri_amd.mzd_addmul(C, A, Bw, 0)
+    m4ri_amd.unpin(C)
+    assert np.array_equal(C.valid_words(), want2.masked())
+    m4ri_amd.unpin(A)
+    m4ri_amd.unpin(PB)
+
+
+def test_repinning_a_reused_address_uploads_again(oracle):
+    """A matrix dropped without unpin leaves a registry entry; a new matrix at the same address must not
+    be served from the dead device copy (m4ri_amd_pin detects the stale entry)."""
+    A = Mzd.random(200, 300, 31)
+    B = Mzd.random(300, 260, 32)
+    m4ri_amd.pin(A)
+    A2 = Mzd(200, 300, buf=A.buf)             # same host block, another descriptor ("freed and reallocated")
+    A2.fill_splitmix(33)
+    m4ri_amd.pin(A2)
+    want = oracle.mul(None, A2, B, 0)
+    assert m4ri_amd.mzd_mul(None, A2, B, 0).equal(want)
+    m4ri_amd.unpin(A2)

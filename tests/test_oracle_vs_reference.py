@@ -122,3 +122,40 @@ def test_fill_and_fingerprint_agree(oracle):
         oracle.fill(b, 99)
         assert np.array_equal(a.buf, b.buf)
         assert a.fingerprint() == oracle.fingerprint(b)
+
+
+def test_fill_matches_reference_randomize_custom(oracle, reference):
+    """Mzd.random / gf2o_fill_splitmix / the device fill all claim the fill order of the reference's
+    mzd_randomize_custom (mzd.c:1282-1292: `width` callback words per row, row-major, the last one
+    merged under the column mask).  Pin that claim against the reference itself, driven by a splitmix64
+    callback -- plain matrices, and windows inside a pattern-filled parent (widths of
+    tests/test_random.c:33-62: n + {1, 2, 32, 50, 51, 52, 63, 64, 65})."""
+    import ctypes
+    from m4ri_amd.mzd import MzdPtr, splitmix_words
+    CB = ctypes.CFUNCTYPE(ctypes.c_uint64, ctypes.c_void_p)
+    fn = reference.L.mzd_randomize_custom
+    fn.restype, fn.argtypes = None, [MzdPtr, CB, ctypes.c_void_p]
+
+    def ref_fill(M, seed):
+        state = {"i": 0}
+
+        def next_word(_):
+            w = int(splitmix_words(seed, state["i"], 1)[0])
+            state["i"] += 1
+            return w
+        cb = CB(next_word)
+        fn(M.ptr, cb, None)
+
+    for base in (0, 64, 128):
+        for extra in (1, 2, 32, 50, 51, 52, 63, 64, 65):
+            c = base + extra
+            a = Mzd.random(7, c, 1234 + c)
+            b = Mzd.init(7, c)
+            ref_fill(b, 1234 + c)
+            assert np.array_equal(a.buf, b.buf), (7, c)
+            # window with non-zero excess: the parent's bits outside the window survive
+            P1, P2 = Mzd.random(9, c + 130, 77), Mzd.random(9, c + 130, 77)
+            w1, w2 = P1.window(1, 64, 8, 64 + c), P2.window(1, 64, 8, 64 + c)
+            w1.fill_splitmix(5)
+            ref_fill(w2, 5)
+            assert np.array_equal(P1.buf, P2.buf), ("window", c)
