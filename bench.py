@@ -4,28 +4,47 @@
     GF(2) n^3-equivalent bit-ops/s and wall-clock of one n x n x n mzd_mul, n = 65536,
     at 1/2/4/8 GPUs (strong scaling: the total work is fixed).
 
-A "step" is one whole product C = A*B on device-resident, synthetic (splitmix64, density 1/2)
-operands: Strassen-Winograd levels over batched M4RM leaves, everything through libm4ri_amd.so's
-C ABI.  Inputs are in HBM before the timed region starts; C stays in HBM (distributed over the ranks
-that own its blocks when N > 1).
+A "step" is one whole product C = A*B on device-resident, synthetic (splitmix64, density 1/2) operands,
+everything through libm4ri_amd.so's C ABI.  Inputs are in HBM before the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 65536] [--workload mul|leaf16384]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 65536] [--workload mul|leaf16384|rect131072]
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL); the product is
-decomposed by m4ri_amd/sharding.py (block products, one pairwise XOR exchange at N = 8).
+N = 1: Strassen-Winograd levels over batched M4RM leaves on one GPU (m4ri_amd_mul_dev).
+
+N > 1 (one process per GPU, torch.distributed.run, RCCL):
+  --variant strassen (default): the sub-products of the top Strassen-Winograd level(s) are spread over the
+      ranks (m4ri_amd/csrc/multi.hip, m4ri_amd/sharding.py).  A, B and C are distributed slab-cyclically
+      (rank r holds rows [cut(r), cut(r+1)) of every row block): every rank runs the level's additions on
+      its own slabs, slabs of sub-product operands travel rank -> owner and slabs of products back, each as
+      one RCCL send/recv on the direct xGMI link of its pair, all posted as one batch per phase.
+      --layout distributed (default): the slabs ARE where the inputs live when the timed region starts and
+          where C is left (the layout products chain in);
+      --layout owner: A and B live on rank 0 and C is gathered there: scatter and gather are inside the
+          timed region (bounded by rank 0's seven links: documented in DESIGN.md 7).
+  --variant blocks: the reference's own template (_mzd_mul_mp4, m4ri/mp.c:158-275): a grid of blocks of C,
+      optionally the inner dimension split with ONE pairwise XOR exchange (--grid 2,2,2); blocks of A and B
+      are scattered from rank 0 and the reduced blocks of C gathered there (owner layout only).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  "roofline"     the dominant kernel (the M4RM leaf launch) against the HBM roofline, duration
-                 measured with HIP events on the launch stream inside the timed region;
-  "cpu_baseline" the real reference M4RI (oracle/_ref, built from /root/reference) timed on this
-                 host's cores on a bounded sample of the same workload (N = 1 only).
+  "roofline"     the dominant kernel (the M4RM leaf launch) against the HBM roofline: duration = mean over ALL
+                 timed steps of HIP events around that launch on its stream; "traffic" = HBM bytes per launch
+                 from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) this script runs on itself (N = 1);
+  "cpu_baseline" the real reference M4RI (oracle/_ref, built from /root/reference) timed on this host's
+                 cores: mzd_mul_mp at the workload's own size, and the reference's bench_multiplication
+                 4096^3 timed region (BASELINE.json configs[0]);
+  "verified"     SHA-256 of the C the timed steps produced against the reference's (tests/golden).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,50 +59,101 @@ from m4ri_amd import sharding  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(n_workload: int):
-    """Reference M4RI on the host cores, bounded sample: mzd_mul at n = 8192 and 16384 (sequential
-    build) and mzd_mul_mp (OpenMP build, all cores) -- about 15-25 s of CPU work."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself on this host's cores
+# ---------------------------------------------------------------------------------------------------
+def sysfs_cache_sizes():
+    """L1/L2/L3 the way the reference's configure reads them (m4/ax_cache_size.m4:46-58): for index 0..3 of
+    cpu0, L<level> = size (a later index of the same level overwrites an earlier one)."""
+    out = {}
+    for idx in range(4):
+        base = f"/sys/devices/system/cpu/cpu0/cache/index{idx}"
+        try:
+            level = int(open(base + "/level").read())
+            size = open(base + "/size").read().strip()
+        except OSError:
+            continue
+        mult = {"K": 1024, "M": 1 << 20, "G": 1 << 30}.get(size[-1].upper(), 1)
+        out[level] = int(size.rstrip("KMGkmg")) * mult
+    return out.get(1), out.get(2), out.get(3)
+
+
+def cpu_baseline(n_workload: int, budget_s: float = 75.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
     import cpu_libs
-    from m4ri_amd.mzd import Mzd
+    from m4ri_amd.mzd import Mzd, MzdPtr, from_struct_ptr
     ncpu = os.cpu_count() or 1
-    ref = cpu_libs.reference()
+    l1, l2, l3 = sysfs_cache_sizes()
+    tag = f"_c{l1}_{l2}_{l3}" if l1 and l2 and l3 else ""
+    ref = cpu_libs.reference(tag=tag) or cpu_libs.reference()
+    matched = cpu_libs.reference(tag=tag) is not None and bool(tag)
+    cache_note = (f"cache macros = this host's sysfs values L1/L2/L3 = {l1}/{l2}/{l3}" if matched else
+                  f"cache macros 32768/2097152/33554432 (no build for this host's sysfs values {l1}/{l2}/{l3} in oracle/_ref)")
     if ref is None:
-        # no reference binary on this box: time our own plain-C restatement instead
-        orc = cpu_libs.oracle()
+        orc = cpu_libs.oracle()  # no reference binary on this box: time our own plain-C restatement instead
         n = 4096
         A, B = Mzd.random(n, n, 3), Mzd.random(n, n, 4)
         t = time.perf_counter()
         orc.mul(None, A, B, 0)
         dt = time.perf_counter() - t
-        return {"value": n ** 3 / dt, "unit": "bit-op/s", "cores": 1, "kind": "port",
-                "sample": f"oracle gf2o_mul {n}^3, 1 run, {dt:.2f} s"}
+        return {"value": n ** 3 / dt, "unit": "bit-op/s", "cores": 1, "kind": "port", "sample": f"oracle gf2o_mul {n}^3, 1 run, {dt:.2f} s"}
+    out = {"unit": "bit-op/s", "kind": "reference", "cache": cache_note}
+    # (1) BASELINE.json configs[0]: bench_multiplication 4096 4096 4096 -- srandom(17), mzd_randomize'd A and B,
+    #     timed region = mzd_mul(NULL, A, B, 0) including the allocation of C (bench/bench_multiplication.c:86-107)
+    libc = ctypes.CDLL(None)
+    libc.srandom(17)
+    rnd = ref.L.mzd_randomize
+    rnd.restype, rnd.argtypes = None, [MzdPtr]
+    A1, B1 = Mzd.init(4096, 4096), Mzd.init(4096, 4096)
+    rnd(A1.ptr)
+    rnd(B1.ptr)
+    ts = []
+    for _ in range(12):
+        t = time.perf_counter()
+        r = ref.L.mzd_mul(None, A1.ptr, B1.ptr, 0)
+        ts.append(time.perf_counter() - t)
+        ref.L.mzd_free(r)
+    ts = ts[2:]
+    out["config1"] = {"what": "bench_multiplication 4096 4096 4096: mzd_mul(NULL,A,B,0) incl. allocating C, srandom(17) + mzd_randomize inputs, "
+                              "sequential SSE2 build, 10 samples after 2 warm-ups",
+                      "seconds_mean": sum(ts) / len(ts), "seconds_min": min(ts), "bitops_per_sec": 4096 ** 3 / (sum(ts) / len(ts)), "cores": 1}
+    # (2) the workload itself on all cores: mzd_mul_mp (OpenMP build), once, if a 16384^3 probe says it fits the budget
+    omp = cpu_libs.reference(openmp=True, tag=tag) or cpu_libs.reference(openmp=True)
     n = 16384
     A, B = Mzd.random(n, n, 3), Mzd.random(n, n, 4)
-    best_seq = 1e30
-    for _ in range(2):
-        t = time.perf_counter()
-        ref.mul(None, A, B, 0)
-        best_seq = min(best_seq, time.perf_counter() - t)
-    out = {"value": n ** 3 / best_seq, "unit": "bit-op/s", "cores": 1, "kind": "reference",
-           "sample": f"reference mzd_mul(NULL,A,B,0) {n}^3 (1/{(n_workload // n) ** 3} of the workload's n^3), "
-                     f"sequential SSE2 build, best of 2: {best_seq:.2f} s"}
-    omp = cpu_libs.reference(openmp=True)
+    t = time.perf_counter()
+    ref.mul(None, A, B, 0)
+    t_seq = time.perf_counter() - t
+    out["sequential"] = {"value": n ** 3 / t_seq, "cores": 1, "sample": f"mzd_mul {n}^3, sequential build, 1 run: {t_seq:.2f} s"}
+    out.update({"value": n ** 3 / t_seq, "cores": 1, "sample": out["sequential"]["sample"]})
     if omp is not None and omp.has_mp:
         os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
-        best_mp = 1e30
+        best = 1e30
         for _ in range(2):
             t = time.perf_counter()
             omp.mul_mp(None, A, B, 0)
-            best_mp = min(best_mp, time.perf_counter() - t)
-        out["openmp"] = {"value": n ** 3 / best_mp, "cores": ncpu,
-                         "sample": f"reference mzd_mul_mp {n}^3, OpenMP build, OMP_NUM_THREADS={ncpu}, best of 2: {best_mp:.2f} s"}
-        if n ** 3 / best_mp > out["value"]:
-            out["value"], out["cores"] = n ** 3 / best_mp, ncpu
-            out["sample"] += f"; headline value = mzd_mul_mp on {ncpu} threads ({best_mp:.2f} s)"
+            best = min(best, time.perf_counter() - t)
+        out["openmp_16384"] = {"value": n ** 3 / best, "cores": ncpu, "sample": f"mzd_mul_mp {n}^3, OpenMP build, {ncpu} threads, best of 2: {best:.2f} s"}
+        out.update({"value": n ** 3 / best, "cores": ncpu, "sample": out["openmp_16384"]["sample"]})
+        predicted = best * (n_workload / n) ** 2.807
+        if n_workload > n and predicted <= budget_s:
+            del A, B
+            A, B = Mzd.random(n_workload, n_workload, 3), Mzd.random(n_workload, n_workload, 4)
+            t = time.perf_counter()
+            omp.mul_mp(None, A, B, 0)
+            dt = time.perf_counter() - t
+            out.update({"value": n_workload ** 3 / dt, "cores": ncpu,
+                        "sample": f"the workload itself: reference mzd_mul_mp {n_workload}^3 (same splitmix64 inputs), OpenMP build, "
+                                  f"OMP_NUM_THREADS={ncpu}, 1 run: {dt:.2f} s"})
+        elif n_workload > n:
+            out["sample"] += f"; the {n_workload}^3 run was skipped (predicted {predicted:.0f} s > budget {budget_s:.0f} s)"
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# models and measurements around the number
+# ---------------------------------------------------------------------------------------------------
 LEAF_KERNELS = {1: "m4rm_leaf_kernel", 2: "m4rm7_kernel", 3: "m4rm8_kernel", 4: "m4rm8q_kernel"}
 # (tile rows, tile columns, inner bits per stage, LDS-array clocks per stage): gathers at 256 B/clk/CU
 # + table writes at 128 B/clk/CU, both measured with tools/ubench.hip (DESIGN.md 3.1)
@@ -107,7 +177,6 @@ def lds_model(gen, m, l, n, products, launch_ms):
 def measured_copy_gbs():
     """On-box HBM copy rate (GB/s, read + write bytes) of a 1 GiB device-to-device copy: the practical
     peak SURVEY.md 8(d) asks to report beside the vendor 8 TB/s."""
-    import torch
     src = torch.empty(1 << 27, dtype=torch.int64, device="cuda")
     dst = torch.empty_like(src)
     dst.copy_(src)
@@ -122,16 +191,41 @@ def measured_copy_gbs():
     return 2.0 * src.numel() * 8 / (best * 1e-3) / 1e9
 
 
-def leaf_traffic(n, world):
-    """HBM bytes of one leaf launch from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-    correction + WRITE_SIZE, MI355X_MICROARCH.md HBM section) -- counters cannot be read from inside
-    this process, so the number is the one tools/prof_bench.sh measured for this exact command
-    (profiles/leaf_traffic.json); null for any other configuration."""
-    p = os.path.join(ROOT, "profiles", "leaf_traffic.json")
-    if world != 1 or not os.path.exists(p):
-        return None
-    d = json.load(open(p))
-    return d.get("bytes_per_launch") if d.get("n") == n else None
+def measure_leaf_traffic(argv_size, cutoff, timeout_s=240):
+    """HBM bytes of ONE leaf launch of this workload from rocprofv3 PMC passes run right now, on this box,
+    over this script in probe mode (one warm-up + one product): FETCH_SIZE and WRITE_SIZE in separate
+    passes (they do not fit one), per-dispatch sums over all instances, bytes = (2*FETCH_SIZE + WRITE_SIZE)
+    * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read
+    stream), WRITE_SIZE as reported.  None (with the reason) when rocprofv3 is unavailable or fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="m4ri_amd_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--probe", "--size", str(argv_size),
+               "--cutoff", str(cutoff)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("results.db")]
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            db = sqlite3.connect(dbs[0])
+            names = dict(db.execute("select id, kernel_name from rocpd_info_kernel_symbol"))
+            ev2k = {ev: names.get(kid, "") for kid, ev in db.execute("select kernel_id, event_id from rocpd_kernel_dispatch")}
+            pmc = {pid: nm for pid, nm in db.execute("select id, name from rocpd_info_pmc")}
+            per_dispatch = {}
+            for ev, pid, val in db.execute("select event_id, pmc_id, value from rocpd_pmc_event"):
+                if pmc.get(pid) == counter and "m4rm" in ev2k.get(ev, ""):
+                    per_dispatch[ev] = per_dispatch.get(ev, 0.0) + val
+            if not per_dispatch:
+                return None, f"no {counter} rows for a leaf kernel"
+            vals[counter] = max(per_dispatch.values())  # the batched leaf launch (strips, if any, are smaller)
+        except Exception as e:  # noqa: BLE001
+            return None, f"{counter}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"]}
 
 
 def bytes_sched(m, l, n, levels):
@@ -140,7 +234,7 @@ def bytes_sched(m, l, n, levels):
     moves 8*(m*W(l) + l*W(n) + m*W(n)) bytes, a quadrant addition of r x c bits 3*8*r*W(c); per level 7
     products + 15 additions (4 on A-quadrant shape, 4 on B-quadrant shape, 7 on C-quadrant shape,
     strassen.c:111-150)."""
-    W = lambda x: (x + 63) // 64
+    W = lambda x: (x + 63) // 64  # noqa: E731
     if levels == 0:
         return 8 * (m * W(l) + l * W(n) + m * W(n))
     hm, hl, hn = m // 2, l // 2, n // 2
@@ -148,6 +242,27 @@ def bytes_sched(m, l, n, levels):
     return adds + 7 * bytes_sched(hm, hl, hn, levels - 1)
 
 
+def golden_sha(op, m, l, n, seeds):
+    """SHA-256 of the reference's result for this product, if tests/golden holds one (make_golden.py --sha)."""
+    p = os.path.join(ROOT, "tests", "golden", "sha256.json")
+    if not os.path.exists(p):
+        return None
+    for e in json.load(open(p)):
+        if (e["op"], e["m"], e["l"], e["n"], e["seed_a"], e["seed_b"]) == (op, m, l, n, seeds[0], seeds[1]) and not e.get("cutoff"):
+            return e["sha256"]
+    return None
+
+
+def sha_of_device_rows(t, chunk_rows=8192):
+    """SHA-256 over the words of a 2-D int64 device tensor, row-major (== over the valid bits when the
+    width is whole words), streamed through the host in chunks."""
+    h = hashlib.sha256()
+    for r0 in range(0, t.shape[0], chunk_rows):
+        h.update(t[r0:r0 + chunk_rows].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,15 +271,21 @@ def main():
     ap.add_argument("--size", type=int, default=65536, help="n of the n x n x n product")
     ap.add_argument("--workload", default="mul", choices=["mul", "leaf16384", "rect131072"],
                     help="mul: n^3 mzd_mul (the headline, configs[2]/[3]); leaf16384: configs[1]; "
-                         "rect131072: 131072 x 8192 x 131072 (configs[4]), rows of A/C split over the ranks")
+                         "rect131072: 131072 x 8192 x 131072 (configs[4])")
     ap.add_argument("--cutoff", type=int, default=0)
-    ap.add_argument("--grid", default="", help="gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
+    ap.add_argument("--variant", default="strassen", choices=["strassen", "blocks"], help="N > 1: what is handed out to the ranks")
+    ap.add_argument("--layout", default="distributed", choices=["distributed", "owner"], help="N > 1: where A, B live and C is left")
+    ap.add_argument("--shard-levels", type=int, default=0, help="strassen variant: sharded levels (1, 2; 0 = automatic)")
+    ap.add_argument("--grid", default="", help="blocks variant: gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
     ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the SHA-256 check of C against the reference's")
+    ap.add_argument("--probe", action="store_true", help="internal: one warm-up + one product, nothing else (run under rocprofv3)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: development aid -- several ranks may share one GPU, P2P is staged through the host")
+                    help="gloo: development aid -- several ranks may share one GPU, pieces are staged through the host")
     ap.add_argument("--check", action="store_true",
-                    help="after timing, every rank recomputes the full product on its own GPU and compares its owned block")
+                    help="after timing, every rank recomputes the full product on its own GPU and compares the part of C it holds")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,60 +311,14 @@ def main():
         m4ri_amd.set_max_fuse(args.max_fuse)
     stream = torch.cuda.current_stream().cuda_stream
 
-    if args.workload == "leaf16384":
-        n = 16384
-    else:
-        n = args.size
+    n = 16384 if args.workload == "leaf16384" else args.size
     assert n % 64 == 0
     M, L, N = (131072, 8192, 131072) if args.workload == "rect131072" else (n, n, n)
     wl, w = L // 64, N // 64  # words per row of A, and of B / C
-
-    # ---- operands, resident in HBM (every rank generates the same A and B; it uses views) ----
-    A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
-    B = torch.empty((L, w), dtype=torch.int64, device="cuda")
     seeds = (5, 6) if args.workload == "rect131072" else (3, 4)
-    m4ri_amd.fill_dev(A.data_ptr(), wl, M, L, seeds[0], stream)
-    m4ri_amd.fill_dev(B.data_ptr(), w, L, N, seeds[1], stream)
-    grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else ((world, 1, 1) if args.workload == "rect131072" else None)
-    plan = sharding.make_plan(world, rank, M, L, N, grid=grid)
-    r0, r1 = plan.row_range()
-    c0, c1 = plan.col_range()
-    k0, k1 = plan.inner_range()
-    P = torch.empty((r1 - r0, (c1 - c0) // 64), dtype=torch.int64, device="cuda")  # this rank's block of C
-    pw = P.shape[1]
-    gh = plan.grid[2]
-    cuts = sharding.ShardPlan._cuts(r1 - r0, gh, 1)
-    recv_buf = torch.empty((cuts[plan.h + 1] - cuts[plan.h], pw), dtype=torch.int64, device="cuda") if gh > 1 else None
 
-    def multiply(r0, r1, k0, k1, c0, c1):
-        a_ptr = A.data_ptr() + 8 * (r0 * wl + k0 // 64)
-        b_ptr = B.data_ptr() + 8 * (k0 * w + c0 // 64)
-        if args.workload == "leaf16384":
-            m4ri_amd.m4rm_dev(P.data_ptr(), pw, a_ptr, wl, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, 0, stream)
-        else:
-            m4ri_amd.mul_dev(P.data_ptr(), pw, a_ptr, wl, b_ptr, w, r1 - r0, k1 - k0, c1 - c0, False, args.cutoff, stream)
-
-    def send_recv(partner, send_rows, recv_rows):
-        if args.backend == "gloo":  # host-staged (development only)
-            out = P[send_rows[0]:send_rows[1]].cpu()
-            inp = torch.empty(recv_buf.shape, dtype=torch.int64)
-            reqs = [dist.isend(out, partner), dist.irecv(inp, partner)]
-            for r in reqs:
-                r.wait()
-            recv_buf.copy_(inp)
-            return recv_buf
-        ops = [dist.P2POp(dist.isend, P[send_rows[0]:send_rows[1]], partner),
-               dist.P2POp(dist.irecv, recv_buf, partner)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        return recv_buf
-
-    def xor_rows(rows, got):
-        ptr = P.data_ptr() + 8 * rows[0] * pw
-        m4ri_amd.xor_dev(ptr, pw, ptr, pw, got.data_ptr(), pw, rows[1] - rows[0], (c1 - c0), stream)
-
-    def step():
-        sharding.run_sharded(plan, multiply, xor_rows, send_recv)
+    def words(count):
+        return torch.empty(max(1, int(count)), dtype=torch.int64, device="cuda")
 
     def fence():
         torch.cuda.synchronize()
@@ -251,11 +326,196 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange = None
+    if dist is not None:
+        exchange = sharding.torch_exchange(dist, staged_device=("cuda" if args.backend == "gloo" else None))
+    A = B = Cfull = None
+    config_extra = {}
+    need_full_inputs = world == 1 or args.layout == "owner" or args.variant == "blocks"
+    if need_full_inputs and (world == 1 or rank == 0):
+        A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
+        B = torch.empty((L, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.fill_dev(A.data_ptr(), wl, M, L, seeds[0], stream)
+        m4ri_amd.fill_dev(B.data_ptr(), w, L, N, seeds[1], stream)
+
+    # ---------------------------------------------------------------- N == 1 -----------------------
+    if world == 1:
+        Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+
+        def step():
+            if args.workload == "leaf16384":
+                m4ri_amd.m4rm_dev(Cfull.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, 0, stream)
+            else:
+                m4ri_amd.mul_dev(Cfull.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, args.cutoff, stream)
+        per_rank_product = [M, L, N]
+        config_extra["parallelism"] = "1 GPU"
+
+    # ---------------------------------------------------------------- N > 1, Strassen sub-products --
+    elif args.variant == "strassen":
+        plan = m4ri_amd.shard_plan(world, M, L, N, args.shard_levels)
+        assert (plan.M, plan.L, plan.N) == (M, L, N), "bench sizes divide evenly: no padding"
+        names = {"local_a": m4ri_amd.BUF_LOCAL_A, "local_b": m4ri_amd.BUF_LOCAL_B, "local_c": m4ri_amd.BUF_LOCAL_C,
+                 "child_a": m4ri_amd.BUF_CHILD_A, "child_b": m4ri_amd.BUF_CHILD_B, "slabs_p": m4ri_amd.BUF_SLABS_P,
+                 "oper_a": m4ri_amd.BUF_OPER_A, "oper_b": m4ri_amd.BUF_OPER_B, "prod": m4ri_amd.BUF_PROD}
+        bufs = {k: words(m4ri_amd.shard_buffer_words(plan, rank, wh)) for k, wh in names.items()}
+        runs_a, runs_b = sharding.local_rows(plan, rank, 0), sharding.local_rows(plan, rank, 1)
+        sa, sb = runs_a[0][1], runs_b[0][1]
+        if args.layout == "distributed":  # the slabs are where the inputs live: fill them straight from the streams
+            for b, (g0, rows) in enumerate(runs_a):
+                m4ri_amd.fill_rows_dev(bufs["local_a"].data_ptr() + 8 * b * sa * wl, wl, g0, rows, L, seeds[0], stream)
+            for b, (g0, rows) in enumerate(runs_b):
+                m4ri_amd.fill_rows_dev(bufs["local_b"].data_ptr() + 8 * b * sb * w, w, g0, rows, N, seeds[1], stream)
+        if args.layout == "owner" and rank == 0:
+            Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+
+        def scatter_from_owner():
+            sends, recvs = [], []
+            for r in range(world):
+                for key, full, runs, width in (("local_a", A, sharding.local_rows(plan, r, 0), wl), ("local_b", B, sharding.local_rows(plan, r, 1), w)):
+                    s = runs[0][1]
+                    for b, (g0, rows) in enumerate(runs):
+                        if rows == 0:
+                            continue
+                        if rank == 0 and r == 0:
+                            bufs[key][b * s * width:(b * s + rows) * width].copy_(full[g0:g0 + rows].reshape(-1))
+                        elif rank == 0:
+                            sends.append((r, full[g0:g0 + rows].reshape(-1)))
+                        elif rank == r:
+                            recvs.append((0, bufs[key][b * s * width:(b * s + rows) * width]))
+            exchange(sends, recvs)
+
+        def gather_to_owner():
+            sends, recvs = [], []
+            for r in range(world):
+                runs = sharding.local_rows(plan, r, 0)
+                s = runs[0][1]
+                for b, (g0, rows) in enumerate(runs):
+                    if rows == 0:
+                        continue
+                    if rank == 0 and r == 0:
+                        Cfull[g0:g0 + rows].reshape(-1).copy_(bufs["local_c"][b * s * w:(b * s + rows) * w])
+                    elif rank == 0:
+                        recvs.append((r, Cfull[g0:g0 + rows].reshape(-1)))
+                    elif rank == r:
+                        sends.append((0, bufs["local_c"][b * s * w:(b * s + rows) * w]))
+            exchange(sends, recvs)
+
+        def do_down():
+            m4ri_amd.shard_down_dev(plan, rank, bufs["local_a"].data_ptr(), wl, bufs["local_b"].data_ptr(), w,
+                                    bufs["child_a"].data_ptr(), bufs["child_b"].data_ptr(), stream)
+
+        def do_product(jl, j):
+            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * jl * plan.bm * plan.cwn, plan.cwn,
+                             bufs["oper_a"].data_ptr() + 8 * jl * plan.bm * plan.cwl, plan.cwl,
+                             bufs["oper_b"].data_ptr() + 8 * jl * plan.bl * plan.cwn, plan.cwn,
+                             plan.bm, plan.bl, plan.cwn * 64, False, args.cutoff, stream)
+
+        def do_up():
+            m4ri_amd.shard_up_dev(plan, rank, bufs["slabs_p"].data_ptr(), bufs["local_c"].data_ptr(), w, False, stream)
+
+        def step():
+            if args.layout == "owner":
+                scatter_from_owner()
+            sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s))
+            if args.layout == "owner":
+                gather_to_owner()
+        per_rank_product = [plan.bm, plan.bl, plan.cwn * 64]
+        moved = sum(pc.words * 8 for side, j, r, pc in sharding.strassen_pieces(plan, (0, 1, 2)) if pc.holder != pc.owner)
+        config_extra.update({"parallelism": f"strassen-sharded x{world}", "variant": "strassen", "layout": args.layout, "sharded_levels": plan.levels,
+                             "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
+                             "bytes_over_links_per_step": moved, "links_used": world * (world - 1),
+                             "scatter_gather_bytes_per_step": (8 * (M * wl + L * w + M * w) * (world - 1) // world) if args.layout == "owner" else 0})
+
+    # ---------------------------------------------------------------- N > 1, blocks of C -----------
+    else:
+        if args.layout != "owner":
+            raise SystemExit("--variant blocks scatters blocks from rank 0 and gathers C there: use --layout owner")
+        grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else ((world, 1, 1) if args.workload == "rect131072" else None)
+        bplan = sharding.make_plan(world, rank, M, L, N, grid=grid)
+        r0, r1 = bplan.row_range()
+        c0, c1 = bplan.col_range()
+        k0, k1 = bplan.inner_range()
+        Ablk = torch.empty((r1 - r0, (k1 - k0) // 64), dtype=torch.int64, device="cuda")
+        Bblk = torch.empty((k1 - k0, (c1 - c0) // 64), dtype=torch.int64, device="cuda")
+        P = torch.empty((r1 - r0, (c1 - c0) // 64), dtype=torch.int64, device="cuda")
+        pw = P.shape[1]
+        gh = bplan.grid[2]
+        cuts = sharding.ShardPlan._cuts(r1 - r0, gh, 1)
+        recv_buf = torch.empty((cuts[bplan.h + 1] - cuts[bplan.h], pw), dtype=torch.int64, device="cuda") if gh > 1 else None
+        if rank == 0:
+            Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+
+        def plan_of(r):
+            return sharding.make_plan(world, r, M, L, N, grid=grid)
+
+        def scatter_blocks():  # mp.c:191-204's zero-copy windows become real transfers: A_ih, B_hj to rank (i, j, h)
+            sends, recvs, keep = [], [], []
+            for r in range(world):
+                pr = plan_of(r)
+                (a0, a1), (b0, b1), (h0, h1) = pr.row_range(), pr.col_range(), pr.inner_range()
+                if rank == 0:
+                    ab = A[a0:a1, h0 // 64:h1 // 64]
+                    bb = B[h0:h1, b0 // 64:b1 // 64]
+                    if r == 0:
+                        Ablk.copy_(ab)
+                        Bblk.copy_(bb)
+                    else:
+                        ab, bb = ab.contiguous(), bb.contiguous()
+                        keep += [ab, bb]
+                        sends += [(r, ab.reshape(-1)), (r, bb.reshape(-1))]
+                elif rank == r:
+                    recvs += [(0, Ablk.reshape(-1)), (0, Bblk.reshape(-1))]
+            exchange(sends, recvs)
+
+        def multiply(_r0, _r1, _k0, _k1, _c0, _c1):
+            m4ri_amd.mul_dev(P.data_ptr(), pw, Ablk.data_ptr(), Ablk.shape[1], Bblk.data_ptr(), pw, r1 - r0, k1 - k0, c1 - c0, False, args.cutoff, stream)
+
+        def send_recv(partner, send_rows, recv_rows):
+            exchange([(partner, P[send_rows[0]:send_rows[1]].reshape(-1))], [(partner, recv_buf.reshape(-1))])
+            return recv_buf
+
+        def xor_rows(rows, got):
+            ptr = P.data_ptr() + 8 * rows[0] * pw
+            m4ri_amd.xor_dev(ptr, pw, ptr, pw, got.data_ptr(), pw, rows[1] - rows[0], (c1 - c0), stream)
+
+        def gather_blocks(region):
+            sends, recvs, tmp = [], [], []
+            for r in range(world):
+                pr = plan_of(r)
+                o0, o1 = pr.owned_rows_after_reduce()
+                b0, b1 = pr.col_range()
+                if rank == 0 and r == 0:
+                    Cfull[o0:o1, b0 // 64:b1 // 64].copy_(P[o0 - r0:o1 - r0])
+                elif rank == 0:
+                    t = torch.empty((o1 - o0, (b1 - b0) // 64), dtype=torch.int64, device="cuda")
+                    tmp.append((t, o0, o1, b0, b1))
+                    recvs.append((r, t.reshape(-1)))
+                elif rank == r:
+                    sends.append((0, P[region[0] - r0:region[1] - r0].reshape(-1)))
+            exchange(sends, recvs)
+            for t, o0, o1, b0, b1 in tmp:
+                Cfull[o0:o1, b0 // 64:b1 // 64].copy_(t)
+
+        def step():
+            scatter_blocks()
+            region = sharding.run_sharded(bplan, multiply, xor_rows, send_recv)
+            gather_blocks(region)
+        per_rank_product = [r1 - r0, k1 - k0, c1 - c0]
+        config_extra.update({"parallelism": f"blocks {list(bplan.grid)}", "variant": "blocks", "layout": "owner", "grid": list(bplan.grid)})
+
+    # ---------------------------------------------------------------- probe mode (under rocprofv3) --
+    if args.probe:
+        step()
+        torch.cuda.synchronize()
+        step()
+        torch.cuda.synchronize()
+        return
+
+    # ---------------------------------------------------------------- timing ------------------------
     for _ in range(args.warmup):
         step()
     fence()
-    m4ri_amd.set_profiling(True)
-    # per-step marks on the stream the products run on (no synchronisation inside the timed region)
+    m4ri_amd.set_profiling(2)  # leaf launches bracketed by HIP events on their stream, accumulated over all steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -265,41 +525,64 @@ def main():
     fence()
     t1 = time.perf_counter()
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    stats = m4ri_amd.get_stats()  # last step's schedule + its leaf launch durations (HIP events)
-    m4ri_amd.set_profiling(False)
+    stats = m4ri_amd.get_stats()  # last product's schedule + the leaf launch durations of ALL timed steps
+    m4ri_amd.set_profiling(0)
     elapsed = t1 - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if args.backend == "gloo":
+            tt = tt.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
     ops = float(M) * L * N  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
     value = ops * args.steps / elapsed
 
-    if args.check:
-        # recompute the whole product on this rank's GPU and compare the region this rank owns
-        region = sharding.run_sharded(plan, multiply, xor_rows, send_recv)
-        torch.cuda.synchronize()
+    # ---------------------------------------------------------------- correctness of what was timed --
+    verified = None
+    if world == 1 and not args.no_verify and args.workload != "leaf16384":
+        want = golden_sha("mul", M, L, N, seeds)
+        if want is not None:
+            got = sha_of_device_rows(Cfull)
+            verified = {"sha256": got, "matches_reference": got == want,
+                        "what": "C of the last timed step vs the real reference's product of the same inputs (tests/golden/sha256.json)"}
+            if got != want:
+                print(json.dumps({"error": "C differs from the reference", "sha256": got, "expected": want}), flush=True)
+                raise SystemExit(4)
+    if args.check and world > 1:
+        fullA = torch.empty((M, wl), dtype=torch.int64, device="cuda")
+        fullB = torch.empty((L, w), dtype=torch.int64, device="cuda")
+        m4ri_amd.fill_dev(fullA.data_ptr(), wl, M, L, seeds[0], stream)
+        m4ri_amd.fill_dev(fullB.data_ptr(), w, L, N, seeds[1], stream)
         full = torch.empty((M, w), dtype=torch.int64, device="cuda")
-        m4ri_amd.mul_dev(full.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, 0, stream)
+        m4ri_amd.mul_dev(full.data_ptr(), w, fullA.data_ptr(), wl, fullB.data_ptr(), w, M, L, N, False, 0, stream)
         torch.cuda.synchronize()
-        rr0, rr1, cc0, cc1 = region
-        mine = P[rr0 - r0:rr1 - r0, :]
-        ok = bool(torch.equal(mine, full[rr0:rr1, cc0 // 64:cc1 // 64]))
-        print(f"[check] rank {rank} grid {plan.grid} owns rows {rr0}:{rr1} cols {cc0}:{cc1} -> {'OK' if ok else 'MISMATCH'}", flush=True)
+        if args.variant == "strassen":
+            ok = True
+            for b, (g0, rows) in enumerate(runs_a):
+                ok = ok and bool(torch.equal(bufs["local_c"][b * sa * w:(b * sa + rows) * w].reshape(rows, w), full[g0:g0 + rows]))
+            what = f"slabs {[(g0, g0 + rows) for g0, rows in runs_a]} of C"
+        else:
+            o0, o1 = bplan.owned_rows_after_reduce()
+            ok = bool(torch.equal(P[o0 - r0:o1 - r0], full[o0:o1, c0 // 64:c1 // 64]))
+            what = f"rows {o0}:{o1} cols {c0}:{c1}"
+        if rank == 0 and Cfull is not None:
+            ok = ok and bool(torch.equal(Cfull, full))
+            what += " + the gathered C"
+        print(f"[check] rank {rank} {config_extra.get('parallelism')} {what} -> {'OK' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             raise SystemExit(3)
-        m4ri_amd.set_profiling(True)
-        step()
-        torch.cuda.synchronize()
-        stats = m4ri_amd.get_stats()
-        m4ri_amd.set_profiling(False)
 
     if rank == 0:
-        leaf_launch_ms = stats.leaf_ms / max(1, stats.leaf_launches)
+        launches = max(1, int(stats.cum_leaf_launches))
+        leaf_launch_ms = stats.cum_leaf_ms / launches               # mean over every leaf launch of the timed steps
         leaf_launch_bytes = stats.leaf_bytes / max(1, stats.leaf_launches)
         achieved = leaf_launch_bytes / (leaf_launch_ms * 1e-3) / 1e9 if leaf_launch_ms > 0 else 0.0
         leaf_ops = float(stats.leaf_m) * stats.leaf_l * stats.leaf_n * stats.leaf_products
+        leaf_ms_per_product = leaf_launch_ms * max(1, int(stats.leaf_launches))
+        traffic, traffic_detail = None, "not measured for this configuration"
+        if world == 1 and args.workload == "mul" and not args.no_traffic:
+            traffic, traffic_detail = measure_leaf_traffic(n, args.cutoff)
         out = {
             "metric": "gf2_matmul_n3_equiv_bitops_per_sec",
             "value": value,
@@ -316,31 +599,34 @@ def main():
             "config": {
                 "workload": (f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves"
                              if args.workload == "mul" else
-                             f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4]), rows of A/C over the ranks" if args.workload == "rect131072"
+                             f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4])" if args.workload == "rect131072"
                              else f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])"),
                 "m": M, "l": L, "n": N,
                 "ops_counted": "m*l*n bit multiply-accumulates (one AND+XOR = 1 op), classical count credited to Strassen",
-                "input": "splitmix64 seeds 3 (A), 4 (B), uniform bits, resident in HBM",
-                "grid": list(plan.grid),
-                "per_rank_product": [r1 - r0, k1 - k0, c1 - c0],
+                "input": f"splitmix64 seeds {seeds[0]} (A), {seeds[1]} (B), uniform bits, resident in HBM"
+                         + ("" if world == 1 else " (slab-cyclic over the ranks)" if args.layout == "distributed" else " of rank 0; C gathered to rank 0"),
+                "per_rank_product": per_rank_product,
                 "strassen_levels": int(stats.levels),
                 "leaf_shape": [int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n)],
                 "leaf_products_per_rank": int(stats.leaf_products),
                 "workspace_GiB": stats.workspace_bytes / 2 ** 30,
+                **config_extra,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": LEAF_KERNELS.get(int(stats.leaf_gen), "?") + " (the M4RM leaf; one batched launch per step, HIP events around that launch alone)",
+                "kernel": LEAF_KERNELS.get(int(stats.leaf_gen), "?") + " (the M4RM leaf; HIP events around every launch on its stream, mean over all timed steps)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": leaf_traffic(n, world) if args.workload == "mul" else None,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
                 "launch_ms": leaf_launch_ms,
-                "launches_per_step": int(stats.leaf_launches),
+                "launches_timed": int(stats.cum_leaf_launches),
+                "launches_per_product": int(stats.leaf_launches),
                 "algorithmic_bytes_per_launch": leaf_launch_bytes,
-                "leaf_bitops_per_sec": (leaf_ops / (stats.leaf_ms * 1e-3)) if stats.leaf_ms > 0 else 0.0,
-                "aux_pass_bytes_per_step": stats.aux_bytes,
+                "leaf_bitops_per_sec": (leaf_ops / (leaf_ms_per_product * 1e-3)) if leaf_ms_per_product > 0 else 0.0,
+                "aux_pass_bytes_per_product": stats.aux_bytes,
                 "lds": lds_model(int(stats.leaf_gen), int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n),
                                  int(stats.leaf_products) // max(1, int(stats.leaf_launches)), leaf_launch_ms),
                 "note": "the leaf is LDS-bound by design (table gathers at 256 B/clk/CU), not HBM-bound: "
@@ -349,21 +635,24 @@ def main():
             },
         }
         out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
+        if verified is not None:
+            out["verified"] = verified
         if args.workload != "leaf16384":
             copy_gbs = measured_copy_gbs()
             # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
-            # this rank's block product / step time); the compulsory bytes beside it
-            pm, pl, pn = r1 - r0, k1 - k0, c1 - c0
-            bs = float(bytes_sched(pm, pl, pn, int(stats.levels)))
+            # this rank's products / step time); the compulsory bytes beside it
+            pm, pl, pn = per_rank_product
+            nprod_rank = 1 if (world == 1 or args.variant == "blocks") else len(sharding.owned_products(plan, 0))
+            bs = float(bytes_sched(pm, pl, pn, int(stats.levels))) * nprod_rank
             out["roofline_schedule"] = {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "bytes_sched_per_rank": bs, "levels": int(stats.levels),
-                "bytes_compulsory_per_rank": float(bytes_sched(pm, pl, pn, 0)),
+                "bytes_compulsory_per_rank": float(bytes_sched(pm, pl, pn, 0)) * nprod_rank,
                 "achieved": bs / (ms_per_step * 1e-3) / 1e9,
                 "frac": bs / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
                 "copy_peak": copy_gbs, "frac_of_copy_peak": bs / (ms_per_step * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
-                "note": "unfused reference schedule bytes (15 quadrant adds/level) over the measured step time; "
+                "note": "unfused reference schedule bytes (15 quadrant adds/level) of the rank's sub-product(s) over the measured step time; "
                         "our fused three-level passes move far fewer bytes; copy_peak = this GPU's measured "
                         "device-to-device copy rate (read + write bytes)",
             }

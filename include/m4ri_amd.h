@@ -135,7 +135,13 @@ typedef struct m4ri_amd_stats {
                                8*(m*W(l) + l*W(n) + m*W(n)) per product             */
   double aux_bytes;         /* declared bytes of the fused down/up passes           */
   double workspace_bytes;   /* HBM held by the engine's workspace                   */
+  double cum_leaf_ms;       /* cumulative profiling (mode 2): leaf time of ALL products since it was
+                               switched on, and how many launches that was           */
+  int64_t cum_leaf_launches;
 } m4ri_amd_stats;
+/* 0: off.  1: the stats describe the most recent product only.  2: additionally cum_leaf_ms /
+ * cum_leaf_launches accumulate over all products until profiling is set again (no host
+ * synchronisation happens until m4ri_amd_get_stats is called). */
 void m4ri_amd_set_profiling(int on);
 int m4ri_amd_get_stats(m4ri_amd_stats *out);
 

@@ -20,6 +20,25 @@ LIB_PATH = os.path.join(_HERE, "libm4ri_amd.so")
 _lib = None
 
 
+class ShardPlan(ctypes.Structure):
+    """m4ri_amd_shard_plan (include/m4ri_amd.h part 4)."""
+
+    _fields_ = [("world", ctypes.c_int32), ("levels", ctypes.c_int32), ("nprod", ctypes.c_int32), ("blocks", ctypes.c_int32),
+                ("m", ctypes.c_int64), ("l", ctypes.c_int64), ("n", ctypes.c_int64),
+                ("M", ctypes.c_int64), ("L", ctypes.c_int64), ("N", ctypes.c_int64),
+                ("bm", ctypes.c_int64), ("bl", ctypes.c_int64), ("cwl", ctypes.c_int64), ("cwn", ctypes.c_int64)]
+
+
+class ShardPiece(ctypes.Structure):
+    """m4ri_amd_shard_piece."""
+
+    _fields_ = [("holder", ctypes.c_int32), ("owner", ctypes.c_int32),
+                ("holder_off", ctypes.c_int64), ("owner_off", ctypes.c_int64), ("words", ctypes.c_int64)]
+
+
+(BUF_LOCAL_A, BUF_LOCAL_B, BUF_LOCAL_C, BUF_CHILD_A, BUF_CHILD_B, BUF_SLABS_P, BUF_OPER_A, BUF_OPER_B, BUF_PROD) = range(9)
+
+
 class Stats(ctypes.Structure):
     """m4ri_amd_stats (include/m4ri_amd.h)."""
 
@@ -35,6 +54,8 @@ class Stats(ctypes.Structure):
         ("leaf_bytes", ctypes.c_double),
         ("aux_bytes", ctypes.c_double),
         ("workspace_bytes", ctypes.c_double),
+        ("cum_leaf_ms", ctypes.c_double),
+        ("cum_leaf_launches", ctypes.c_int64),
     ]
 
 
@@ -77,6 +98,19 @@ SYMBOLS = {
     "m4ri_amd_unpin": (_I, [MzdPtr]),
     "m4ri_amd_is_pinned": (_I, [MzdPtr]),
     "m4ri_amd_get_stats": (_I, [ctypes.POINTER(Stats)]),
+    "m4ri_amd_shard_plan_make": (_I, [ctypes.POINTER(ShardPlan), _I, _I64, _I64, _I64, _I]),
+    "m4ri_amd_shard_cut": (_I64, [_I64, _I, _I]),
+    "m4ri_amd_shard_owner": (_I, [ctypes.POINTER(ShardPlan), _I]),
+    "m4ri_amd_shard_slab_rows": (_I64, [ctypes.POINTER(ShardPlan), _I, _I]),
+    "m4ri_amd_shard_buffer_words": (_I64, [ctypes.POINTER(ShardPlan), _I, _I]),
+    "m4ri_amd_shard_piece_of": (_I, [ctypes.POINTER(ShardPlan), _I, _I, _I, ctypes.POINTER(ShardPiece)]),
+    "m4ri_amd_shard_down_dev": (_I, [ctypes.POINTER(ShardPlan), _I, _P, _I64, _P, _I64, _P, _P, _P]),
+    "m4ri_amd_shard_up_dev": (_I, [ctypes.POINTER(ShardPlan), _I, _P, _P, _I64, _I, _P]),
+    "m4ri_amd_fill_rows_dev": (_I, [_P, _I64, _I64, _I64, _I64, ctypes.c_uint64, _P]),
+    "m4ri_amd_mul_multi": (_I, [MzdPtr, MzdPtr, MzdPtr, _I, _I, _I]),
+    "m4ri_amd_set_devices": (_I, [_I, ctypes.POINTER(_I)]),
+    "m4ri_amd_get_device_list": (_I, [ctypes.POINTER(_I), _I]),
+    "m4ri_amd_set_multi_threshold": (_I64, [_I64]),
     "m4ri_amd_release_workspace": (None, []),
 }
 
@@ -186,6 +220,69 @@ def fill_dev(M: int, stride: int, rows: int, ncols: int, seed: int, stream: int 
     _check(lib().m4ri_amd_fill_dev(M, stride, rows, ncols, seed, stream), "m4ri_amd_fill_dev")
 
 
+def fill_rows_dev(M: int, stride: int, row0: int, rows: int, ncols: int, seed: int, stream: int = 0) -> None:
+    """Rows [row0, row0 + rows) of the matrix fill_dev(seed) would produce, written from M's row 0."""
+    _check(lib().m4ri_amd_fill_rows_dev(M, stride, row0, rows, ncols, seed, stream), "m4ri_amd_fill_rows_dev")
+
+
+# ---- several GPUs (include/m4ri_amd.h part 4) ------------------------------------------------------
+def shard_plan(world: int, m: int, l: int, n: int, levels: int = 0) -> ShardPlan:
+    """Plan of one product over `world` ranks (pure host arithmetic, no GPU needed)."""
+    p = ShardPlan()
+    if lib().m4ri_amd_shard_plan_make(ctypes.byref(p), world, m, l, n, levels) != 0:
+        raise ValueError(f"m4ri_amd_shard_plan_make({world}, {m}, {l}, {n}, {levels}) rejected its arguments")
+    return p
+
+
+def shard_piece(plan: ShardPlan, side: int, j: int, r: int) -> ShardPiece:
+    pc = ShardPiece()
+    if lib().m4ri_amd_shard_piece_of(ctypes.byref(plan), side, j, r, ctypes.byref(pc)) != 0:
+        raise ValueError("m4ri_amd_shard_piece_of: bad arguments")
+    return pc
+
+
+def shard_buffer_words(plan: ShardPlan, rank: int, which: int) -> int:
+    return int(lib().m4ri_amd_shard_buffer_words(ctypes.byref(plan), rank, which))
+
+
+def shard_slab_rows(plan: ShardPlan, rank: int, which: int) -> int:
+    return int(lib().m4ri_amd_shard_slab_rows(ctypes.byref(plan), rank, which))
+
+
+def shard_down_dev(plan: ShardPlan, rank: int, A_local: int, a_stride: int, B_local: int, b_stride: int,
+                   child_a: int, child_b: int, stream: int = 0) -> None:
+    _check(lib().m4ri_amd_shard_down_dev(ctypes.byref(plan), rank, A_local, a_stride, B_local, b_stride, child_a, child_b, stream),
+           "m4ri_amd_shard_down_dev")
+
+
+def shard_up_dev(plan: ShardPlan, rank: int, slabs_p: int, C_local: int, c_stride: int, add: bool = False, stream: int = 0) -> None:
+    _check(lib().m4ri_amd_shard_up_dev(ctypes.byref(plan), rank, slabs_p, C_local, c_stride, int(add), stream), "m4ri_amd_shard_up_dev")
+
+
+def mul_multi(C: Mzd, A: Mzd, B: Mzd, add: bool = False, cutoff: int = 0, levels: int = 0) -> Mzd:
+    """C (+)= A*B over the configured devices (set_devices), host matrices in and out."""
+    _check(lib().m4ri_amd_mul_multi(C.ptr, A.ptr, B.ptr, int(add), cutoff, levels), "m4ri_amd_mul_multi")
+    return C
+
+
+def set_devices(ids) -> None:
+    """Devices mzd_mul_mp / mul_multi spread a product over; an id may repeat (ranks sharing a GPU);
+    an empty list restores the default (M4RI_AMD_DEVICES or every visible device)."""
+    arr = (ctypes.c_int * max(1, len(ids)))(*ids)
+    if lib().m4ri_amd_set_devices(len(ids), arr) != 0:
+        raise ValueError(f"m4ri_amd_set_devices({list(ids)}): unknown device id")
+
+
+def get_devices() -> list:
+    arr = (ctypes.c_int * 64)()
+    n = lib().m4ri_amd_get_device_list(arr, 64)
+    return [int(arr[i]) for i in range(min(n, 64))]
+
+
+def set_multi_threshold(min_dim: int) -> int:
+    return int(lib().m4ri_amd_set_multi_threshold(int(min_dim)))
+
+
 # ---- residency (include/m4ri_amd.h part 3) --------------------------------------------------------
 def pin(M: Mzd) -> None:
     """Keep a device copy of M (which must own its block); products then read it, and windows into it,
@@ -228,7 +325,8 @@ def set_max_fuse(levels: int) -> int:
     return int(lib().m4ri_amd_set_max_fuse(int(levels)))
 
 
-def set_profiling(on: bool) -> None:
+def set_profiling(on) -> None:
+    """0/False off, 1/True per product, 2 cumulative over products (Stats.cum_leaf_ms / cum_leaf_launches)."""
     lib().m4ri_amd_set_profiling(int(on))
 
 

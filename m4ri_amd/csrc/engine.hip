@@ -97,9 +97,13 @@ struct Engine {
   word *apk             = nullptr;  // packed-A scratch of the current call (inside ws)
   size_t apk_words      = 0;
   word *part            = nullptr;  // slabs of split leaf launches (inside ws, PART_SLABS tiles)
-  bool profiling        = false;
+  int profiling         = 0;        // 0 off, 1 per call, 2 cumulative over calls (m4ri_amd_set_profiling)
   m4ri_amd_stats stats  = {};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // leaf launches awaiting readout
+  struct Pending { hipEvent_t e0, e1; long call; };
+  std::vector<Pending> pending;     // leaf launches awaiting readout
+  long call_seq         = 0;        // products issued so far (tags the pending launches)
+  double cum_ms         = 0;        // cumulative mode: leaf time and launches read out so far
+  long cum_launches     = 0;
   std::vector<hipEvent_t> event_pool;
   hipStream_t pending_stream = nullptr;
   int cus               = 0;        // compute units of the device (workgroups resident at once: one per CU)
@@ -302,7 +306,7 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
-    e->pending.emplace_back(e0, e1);
+    e->pending.push_back({e0, e1, e->call_seq});
     e->pending_stream = st;
   }
   e->stats.leaf_launches += 1;
@@ -618,9 +622,12 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
 
 void reset_stats(Engine *e) {
   const double ws = (double)e->ws_cap * 8.0;
-  // keep un-read profiling events out of the next call's sum
-  for (auto &pr : e->pending) { e->event_pool.push_back(pr.first); e->event_pool.push_back(pr.second); }
-  e->pending.clear();
+  // keep un-read profiling events out of the next call's sum (cumulative mode keeps them for the total)
+  if (e->profiling != 2) {
+    for (auto &pr : e->pending) { e->event_pool.push_back(pr.e0); e->event_pool.push_back(pr.e1); }
+    e->pending.clear();
+  }
+  e->call_seq += 1;
   e->stats = m4ri_amd_stats{};
   e->stats.workspace_bytes = ws;
 }
@@ -722,7 +729,11 @@ int m4ri_amd_set_max_fuse(int levels) {
 void m4ri_amd_set_profiling(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   Engine *e = engine_for_current_device();
-  if (e) e->profiling = on != 0;
+  if (!e) return;
+  for (auto &pr : e->pending) { e->event_pool.push_back(pr.e0); e->event_pool.push_back(pr.e1); }
+  e->pending.clear();
+  e->cum_ms = 0; e->cum_launches = 0;
+  e->profiling = on < 0 ? 0 : on > 2 ? 2 : on;
 }
 
 int m4ri_amd_get_stats(m4ri_amd_stats *out) {
@@ -730,17 +741,20 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out) {
   Engine *e = engine_for_current_device();
   if (!e || !out) return (int)hipErrorInvalidValue;
   if (!e->pending.empty()) {
-    HIPTRY(hipEventSynchronize(e->pending.back().second));
+    HIPTRY(hipEventSynchronize(e->pending.back().e1));
     double sum = 0;
     for (auto &pr : e->pending) {
       float ms = 0;
-      HIPTRY(hipEventElapsedTime(&ms, pr.first, pr.second));
-      sum += ms;
-      e->event_pool.push_back(pr.first); e->event_pool.push_back(pr.second);
+      HIPTRY(hipEventElapsedTime(&ms, pr.e0, pr.e1));
+      if (pr.call == e->call_seq) sum += ms;  // the most recent product's launches
+      e->cum_ms += ms; e->cum_launches += 1;
+      e->event_pool.push_back(pr.e0); e->event_pool.push_back(pr.e1);
     }
     e->pending.clear();
     e->stats.leaf_ms += sum;
   }
+  e->stats.cum_leaf_ms       = e->cum_ms;
+  e->stats.cum_leaf_launches = e->cum_launches;
   *out = e->stats;
   return 0;
 }

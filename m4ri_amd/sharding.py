@@ -119,3 +119,106 @@ def run_sharded(plan: ShardPlan, multiply, xor_rows, send_recv):
         got = send_recv(pr, theirs, mine)
         xor_rows(mine, got)
     return r0 + mine[0], r0 + mine[1], c0, c1
+
+
+# ==================================================================================================
+# Strassen-level sharding (include/m4ri_amd.h part 4, m4ri_amd/csrc/multi.hip): the sub-products of the
+# top Strassen-Winograd level(s) over the ranks, matrices distributed slab-cyclically.
+#
+# One process per GPU.  The plan and the piece table come from the C library (pure host arithmetic);
+# this module only walks the table and hands every piece to the injected transport, so the very same
+# code runs under RCCL on HBM tensors (bench.py), under gloo on one shared GPU (tests -m gpu) and
+# under gloo on CPU tensors (tests/test_sharding_gloo.py).
+# ==================================================================================================
+def strassen_pieces(plan, sides=(0, 1)):
+    """All pieces (side, j, r) of the plan in the canonical order both ends of a link post them in."""
+    import m4ri_amd
+    out = []
+    for side in sides:
+        for j in range(plan.nprod):
+            for r in range(plan.world):
+                pc = m4ri_amd.shard_piece(plan, side, j, r)
+                if pc.words:
+                    out.append((side, j, r, pc))
+    return out
+
+
+def owned_products(plan, rank):
+    return list(range(rank, plan.nprod, plan.world))
+
+
+def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local):
+    """One product C = A*B over plan.world ranks; this is rank `rank`'s part.
+
+    bufs: dict of 1-D word tensors/arrays keyed 'child_a', 'child_b', 'slabs_p', 'oper_a', 'oper_b', 'prod'
+          (sizes: m4ri_amd.shard_buffer_words).
+    down():            local parents of A and B -> bufs['child_a'], bufs['child_b']   (local Winograd down pass)
+    product(jl, j):    bufs['prod'][jl] = bufs['oper_a'][jl] * bufs['oper_b'][jl]      (owned sub-product number jl)
+    up():              bufs['slabs_p'] -> local parent of C                            (local Winograd up pass)
+    exchange(sends, recvs): sends = [(dst_rank, view)], recvs = [(src_rank, view)], each list in the
+                       canonical piece order; must complete before returning.
+    copy_local(dst_view, src_view): a piece whose holder and owner are this rank.
+    """
+    child = {0: bufs["child_a"], 1: bufs["child_b"]}
+    oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
+    down()
+    sends, recvs = [], []
+    for side, j, r, pc in strassen_pieces(plan, (0, 1)):
+        src = child[side][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
+        dst = oper[side][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
+        if pc.holder == rank and pc.owner == rank:
+            copy_local(dst, src)
+        elif pc.holder == rank:
+            sends.append((pc.owner, src))
+        elif pc.owner == rank:
+            recvs.append((pc.holder, dst))
+    exchange(sends, recvs)
+    for jl, j in enumerate(owned_products(plan, rank)):
+        product(jl, j)
+    sends, recvs = [], []
+    for side, j, r, pc in strassen_pieces(plan, (2,)):
+        src = bufs["prod"][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
+        dst = bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
+        if pc.holder == rank and pc.owner == rank:
+            copy_local(dst, src)
+        elif pc.owner == rank:
+            sends.append((pc.holder, src))
+        elif pc.holder == rank:
+            recvs.append((pc.owner, dst))
+    exchange(sends, recvs)
+    up()
+
+
+def local_rows(plan, rank, which):
+    """Global row indices (of A/C for which == 0, of B for which == 1) held by `rank`, in local order:
+    slab `rank` of block 0, of block 1, ... -- as (global_row0, rows) runs."""
+    import m4ri_amd
+    brows = plan.bl if which else plan.bm
+    c0 = int(m4ri_amd.lib().m4ri_amd_shard_cut(brows, plan.world, rank))
+    c1 = int(m4ri_amd.lib().m4ri_amd_shard_cut(brows, plan.world, rank + 1))
+    return [(b * brows + c0, c1 - c0) for b in range(plan.blocks)]
+
+
+def torch_exchange(dist, staged_device=None):
+    """Transport over torch.distributed P2P ops (backend nccl == RCCL: every piece is one send/recv pair on
+    the direct xGMI link between its two ranks; all pieces of a phase are posted as one batch, so all links
+    of the mesh work concurrently).  staged_device: tensors live on that device but the backend (gloo)
+    cannot move them -- stage through the host (development / one-GPU tests only)."""
+    import torch
+
+    def exchange(sends, recvs):
+        if not sends and not recvs:
+            return
+        if staged_device is not None:
+            outs = [(dst, v.cpu()) for dst, v in sends]
+            ins = [(src, torch.empty(v.shape, dtype=v.dtype), v) for src, v in recvs]
+            ops = [dist.P2POp(dist.isend, t, dst) for dst, t in outs] + [dist.P2POp(dist.irecv, t, src) for src, t, _ in ins]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for _, t, v in ins:
+                v.copy_(t)
+            return
+        ops = [dist.P2POp(dist.isend, v, dst) for dst, v in sends] + [dist.P2POp(dist.irecv, v, src) for src, v in recvs]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return exchange

@@ -142,11 +142,12 @@ def oracle() -> Oracle:
     return _oracle
 
 
-def reference(openmp: bool = False) -> Reference | None:
-    name = "libm4ri_ref_omp.so" if openmp else "libm4ri_ref.so"
+def reference(openmp: bool = False, tag: str = "") -> Reference | None:
+    """tag: a build with other cache macros, e.g. "_c32768_1048576_33554432" (oracle/Makefile `ref-cache`)."""
+    name = ("libm4ri_ref_omp" if openmp else "libm4ri_ref") + tag + ".so"
     if name not in _refs:
         so = os.path.join(ORACLE_DIR, "_ref", name)
-        if not os.path.exists(so) and os.path.exists("/root/reference/m4ri/mzd.c"):
+        if not os.path.exists(so) and not tag and os.path.exists("/root/reference/m4ri/mzd.c"):
             subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
         _refs[name] = Reference(so) if os.path.exists(so) else None
     return _refs[name]

@@ -196,8 +196,52 @@ def fingerprint_window_xl():
                         fp_reference_on_windows=np.array([fp_on_windows], dtype=np.uint64))
 
 
+def sha256_large():
+    """SHA-256 (over the valid words, row-major, excess bits masked: Mzd.masked().tobytes()) of the large
+    fixtures, beside their 64-bit FNV fingerprints (SURVEY.md 8c asks for SHA-256): the two BASELINE-size
+    products, the six ragged XL products and the windowed 30000^2 accumulate.  Every product is recomputed by
+    the reference here and its FNV fingerprint compared with the stored one first.  -> sha256.json"""
+    import hashlib
+    import json
+    out = []
+
+    def sha(M):
+        return hashlib.sha256(M.masked().tobytes()).hexdigest()
+
+    for fname in ("fingerprints_xl.npz", "fingerprints_ragged_xl.npz"):
+        z = np.load(os.path.join(HERE, fname))
+        for op, (m, l, n, par), (sa, sb, sc), fp in zip(z["ops"], z["meta"], z["seeds"], z["fp"]):
+            op, m, l, n, par, sa, sb, sc = str(op), int(m), int(l), int(n), int(par), int(sa), int(sb), int(sc)
+            t = time.time()
+            A, B = Mzd.random(m, l, sa), Mzd.random(l, n, sb)
+            C = (ref.mul(None, A, B, par) if op == "mul" else ref.mul_m4rm(None, A, B, par) if op == "m4rm"
+                 else ref.addmul(Mzd.random(m, n, sc), A, B, par))
+            assert orc.fingerprint(C) == int(fp), (fname, op, m, l, n)
+            out.append({"op": op, "m": m, "l": l, "n": n, "cutoff": par, "seed_a": sa, "seed_b": sb, "seed_c": sc,
+                        "fnv1a": hex(int(fp)), "sha256": sha(C), "source": fname})
+            print(op, m, l, n, par, out[-1]["sha256"][:16], f"{time.time() - t:.1f}s", flush=True)
+            del A, B, C
+            json.dump(out, open(os.path.join(HERE, "sha256.json"), "w"), indent=1)
+    W = WINDOW_XL
+    Pa, Pb, Pc = (Mzd.random(*W[k]) for k in ("pa", "pb", "pc"))
+    A, B, C = Pa.window(*W["a"]), Pb.window(*W["b"]), Pc.window(*W["c"])
+    clean = ref.addmul(C.copy(), A.copy(), B.copy(), 0)
+    rows, wd = C.rows(), C.width
+    rows[:, :wd - 1] = clean.rows()[:, :wd - 1]
+    mask = np.uint64((1 << (C.ncols % 64)) - 1) if C.ncols % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    rows[:, wd - 1] = (rows[:, wd - 1] & ~mask) | (clean.rows()[:, wd - 1] & mask)
+    z = np.load(os.path.join(HERE, "fingerprint_window_xl.npz"))
+    assert orc.fingerprint(Pc) == int(z["fp"][0])
+    out.append({"op": "window_addmul_parent", "m": A.nrows, "l": A.ncols, "n": B.ncols, "cutoff": 0, "seed_a": 41, "seed_b": 42, "seed_c": 43,
+                "fnv1a": hex(int(z["fp"][0])), "sha256": sha(Pc), "source": "fingerprint_window_xl.npz"})
+    json.dump(out, open(os.path.join(HERE, "sha256.json"), "w"), indent=1)
+    print("sha256.json:", len(out), "entries")
+
+
 if __name__ == "__main__":
-    if "--window-xl" in sys.argv:
+    if "--sha" in sys.argv:
+        sha256_large()
+    elif "--window-xl" in sys.argv:
         fingerprint_window_xl()
     elif "--ragged-xl" in sys.argv:
         fingerprints_ragged_xl()

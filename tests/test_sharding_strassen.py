@@ -1,0 +1,134 @@
+"""The Strassen-sharded multi-GPU product on CPU (include/m4ri_amd.h part 4, m4ri_amd/csrc/multi.hip,
+m4ri_amd/sharding.py): the plan and piece table of the C library and the exchange walk of sharding.py,
+with the device steps replaced by numpy/oracle stand-ins (tests/shard_sim.py).
+
+  * every world size / level count in one process (ranks as threads over a mailbox),
+  * world_size 2 under torch.distributed with the gloo backend -- exactly the transport code bench.py
+    runs under RCCL."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import m4ri_amd  # noqa: E402
+import shard_sim  # noqa: E402
+from m4ri_amd import sharding  # noqa: E402
+from m4ri_amd.mzd import Mzd  # noqa: E402
+
+
+def test_plan_arithmetic():
+    for world, want in ((2, 2), (3, 2), (4, 2), (7, 1), (8, 1)):
+        assert m4ri_amd.shard_plan(world, 65536, 65536, 65536).levels == want      # fewest rounds on the busiest rank
+    assert m4ri_amd.shard_plan(4, 4096, 4096, 4096).levels == 1                    # second level only on large sub-products
+    p = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
+    assert (p.nprod, p.blocks, p.bm, p.bl, p.cwl, p.cwn) == (7, 2, 32768, 32768, 512, 512)
+    assert [len(sharding.owned_products(p, r)) for r in range(8)] == [1] * 7 + [0]
+    # every directed link of the mesh carries the same share of an operand: 1/8 of 128 MiB
+    per_link = {}
+    for side, j, r, pc in sharding.strassen_pieces(p, (0,)):
+        if pc.holder != pc.owner:
+            per_link[(pc.holder, pc.owner)] = per_link.get((pc.holder, pc.owner), 0) + pc.words * 8
+    assert set(per_link.values()) == {16 << 20} and len(per_link) == 7 * 7
+    p = m4ri_amd.shard_plan(4, 65536, 65536, 65536)
+    assert [len(sharding.owned_products(p, r)) for r in range(4)] == [13, 12, 12, 12]
+    # ragged: padded to whole blocks / words, pieces tile every operand exactly once
+    p = m4ri_amd.shard_plan(3, 1001, 777, 130, 2)
+    assert (p.M, p.L, p.N) == (1004, 1024, 256) and p.bm == 251 and p.cwl == 4 and p.cwn == 1
+    for side, rows, cw in ((0, p.bm, p.cwl), (1, p.bl, p.cwn), (2, p.bm, p.cwn)):
+        for j in range(p.nprod):
+            cover = np.zeros(rows * cw, dtype=np.int32)
+            for r in range(p.world):
+                pc = m4ri_amd.shard_piece(p, side, j, r)
+                assert pc.owner == j % 3 and pc.holder == r
+                base = (j // 3) * rows * cw
+                cover[pc.owner_off - base:pc.owner_off - base + pc.words] += 1
+            assert (cover == 1).all()
+
+
+@pytest.mark.parametrize("world,levels,m,l,n", [(2, 1, 64, 128, 128), (2, 2, 100, 256, 256), (3, 1, 77, 130, 65),
+                                                (4, 2, 203, 300, 257), (8, 1, 130, 129, 200), (8, 2, 64, 512, 256),
+                                                (5, 2, 7, 64, 64)])   # more ranks than rows per block: empty slabs
+def test_all_ranks_in_one_process(oracle, world, levels, m, l, n):
+    A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    mail, lock, barrier = {}, threading.Lock(), threading.Barrier(world)
+    parts, errors = {}, []
+
+    def make_exchange(rank):
+        def exchange(sends, recvs):
+            with lock:
+                for dst, v in sends:
+                    mail.setdefault((rank, dst), []).append(np.array(v, copy=True))
+            barrier.wait()
+            for src, v in recvs:
+                with lock:
+                    v[:] = mail[(src, rank)].pop(0)
+            barrier.wait()
+        return exchange
+
+    def work(rank):
+        try:
+            parts[rank] = shard_sim.rank_part(plan, rank, A, B, oracle, make_exchange(rank))
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert all(not q for q in mail.values()), "every posted piece must have been received"
+    got = shard_sim.assemble(plan, parts, m, n)
+    assert np.array_equal(got, oracle.mul(None, A, B, 0).masked())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, levels, m, l, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_libs
+    orc = cpu_libs.oracle()
+    A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    torch_x = sharding.torch_exchange(dist)
+
+    def exchange(sends, recvs):  # numpy views <-> torch tensors sharing memory: the transport is sharding.torch_exchange
+        torch_x([(d, torch.from_numpy(v.view(np.int64))) for d, v in sends], [(s, torch.from_numpy(v.view(np.int64))) for s, v in recvs])
+
+    CL, runs = shard_sim.rank_part(plan, rank, A, B, orc, exchange)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=CL, runs=np.array(runs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("levels,m,l,n", [(1, 200, 256, 320), (2, 131, 257, 129)])
+def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path)), nprocs=world, join=True)
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    parts = {}
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        parts[r] = (z["C"], [tuple(int(x) for x in row) for row in z["runs"]])
+    got = shard_sim.assemble(plan, parts, m, n)
+    assert np.array_equal(got, oracle.mul(None, Mzd.random(m, l, 3), Mzd.random(l, n, 4), 0).masked())
