@@ -40,6 +40,15 @@ typedef struct mzd_t {
 } mzd_t;
 #endif
 
+/* mzp_t: layout-identical to m4ri/mzp.h:37-49 (LAPACK-style transpositions: values[i] is the index swapped
+ * with i, for i ascending). */
+#ifndef M4RI_AMD_NO_MZD_T
+typedef struct mzp_t {
+  rci_t *values;
+  rci_t length;
+} mzp_t;
+#endif
+
 /* =================================================================================================
  * Part 1 -- drop-in entry points (host mzd_t in, host mzd_t out, blocking)
  *
@@ -75,6 +84,29 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
  * replaces the omp sections). */
 mzd_t *mzd_mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
 mzd_t *mzd_addmul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+
+/* ---- triangular solves with a matrix right-hand side (the callers of the multiply
+ * path one step up; TRSM base cases are where an LD_PRELOADed PLE / solve spends its CPU time) ------------
+ * B <- L^-1 B / B <- U^-1 B in place, T unit triangular: its diagonal and its other triangle are never read
+ * (m4ri/triangular.c:406-455, :467-514), B and T may be windows, the bits of B's last word outside its
+ * columns are kept.  The solution is unique, so every schedule gives the reference's bits; `k` and `cutoff`
+ * are hints.  m4ri/triangular.h:115, :127, :142, :153; m4ri/triangular_russian.h:43, :55. */
+void mzd_trsm_lower_left(mzd_t const *L, mzd_t *B, const int cutoff);
+void _mzd_trsm_lower_left(mzd_t const *L, mzd_t *B, const int cutoff);
+void _mzd_trsm_lower_left_russian(mzd_t const *L, mzd_t *B, int k);
+void mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff);
+void _mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff);
+void _mzd_trsm_upper_left_russian(mzd_t const *U, mzd_t *B, int k);
+
+/* ---- PLE decomposition -----------------------------------------------------------
+ * A = P L E Q in place: returns the rank r; afterwards the first r columns of A hold L below the diagonal (unit
+ * diagonal implied), E sits in the rows 0..r-1 from each row's pivot column on, P (A->nrows entries) and Q
+ * (A->ncols entries) hold the row / column transpositions -- exactly the reference's output, which is fixed by
+ * its pivoting rule (first row with a set bit, columns left to right), not by its schedule.  `cutoff`, `k`:
+ * hints.  m4ri/ple.h:103, :137; m4ri/ple_russian.h:81 (ple.c:33-171, ple_russian.c:380-617). */
+rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
+rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
+rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k);
 
 /* Allocation used for C == NULL when the process has no libm4ri (standalone use, our tests):
  * same layout rules as mzd_init/mzd_free (mzd.c:142-157,179-185). */
@@ -115,6 +147,16 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
  * and the other bits of C's last word are kept (mzd.c:1489). */
 int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t rows, int64_t ncols, void *stream);
+/* B (mb x nb, device) <- L^-1 B / U^-1 B in place, T (mb x mb, device) unit triangular -- the device twins of
+ * _mzd_trsm_lower_left / _mzd_trsm_upper_left: halves recursion down to 64-row blocks, every update one
+ * m4ri_amd_mul_dev on views.  Bits of B at column >= nb: zero in, zero out. */
+int m4ri_amd_trsm_lower_left_dev(const word *L, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                 void *stream);
+int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                 void *stream);
+/* PLE of a device matrix in place (bits at column >= ncols zero in, zero out).  P (nrows entries) and Q (ncols
+ * entries) are HOST arrays.  Blocking: the pivots of every 64-column block are read back. */
+int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out, void *stream);
 /* Deterministic fill: word (r, j) = splitmix64 stream `seed`, output number r*width + j, last word
  * masked -- the order mzd_randomize_custom fills a matrix in (mzd.c:1282-1292). */
 int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed, void *stream);

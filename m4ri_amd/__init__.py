@@ -20,6 +20,12 @@ LIB_PATH = os.path.join(_HERE, "libm4ri_amd.so")
 _lib = None
 
 
+class Mzp(ctypes.Structure):
+    """mzp_t (include/m4ri_amd.h; reference m4ri/mzp.h:37-49)."""
+
+    _fields_ = [("values", ctypes.POINTER(ctypes.c_int32)), ("length", ctypes.c_int32)]
+
+
 class ShardPlan(ctypes.Structure):
     """m4ri_amd_shard_plan (include/m4ri_amd.h part 4)."""
 
@@ -78,6 +84,18 @@ SYMBOLS = {
     "_mzd_mul_m4rm": (MzdPtr, [MzdPtr, MzdPtr, MzdPtr, _I, _I]),
     "mzd_mul_mp": _MULSIG,
     "mzd_addmul_mp": _MULSIG,
+    "mzd_trsm_lower_left": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_lower_left": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_lower_left_russian": (None, [MzdPtr, MzdPtr, _I]),
+    "mzd_trsm_upper_left": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_upper_left": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_upper_left_russian": (None, [MzdPtr, MzdPtr, _I]),
+    "m4ri_amd_trsm_lower_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "m4ri_amd_trsm_upper_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "_mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "_mzd_ple_russian": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
     "m4ri_amd_mzd_free": (None, [MzdPtr]),
     "m4ri_amd_result_free": (None, [MzdPtr]),
@@ -189,6 +207,31 @@ def mzd_mul_mp(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
 
 def mzd_addmul_mp(C: Mzd | None, A: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
     return _ret(C, lib().mzd_addmul_mp(_p(C), A.ptr, B.ptr, cutoff))
+
+
+# ---- triangular solves (reference m4ri/triangular.h:115-153, m4ri/triangular_russian.h:43, :55) -------
+def mzd_trsm_lower_left(L: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    """B <- L^-1 B in place, L unit lower triangular (only the bits below its diagonal are read)."""
+    lib().mzd_trsm_lower_left(L.ptr, B.ptr, cutoff)
+    return B
+
+
+def mzd_trsm_upper_left(U: Mzd, B: Mzd, cutoff: int = 0) -> Mzd:
+    """B <- U^-1 B in place, U unit upper triangular (only the bits above its diagonal are read)."""
+    lib().mzd_trsm_upper_left(U.ptr, B.ptr, cutoff)
+    return B
+
+
+def mzd_ple(A: Mzd, cutoff: int = 0, which: str = "mzd_ple"):
+    """PLE decomposition of A in place (reference m4ri/ple.h:103); returns (rank, P, Q) with P, Q numpy int32
+    arrays of A.nrows / A.ncols transpositions."""
+    import numpy as np
+    P, Q = np.zeros(max(1, A.nrows), dtype=np.int32), np.zeros(max(1, A.ncols), dtype=np.int32)
+    mp, mq = Mzp(), Mzp()
+    mp.values, mp.length = P.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), A.nrows
+    mq.values, mq.length = Q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), A.ncols
+    r = getattr(lib(), which)(A.ptr, ctypes.byref(mp), ctypes.byref(mq), cutoff)
+    return int(r), P[:A.nrows], Q[:A.ncols]
 
 
 # ---- device-resident API -------------------------------------------------------------------------

@@ -250,6 +250,64 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   return C;
 }
 
+// ---- in/out matrices of the solvers (B of a TRSM, A of a PLE) --------------------------------------
+// device view of a matrix that is read AND written: inside its pinned parent when the engine may write
+// whole last words there, otherwise a staged copy (uploaded, or copied out of the pinned parent)
+struct InOut {
+  DevMat d;
+  bool staged = true;
+  Pin *pin    = nullptr;
+};
+
+size_t inout_words(const mzd_t *M) {
+  Pin *p = find_pin(M);
+  const bool staged = !p || (M->ncols % 64 != 0 && M->ncols != p->ncols);
+  return staged ? dev_words(M->nrows, M->ncols) : 0;
+}
+
+InOut inout_begin(mzd_t *M) {
+  InOut io;
+  io.pin    = find_pin(M);
+  io.staged = !io.pin || (M->ncols % 64 != 0 && M->ncols != io.pin->ncols);
+  if (!io.staged) { io.d = operand(M, false); return io; }
+  if (!io.pin) { upload(io.d, M); return io; }
+  dev_alloc(io.d, M->nrows, M->ncols);
+  const DevMat src = operand(M, false);
+  HIPDIE(hipMemcpy2DAsync(io.d.p, (size_t)io.d.stride * 8, src.p, (size_t)src.stride * 8, (size_t)M->width * 8, (size_t)M->nrows,
+                          hipMemcpyDeviceToDevice, nullptr));
+  HIPDIE(m4ri_amd_mask_tail_dev(io.d.p, io.d.stride, M->nrows, M->ncols, nullptr));
+  return io;
+}
+
+void inout_end(InOut &io, mzd_t *M) {
+  if (io.pin) {
+    if (io.staged) {
+      const DevMat dst = operand(M, false);
+      HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, io.d.p, io.d.stride, M->nrows, M->ncols));
+    }
+    io.pin->dev_newer = true;
+  } else {
+    download(io.d, M);
+  }
+}
+
+// B <- T^-1 B for a unit triangular T (triangular.c:406-455, :467-514); T's other triangle and diagonal are never read
+void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  if (B->nrows <= 1 || B->ncols == 0) return;  // one row: X = B
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve((find_pin(T) ? 0 : dev_words(T->nrows, T->ncols)) + inout_words(B));
+  const DevMat dT = operand(T, true);
+  InOut io        = inout_begin(B);
+  if (upper) HIPDIE(m4ri_amd_trsm_upper_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  else       HIPDIE(m4ri_amd_trsm_lower_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  inout_end(io, B);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+}
+
 void pin_download(Pin &p) {
   if (!p.dev_newer) return;
   const int64_t width = words_of(p.ncols);
@@ -345,6 +403,53 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
   (void)k;
   return run(C, A, B, clear == 0, false, 0);
 }
+
+// ---- triangular solves: the reference's names, host mzd_t in / out -------------
+void mzd_trsm_lower_left(mzd_t const *L, mzd_t *B, const int cutoff) {  // triangular.c:396-404
+  if (L->ncols != B->nrows) die("mzd_trsm_lower_left: L ncols (%d) need to match B nrows (%d).\n", L->ncols, B->nrows);
+  if (L->nrows != L->ncols) die("mzd_trsm_lower_left: L must be square and is found to be (%d) x (%d).\n", L->nrows, L->ncols);
+  run_trsm(false, L, B, cutoff < 0 ? 0 : cutoff);
+}
+void _mzd_trsm_lower_left(mzd_t const *L, mzd_t *B, const int cutoff) { run_trsm(false, L, B, cutoff < 0 ? 0 : cutoff); }  // triangular.c:406
+void _mzd_trsm_lower_left_russian(mzd_t const *L, mzd_t *B, int k) { (void)k; run_trsm(false, L, B, 0); }  // triangular_russian.c:206
+
+void mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff) {  // triangular.c:457-465
+  if (U->ncols != B->nrows) die("mzd_trsm_upper_left: U ncols (%d) need to match B nrows (%d).\n", U->ncols, B->nrows);
+  if (U->nrows != U->ncols) die("mzd_trsm_upper_left: U must be square and is found to be (%d) x (%d).\n", U->nrows, U->ncols);
+  run_trsm(true, U, B, cutoff < 0 ? 0 : cutoff);
+}
+void _mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff) { run_trsm(true, U, B, cutoff < 0 ? 0 : cutoff); }  // triangular.c:467
+void _mzd_trsm_upper_left_russian(mzd_t const *U, mzd_t *B, int k) { (void)k; run_trsm(true, U, B, 0); }  // triangular_russian.c:50
+
+// ---- PLE decomposition: the reference's names, host mzd_t / mzp_t in and out ---------
+static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  if (A->nrows == 0 || A->ncols == 0) {
+    for (rci_t i = 0; i < A->nrows; ++i) P->values[i] = i;
+    for (rci_t j = 0; j < A->ncols; ++j) Q->values[j] = j;
+    return 0;
+  }
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  int32_t rank = 0;
+  HIPDIE(m4ri_amd_ple_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, Q->values, &rank, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return rank;
+}
+
+rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) {  // ple.c:33-39
+  (void)cutoff;
+  if (P->length != A->nrows) die("mzd_ple: Permutation P length (%d) must match A nrows (%d)\n", P->length, A->nrows);
+  if (Q->length != A->ncols) die("mzd_ple: Permutation Q length (%d) must match A ncols (%d)\n", Q->length, A->ncols);
+  return run_ple(A, P, Q);
+}
+rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) { (void)cutoff; return run_ple(A, P, Q); }  // ple.c:62-171
+rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return run_ple(A, P, Q); }           // ple_russian.c:380-617
 
 void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena
   std::lock_guard<std::mutex> lk(g_api_mu);

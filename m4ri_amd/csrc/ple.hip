@@ -1,0 +1,289 @@
+// ple.hip -- PLE decomposition on the device: A = P L E Q in place, the elimination step above the multiply
+// path.
+//
+// Reference interfaces replaced (same A, P, Q and rank, bit for bit):
+//   _mzd_ple_russian   /root/reference m4ri/ple_russian.c:380-617   the block-iterative "Russian" base case
+//   _mzd_ple / mzd_ple m4ri/ple.c:62-171, m4ri/ple.h                the recursive driver over it
+// What they compute is fixed by the pivoting rule, not by the schedule: columns left to right, pivot = the
+// first row at or below the current rank position whose bit in the column is set after elimination by the
+// earlier pivots, swap it up, clear the rows below from the NEXT column on (the multiplier stays in the pivot
+// column), finally move L's columns to the left (ple_russian.c:596-602).  The CPU checker states that rule
+// column by column and tests/test_ple_oracle.py pins it against both reference routines.
+//
+// Schedule here -- right-looking, one 64-column word block at a time, everything on the device:
+//   1. slice kernel (ONE workgroup): the block's word of every remaining row is copied into a dense vector and
+//      eliminated column by column there (64 passes over <= nrows words: the only sequential part) -> the
+//      pivots of the block, the row swaps, and every row's multipliers, left in place in its slice word;
+//   2. the swaps are applied to the other words of the rows; the pivot rows (<= 64) are reduced among
+//      themselves on the words to the right (the reference's A10 step, ple_russian.c:306-325);
+//   3. rows below, words to the right:  C ^= M * U  with M = the rows' multipliers (<= 64 bits each) and U the
+//      block's pivot rows -- a rank-<=64 update by the engine's own M4RM leaf (the reference's table steps
+//      _mzd_ple_a11_N / _mzd_process_rows_ple_N, ple_russian_template.h, are this product by seven tables);
+//      it streams the trailing matrix once per 64 columns: HBM-bound;
+//   4. after the last block one gather pass compresses L (closed form of ple_russian.c:596-602: row r takes
+//      new[j] = old[Q[j]] for j <= min(r, rank - 1) and zeros at the vacated pivot columns).
+// The host only reads back the block's pivots (a few hundred bytes per 64 columns).
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "gf2_common.h"
+#include "../../include/m4ri_amd.h"
+
+namespace {
+
+#define HIPTRY(expr)                                  \
+  do {                                                \
+    hipError_t e_ = (hipError_t)(expr);               \
+    if (e_ != hipSuccess) return (int)e_;             \
+  } while (0)
+
+constexpr int SLICE_THREADS = 1024;
+constexpr int ROW_THREADS   = 256;
+
+struct PleBlock {
+  int32_t rank;
+  int32_t pivcol[64];   // column of pivot t inside the block
+  int32_t swaprow[64];  // absolute row that was swapped into position r0 + t
+};
+
+// ---- 1. the block's slice: pivots, swaps, multipliers ------------------------------------------------------
+__global__ __launch_bounds__(SLICE_THREADS) void ple_slice_kernel(const word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0,
+                                                                  int64_t wb, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
+  __shared__ int s_min;
+  __shared__ word s_vp;
+  const int tid   = threadIdx.x;
+  const int64_t n = nrows - r0;  // V[i] <-> row r0 + i
+  for (int64_t i = tid; i < n; i += SLICE_THREADS) V[i] = A[(r0 + i) * stride + wb];
+  if (tid == 0) s_min = INT_MAX;
+  __syncthreads();
+  int rank = 0, cprev = 0;
+  bool have = false;
+  word vp_high = 0;
+  for (int c = 0; c < ncb && rank < n; ++c) {
+    // one pass: finish the previous pivot's elimination on the rows below it, and look for column c's pivot
+    int local = INT_MAX;
+    for (int64_t i = rank + tid; i < n; i += SLICE_THREADS) {
+      word v = V[i];
+      if (have && ((v >> cprev) & 1)) { v ^= vp_high; V[i] = v; }
+      if (((v >> c) & 1) && local == INT_MAX) local = (int)i;
+    }
+    have = false;
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(local, off, 64); local = o < local ? o : local; }
+    if ((tid & 63) == 0 && local != INT_MAX) atomicMin(&s_min, local);
+    __syncthreads();
+    const int p = s_min;
+    __syncthreads();
+    if (p != INT_MAX) {
+      if (tid == 0) {
+        const word vp = V[p];
+        V[p]    = V[rank];
+        V[rank] = vp;
+        s_vp    = vp;
+        s_min   = INT_MAX;
+        out->pivcol[rank]  = c;
+        out->swaprow[rank] = (int32_t)(r0 + p);
+      }
+      __syncthreads();
+      vp_high = c < 63 ? (s_vp & (~(word)0 << (c + 1))) : 0;  // the pivot row from the NEXT column on
+      cprev   = c;
+      have    = true;
+      ++rank;
+    }
+  }
+  if (have)
+    for (int64_t i = rank + tid; i < n; i += SLICE_THREADS) {
+      const word v = V[i];
+      if ((v >> cprev) & 1) V[i] = v ^ vp_high;
+    }
+  if (tid == 0) out->rank = rank;
+}
+
+// ---- 2a. the block's row swaps on every other word; one thread per word column ---------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wb, int64_t r0,
+                                                                   const PleBlock *__restrict__ blk) {
+  const int64_t w = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
+  if (w >= width || w == wb) return;
+  const int rank = blk->rank;
+  for (int t = 0; t < rank; ++t) {
+    const int64_t a = r0 + t, b = blk->swaprow[t];
+    if (a == b) continue;
+    const word x = A[a * stride + w], y = A[b * stride + w];
+    A[a * stride + w] = y;
+    A[b * stride + w] = x;
+  }
+}
+
+// ---- 2b. slice words back into the matrix + the rows' multipliers gathered into `rank` low bits -----------------
+__global__ __launch_bounds__(ROW_THREADS) void ple_writeback_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
+                                                                   const word *__restrict__ V, const PleBlock *__restrict__ blk,
+                                                                   word *__restrict__ Mc) {
+  const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;  // V index
+  if (i >= nrows - r0) return;
+  const word v = V[i];
+  A[(r0 + i) * stride + wb] = v;
+  const int rank = blk->rank;
+  if (i >= rank) {
+    word m = 0;
+    for (int t = 0; t < rank; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
+    Mc[i - rank] = m;
+  }
+}
+
+// ---- 2c. the pivot rows among themselves, words right of the block (ple_russian.c:306-325) ------------------------
+__global__ __launch_bounds__(ROW_THREADS) void ple_reduce_pivot_rows_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wb,
+                                                                           int64_t r0, const word *__restrict__ V,
+                                                                           const PleBlock *__restrict__ blk) {
+  const int64_t w = wb + 1 + (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
+  if (w >= width) return;
+  const int rank = blk->rank;
+  for (int t = 1; t < rank; ++t) {
+    const word mult = V[t];  // wave-uniform
+    word x = A[(r0 + t) * stride + w];
+    for (int j = 0; j < t; ++j)
+      if ((mult >> blk->pivcol[j]) & 1) x ^= A[(r0 + j) * stride + w];
+    A[(r0 + t) * stride + w] = x;
+  }
+}
+
+// ---- 4. compressing L: one workgroup per row ---------------------------------------------------------------------
+// new[j] = old[Q[j]] for j <= t = min(r, rank - 1); pivot columns Q[j] > t (j <= t) become 0; everything else stays.
+__global__ __launch_bounds__(ROW_THREADS) void ple_compress_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t width,
+                                                                  const int32_t *__restrict__ Q, const word *__restrict__ pivmask, int rank) {
+  extern __shared__ word s_new[];  // gathered words 0 .. t/64
+  const int64_t r = blockIdx.x;
+  if (r >= nrows || rank == 0) return;
+  word *row       = A + r * stride;
+  const int t     = (int)(r < rank - 1 ? r : rank - 1);
+  const int nw    = t / 64 + 1;
+  const int64_t qt = Q[t];  // pivots j <= t sit in columns <= Q[t]
+  for (int w = threadIdx.x; w < nw; w += ROW_THREADS) {
+    word x = 0;
+    const int jend = (w * 64 + 63) < t ? 64 : (t - w * 64 + 1);
+    for (int b = 0; b < jend; ++b) {
+      const int32_t q = Q[w * 64 + b];
+      x |= ((row[q >> 6] >> (q & 63)) & 1) << b;
+    }
+    s_new[w] = x;
+  }
+  __syncthreads();
+  // vacated pivot columns: those in (t, Q[t]]
+  for (int64_t w = threadIdx.x; w <= (qt >> 6) && w < width; w += ROW_THREADS) {
+    word keep = ~(word)0;
+    word pm   = pivmask[w];
+    if (w == (qt >> 6) && (qt & 63) != 63) pm &= (((word)1 << ((qt & 63) + 1)) - 1);  // only pivots <= t, i.e. columns <= Q[t]
+    if (w * 64 + 63 <= t) pm = 0;                                                      // gathered words are rewritten below
+    else if (w * 64 <= t) pm &= ~(word)0 << (t - w * 64 + 1);
+    keep = ~pm;
+    word v = row[w] & keep;
+    if (w < nw) {
+      const int jend = (w * 64 + 63) < t ? 64 : (int)(t - w * 64 + 1);
+      const word gm  = jend == 64 ? ~(word)0 : (((word)1 << jend) - 1);
+      v = (v & ~gm) | (s_new[w] & gm);
+    }
+    row[w] = v;
+  }
+}
+
+// ---- per-device scratch ------------------------------------------------------------------------------------------
+struct Scratch {
+  word *V = nullptr, *Mc = nullptr, *pivmask = nullptr;
+  int32_t *Q = nullptr;
+  PleBlock *blk = nullptr;
+  PleBlock *hblk = nullptr;  // pinned host mirror
+  int64_t rows = 0, cols = 0;
+};
+std::mutex g_ple_mu;
+Scratch g_scratch[16];
+
+int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
+  if (!s.blk) {
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.blk), sizeof(PleBlock)));
+    HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hblk), sizeof(PleBlock), hipHostMallocDefault));
+  }
+  if (nrows > s.rows) {
+    if (s.V) { HIPTRY(hipFree(s.V)); HIPTRY(hipFree(s.Mc)); }
+    s.V = s.Mc = nullptr; s.rows = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.V), (size_t)nrows * 8));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Mc), (size_t)nrows * 8));
+    s.rows = nrows;
+  }
+  if (ncols > s.cols) {
+    if (s.Q) { HIPTRY(hipFree(s.Q)); HIPTRY(hipFree(s.pivmask)); }
+    s.Q = nullptr; s.pivmask = nullptr; s.cols = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Q), (size_t)ncols * 4));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.pivmask), (size_t)words_of(ncols) * 8));
+    s.cols = ncols;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// PLE of the device matrix A (nrows x ncols, bits at column >= ncols zero) in place.  P (nrows entries) and Q
+// (ncols entries) are HOST arrays; returns the rank in *rank_out.  Blocking (reads the pivots back per block).
+int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out, void *stream) {
+  if (nrows < 0 || ncols < 0 || !P || !Q || !rank_out) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < nrows; ++i) P[i] = (int32_t)i;  // ple_russian.c:412-414
+  for (int64_t j = 0; j < ncols; ++j) Q[j] = (int32_t)j;
+  *rank_out = 0;
+  if (nrows == 0 || ncols == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_ple_mu);
+  int dev = 0;
+  HIPTRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  Scratch &s = g_scratch[dev];
+  if (int rc = reserve(s, nrows, ncols)) return rc;
+  const int64_t width = words_of(ncols);
+  int64_t r0 = 0;
+  for (int64_t wb = 0; wb < width && r0 < nrows; ++wb) {
+    const int ncb = (int)((ncols - wb * 64) < 64 ? (ncols - wb * 64) : 64);
+    hipLaunchKernelGGL(ple_slice_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, A, stride, nrows, r0, wb, ncb, s.V, s.blk);
+    HIPTRY(hipGetLastError());
+    HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
+    HIPTRY(hipStreamSynchronize(st));
+    const int rank = s.hblk->rank;
+    if (rank == 0) continue;  // nothing moved: the slice words are unchanged
+    const int64_t below = nrows - r0 - rank;
+    hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
+                       r0, s.blk);
+    hipLaunchKernelGGL(ple_writeback_kernel, dim3((unsigned)((nrows - r0 + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride,
+                       nrows, r0, wb, s.V, s.blk, s.Mc);
+    if (wb + 1 < width) {
+      hipLaunchKernelGGL(ple_reduce_pivot_rows_kernel, dim3((unsigned)((width - wb - 1 + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A,
+                         stride, width, wb, r0, s.V, s.blk);
+      HIPTRY(hipGetLastError());
+      if (below > 0)  // rows below, words to the right: C ^= M * U, inner dimension = the block's rank
+        HIPTRY(m4ri_amd_m4rm_dev(A + (r0 + rank) * stride + wb + 1, stride, s.Mc, 1, A + r0 * stride + wb + 1, stride, below, rank,
+                                 ncols - (wb + 1) * 64, 1, 0, st));
+    }
+    HIPTRY(hipGetLastError());
+    for (int t = 0; t < rank; ++t) {
+      P[r0 + t] = s.hblk->swaprow[t];
+      Q[r0 + t] = (int32_t)(wb * 64 + s.hblk->pivcol[t]);
+    }
+    r0 += rank;
+  }
+  const int rank = (int)r0;
+  *rank_out      = rank;
+  if (rank > 0) {
+    std::vector<word> pm((size_t)width, 0);
+    bool identity = true;
+    for (int j = 0; j < rank; ++j) { pm[(size_t)(Q[j] >> 6)] |= (word)1 << (Q[j] & 63); identity = identity && Q[j] == j; }
+    if (!identity) {  // pivots on the diagonal: L already sits where it belongs
+      HIPTRY(hipMemcpyAsync(s.Q, Q, (size_t)rank * 4, hipMemcpyHostToDevice, st));
+      HIPTRY(hipMemcpyAsync(s.pivmask, pm.data(), (size_t)width * 8, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(ple_compress_kernel, dim3((unsigned)nrows), dim3(ROW_THREADS), (size_t)((rank - 1) / 64 + 1) * 8, st, A, stride, nrows, width,
+                         s.Q, s.pivmask, rank);
+      HIPTRY(hipGetLastError());
+      HIPTRY(hipStreamSynchronize(st));  // pm / Q are host temporaries of this call
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

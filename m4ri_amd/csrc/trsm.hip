@@ -1,0 +1,118 @@
+// trsm.hip -- triangular solves with a matrix right-hand side on the device: B <- L^-1 B (L unit lower
+// triangular) and B <- U^-1 B (U unit upper triangular), the callers of the multiply path one step up
+// (SURVEY.md 8f rank 3).
+//
+// Reference interfaces replaced (same results -- the solution of a triangular system is unique, so any
+// correct schedule is bit-identical):
+//   _mzd_trsm_lower_left / _mzd_trsm_upper_left               /root/reference m4ri/triangular.c:406-455, :467-514
+//   _mzd_trsm_lower_left_russian / _mzd_trsm_upper_left_russian  m4ri/triangular_russian.c:206-330, :50-170
+// The reference recurses on halves with mzd_addmul for the update (triangular.c:437-441, :501-505), solves
+// blocks of <= 2048 rows by a Four-Russians sweep (tables of the rows just solved, one pass over the rows
+// below per 8k pivot rows) and blocks of <= 64 rows by direct substitution.  Here the recursion goes all the
+// way down to 64 rows with the engine's own product for every update (a rank-64 .. rank-n/2 addmul on
+// device-resident views), and the 64-row base is one small kernel: a thread owns one 64-bit word column of B,
+// keeps its 64 words in registers and substitutes; the rows of the triangle are wave-uniform (scalar loads).
+// The diagonal is never read (taken as 1) and neither is the other triangle, exactly like the reference.
+#include <hip/hip_runtime.h>
+#include "gf2_common.h"
+#include "../../include/m4ri_amd.h"
+
+namespace {
+
+#define HIPTRY(expr)                                  \
+  do {                                                \
+    hipError_t e_ = (hipError_t)(expr);               \
+    if (e_ != hipSuccess) return (int)e_;             \
+  } while (0)
+
+constexpr int TRSM_THREADS = 64;
+
+// B (mb x wn words, mb <= 64) <- T^-1 B in place; T's block sits in bits 0..mb-1 of the first word of its rows.
+template <bool UPPER>
+__global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__restrict__ T, int64_t t_stride, word *__restrict__ B,
+                                                                  int64_t b_stride, int mb, int64_t wn, word last_mask) {
+  const int64_t j = (int64_t)blockIdx.x * TRSM_THREADS + threadIdx.x;
+  if (j >= wn) return;
+  word x[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) x[i] = i < mb ? B[(int64_t)i * b_stride + j] : 0;
+  if (!UPPER) {
+#pragma unroll
+    for (int i = 1; i < 64; ++i) {
+      if (i < mb) {
+        const word row = T[(int64_t)i * t_stride];  // wave-uniform
+        word acc       = 0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc ^= ((row >> k) & 1) ? x[k] : 0;
+        x[i] ^= acc;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 62; i >= 0; --i) {
+      if (i < mb - 1) {
+        const word row = T[(int64_t)i * t_stride];
+        word acc       = 0;
+#pragma unroll
+        for (int k = i + 1; k < 64; ++k) acc ^= (k < mb && ((row >> k) & 1)) ? x[k] : 0;
+        x[i] ^= acc;
+      }
+    }
+  }
+  // the last word of a row is merged under the column mask (triangular.c:421, :482): bits beyond B's columns stay
+  const bool last = (j == wn - 1) && last_mask != ~(word)0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i)
+    if (i < mb) {
+      word *p = B + (int64_t)i * b_stride + j;
+      *p      = last ? ((*p & ~last_mask) | (x[i] & last_mask)) : x[i];
+    }
+}
+
+int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb, int64_t nb, int cutoff, hipStream_t st) {
+  if (mb <= 1 || nb <= 0) return 0;
+  if (mb <= 64) {
+    const int64_t wn = words_of(nb);
+    const word mask  = (nb % 64) ? ((~(word)0) >> (64 - nb % 64)) : ~(word)0;
+    const unsigned g = (unsigned)((wn + TRSM_THREADS - 1) / TRSM_THREADS);
+    if (upper) hipLaunchKernelGGL((trsm_base_kernel<true>), dim3(g), dim3(TRSM_THREADS), 0, st, T, ts, B, bs, (int)mb, wn, mask);
+    else       hipLaunchKernelGGL((trsm_base_kernel<false>), dim3(g), dim3(TRSM_THREADS), 0, st, T, ts, B, bs, (int)mb, wn, mask);
+    return (int)hipGetLastError();
+  }
+  // halves on a word boundary of the triangle's columns (triangular.c:428, :492)
+  const int64_t mb1 = (((mb - 1) / 64 + 1) >> 1) * 64;
+  word *B0 = B, *B1 = B + mb1 * bs;
+  const word *T00 = T, *T11 = T + mb1 * ts + mb1 / 64;
+  if (!upper) {
+    const word *L10 = T + mb1 * ts;  // (mb - mb1) x mb1
+    if (int rc = solve(false, T00, ts, B0, bs, mb1, nb, cutoff, st)) return rc;
+    HIPTRY(m4ri_amd_mul_dev(B1, bs, L10, ts, B0, bs, mb - mb1, mb1, nb, 1, cutoff, st));
+    return solve(false, T11, ts, B1, bs, mb - mb1, nb, cutoff, st);
+  }
+  const word *U01 = T + mb1 / 64;    // mb1 x (mb - mb1)
+  if (int rc = solve(true, T11, ts, B1, bs, mb - mb1, nb, cutoff, st)) return rc;
+  HIPTRY(m4ri_amd_mul_dev(B0, bs, U01, ts, B1, bs, mb1, mb - mb1, nb, 1, cutoff, st));
+  return solve(true, T00, ts, B0, bs, mb1, nb, cutoff, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// B (mb x nb bits, stride b_stride) <- L^-1 B, L (mb x mb, stride t_stride) unit lower triangular: only the
+// bits strictly below its diagonal are read.  Device pointers; bits of B at column >= nb must be zero on
+// entry and are zero on return.  Asynchronous on `stream`.
+int m4ri_amd_trsm_lower_left_dev(const word *L, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                 void *stream) {
+  if (mb < 0 || nb < 0 || cutoff < 0) return (int)hipErrorInvalidValue;
+  return solve(false, L, t_stride, B, b_stride, mb, nb, cutoff, (hipStream_t)stream);
+}
+
+// B <- U^-1 B, U unit upper triangular: only the bits strictly above its diagonal are read.
+int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                 void *stream) {
+  if (mb < 0 || nb < 0 || cutoff < 0) return (int)hipErrorInvalidValue;
+  return solve(true, U, t_stride, B, b_stride, mb, nb, cutoff, (hipStream_t)stream);
+}
+
+}  // extern "C"

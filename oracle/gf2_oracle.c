@@ -399,3 +399,89 @@ gf2o_mat *gf2o_addmul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cut
   if (A->nrows == 0 || A->ncols == 0 || B->ncols == 0) return C;
   return gf2o_addmul_even(C, A, B, cutoff);
 }
+
+
+/* ---- triangular solves (m4ri/triangular.c:406-455, :467-514) ----------------------------------------
+ * X_i = B_i + sum_{k<i} L[i,k] X_k (lower) / sum_{k>i} U[i,k] X_k (upper), rows added whole with the last
+ * word under B's column mask (triangular.c:421, :482).  The reference does this only for <= 64 rows and
+ * recurses / uses tables above; the result does not depend on that. */
+static int o_bit(const gf2o_mat *M, int64_t r, int64_t c) { return (int)((M->data[r * M->rowstride + c / 64] >> (c % 64)) & 1); }
+
+static void o_row_add(gf2o_mat *B, int64_t dst, int64_t src) {
+  gf2o_word *d = B->data + dst * B->rowstride;
+  const gf2o_word *s = B->data + src * B->rowstride;
+  for (int64_t j = 0; j + 1 < B->width; ++j) d[j] ^= s[j];
+  if (B->width) d[B->width - 1] ^= s[B->width - 1] & B->high_bitmask;
+}
+
+void gf2o_trsm_lower_left(const gf2o_mat *L, gf2o_mat *B) {
+  for (int64_t i = 1; i < B->nrows; ++i)
+    for (int64_t k = 0; k < i; ++k)
+      if (o_bit(L, i, k)) o_row_add(B, i, k);
+}
+
+void gf2o_trsm_upper_left(const gf2o_mat *U, gf2o_mat *B) {
+  for (int64_t i = (int64_t)B->nrows - 2; i >= 0; --i)
+    for (int64_t k = i + 1; k < B->nrows; ++k)
+      if (o_bit(U, i, k)) o_row_add(B, i, k);
+}
+
+
+/* ---- PLE (m4ri/ple_russian.c:380-617, restated column by column) ------------------------------------- */
+static void o_row_swap(gf2o_mat *A, int64_t a, int64_t b) {
+  if (a == b) return;
+  gf2o_word *x = A->data + a * A->rowstride, *y = A->data + b * A->rowstride;
+  for (int64_t j = 0; j + 1 < A->width; ++j) { gf2o_word t = x[j]; x[j] = y[j]; y[j] = t; }
+  if (A->width) {  /* last word under the column mask (mzd.h: mzd_row_swap masks the last word) */
+    const gf2o_word m = A->high_bitmask, t = (x[A->width - 1] ^ y[A->width - 1]) & m;
+    x[A->width - 1] ^= t; y[A->width - 1] ^= t;
+  }
+}
+
+/* dst ^= src from column `col` to the end (mzd.h: mzd_row_add_offset) */
+static void o_row_add_from(gf2o_mat *A, int64_t dst, int64_t src, int64_t col) {
+  if (col >= A->ncols) return;
+  gf2o_word *d = A->data + dst * A->rowstride;
+  const gf2o_word *s = A->data + src * A->rowstride;
+  int64_t w = col / 64;
+  gf2o_word first = ~(gf2o_word)0 << (col % 64);
+  for (; w < A->width; ++w) {
+    gf2o_word v = s[w] & first;
+    if (w == A->width - 1) v &= A->high_bitmask;
+    d[w] ^= v;
+    first = ~(gf2o_word)0;
+  }
+}
+
+static void o_col_swap_in_row(gf2o_mat *A, int64_t r, int64_t a, int64_t b) {
+  gf2o_word *row = A->data + r * A->rowstride;
+  const gf2o_word x = ((row[a / 64] >> (a % 64)) ^ (row[b / 64] >> (b % 64))) & 1;
+  row[a / 64] ^= x << (a % 64);
+  row[b / 64] ^= x << (b % 64);
+}
+
+int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q) {
+  const int64_t nrows = A->nrows, ncols = A->ncols;
+  for (int64_t i = 0; i < nrows; ++i) P[i] = (int32_t)i;  /* ple_russian.c:412-414 */
+  for (int64_t j = 0; j < ncols; ++j) Q[j] = (int32_t)j;
+  int64_t rank = 0;
+  for (int64_t c = 0; c < ncols && rank < nrows; ++c) {
+    int64_t piv = -1;
+    for (int64_t i = rank; i < nrows; ++i)
+      if (o_bit(A, i, c)) { piv = i; break; }            /* ple_russian.c:141-159: first row with the bit set */
+    if (piv < 0) continue;
+    P[rank] = (int32_t)piv;                              /* :162-166 */
+    Q[rank] = (int32_t)c;
+    o_row_swap(A, piv, rank);
+    for (int64_t r = rank + 1; r < nrows; ++r)
+      if (o_bit(A, r, c)) o_row_add_from(A, r, rank, c + 1);  /* :150, :180-183: the multiplier stays at column c */
+    ++rank;
+  }
+  /* compressing L (:596-602): row r takes the column swaps (j, Q[j]) for j = 0 .. min(r, rank - 1), in order */
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t last = r < rank - 1 ? r : rank - 1;
+    for (int64_t j = 0; j <= last; ++j)
+      if (Q[j] != j) o_col_swap_in_row(A, r, j, Q[j]);
+  }
+  return (int32_t)rank;
+}

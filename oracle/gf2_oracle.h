@@ -65,6 +65,21 @@ gf2o_mat *gf2o_addmul_even(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, in
 gf2o_mat *gf2o_mul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);             /* strassen.c:345-365 */
 gf2o_mat *gf2o_addmul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cutoff);          /* strassen.c:675-700 */
 
+/* triangular solves, B <- T^-1 B in place, T unit triangular (diagonal and other triangle never read):
+ * plain substitution, the base case of m4ri/triangular.c:406-455 (lower) and :467-514 (upper) applied to
+ * the whole matrix -- the solution is unique, so this equals the reference's recursive / Russian schedules */
+void gf2o_trsm_lower_left(const gf2o_mat *L, gf2o_mat *B);
+void gf2o_trsm_upper_left(const gf2o_mat *U, gf2o_mat *B);
+
+/* PLE decomposition in place, the semantics of _mzd_ple_russian (m4ri/ple_russian.c:380-617): columns left
+ * to right, pivot = the first row at or below the current rank position with a set bit in the column after
+ * elimination by the earlier pivots, that row swapped up, rows below cleared from the NEXT column on (the
+ * multipliers stay in the pivot column), then L compressed to the left (ple_russian.c:596-602).  P (nrows
+ * entries) and Q (ncols entries) receive the row / column transpositions in the reference's LAPACK-style
+ * convention.  Returns the rank.  The reference's blocks, tables and lazy updates (ple_russian.c:119-196)
+ * change when row operations happen, never their outcome. */
+int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q);
+
 /* FNV-1a over the valid bits, row-major, excess masked: a size-independent fingerprint used for
  * the large fixtures (the reference's own mzd_hash is unusable: debug_dump.h:35 shifts by data). */
 uint64_t gf2o_fingerprint(const gf2o_mat *A);

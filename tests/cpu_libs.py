@@ -39,6 +39,9 @@ class Oracle:
             "gf2o_fill_splitmix": (None, [MzdPtr, ctypes.c_uint64]),
             "gf2o_fingerprint": (ctypes.c_uint64, [MzdPtr]),
             "gf2o_free": (None, [MzdPtr]),
+            "gf2o_trsm_lower_left": (None, [MzdPtr, MzdPtr]),
+            "gf2o_trsm_upper_left": (None, [MzdPtr, MzdPtr]),
+            "gf2o_ple": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
         }.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
@@ -64,6 +67,21 @@ class Oracle:
         self.L.gf2o_add(C.ptr, A.ptr, B.ptr)
         return C
 
+    def trsm_lower_left(self, L, B):
+        self.L.gf2o_trsm_lower_left(L.ptr, B.ptr)
+        return B
+
+    def trsm_upper_left(self, U, B):
+        self.L.gf2o_trsm_upper_left(U.ptr, B.ptr)
+        return B
+
+    def ple(self, A):
+        """In place; returns (rank, P, Q) as numpy int32 arrays."""
+        import numpy as np
+        P, Q = np.zeros(max(1, A.nrows), dtype=np.int32), np.zeros(max(1, A.ncols), dtype=np.int32)
+        r = self.L.gf2o_ple(A.ptr, P.ctypes.data, Q.ctypes.data)
+        return int(r), P[:A.nrows], Q[:A.ncols]
+
     def fill(self, A, seed):
         self.L.gf2o_fill_splitmix(A.ptr, seed)
 
@@ -72,6 +90,20 @@ class Oracle:
 
     def equal(self, A, B):
         return bool(self.L.gf2o_equal(A.ptr, B.ptr))
+
+
+class Mzp(ctypes.Structure):
+    """The reference's mzp_t (m4ri/mzp.h:37-49): LAPACK-style transpositions."""
+
+    _fields_ = [("values", ctypes.POINTER(ctypes.c_int32)), ("length", ctypes.c_int32)]
+
+
+def mzp_of(arr):
+    """An mzp_t over a numpy int32 array (kept alive by the caller)."""
+    p = Mzp()
+    p.values = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    p.length = len(arr)
+    return p
 
 
 class Reference:
@@ -95,6 +127,13 @@ class Reference:
         for name, (res, args) in table.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        for name in ("mzd_trsm_lower_left", "_mzd_trsm_lower_left", "_mzd_trsm_lower_left_russian",
+                     "mzd_trsm_upper_left", "_mzd_trsm_upper_left", "_mzd_trsm_upper_left_russian"):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = None, [MzdPtr, MzdPtr, _I]
+        for name in ("_mzd_ple_russian", "_mzd_pluq_russian", "mzd_ple", "mzd_pluq"):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = _I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]
         self.has_mp = hasattr(L, "mzd_mul_mp")
         if self.has_mp:
             L.mzd_mul_mp.restype, L.mzd_mul_mp.argtypes = sig4
@@ -125,6 +164,15 @@ class Reference:
     def add(self, C, A, B):
         self.L._mzd_add(C.ptr, A.ptr, B.ptr)
         return C
+
+    def ple(self, A, which="_mzd_ple_russian", k=0):
+        """In place; returns (rank, P, Q)."""
+        import numpy as np
+        P, Q = np.zeros(max(1, A.nrows), dtype=np.int32), np.zeros(max(1, A.ncols), dtype=np.int32)
+        mp, mq = mzp_of(P[:A.nrows] if A.nrows else P), mzp_of(Q[:A.ncols] if A.ncols else Q)
+        mp.length, mq.length = A.nrows, A.ncols
+        r = getattr(self.L, which)(A.ptr, ctypes.byref(mp), ctypes.byref(mq), k)
+        return int(r), P[:A.nrows], Q[:A.ncols]
 
 
 _oracle = None

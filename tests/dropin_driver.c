@@ -70,7 +70,7 @@ static int window_case(rci_t M, rci_t N, rci_t m, rci_t n) {
 static long long interposed_products(void) {
   typedef int (*stats_fn)(void *);
   stats_fn st = (stats_fn)dlsym(RTLD_DEFAULT, "m4ri_amd_get_stats");
-  struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d; } s;
+  struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d, cum_ms; long long cum_launches; } s; /* m4ri_amd_stats */
   return (st && st(&s) == 0) ? s.leaf_launches : -1;
 }
 
@@ -142,7 +142,7 @@ int main(void) {
   status += l4_case(3000, 3000, 512);
   if (interposed_products() >= 0) printf("dropin_driver: the L4 cases ended on an interposed product (%lld leaf launch(es))\n", interposed_products());
   if (st) {
-    struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d; } s;
+    struct { int levels, leaf_launches; long long leaf_products; int lm, ll, ln, r; double a, b, c, d, cum_ms; long long cum_launches; } s; /* m4ri_amd_stats */
     if (st(&s) == 0) printf("dropin_driver: last interposed call used %d leaf launch(es)\n", s.leaf_launches);
   }
   printf(status ? "dropin_driver: FAILED\n" : "dropin_driver: ALL OK\n");

@@ -1,0 +1,80 @@
+"""PLE decomposition on the GPU (include/m4ri_amd.h: mzd_ple / _mzd_ple / _mzd_ple_russian; reference
+m4ri/ple.c:33-171, m4ri/ple_russian.c:380-617) against the oracle's column-by-column PLE, which
+tests/test_ple_oracle.py pins to the reference: decomposed matrix, P, Q and rank, bit for bit."""
+import numpy as np
+import pytest
+
+import m4ri_amd
+from m4ri_amd.mzd import Mzd
+from test_ple_oracle import SHAPES, _make
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert m4ri_amd.lib().m4ri_amd_device_count() >= 1, "no HIP device visible: the gpu tests have nothing to run on"
+    m4ri_amd.init(0)
+
+
+def _same(got, want, Ag, Ao):
+    assert got[0] == want[0], ("rank", got[0], want[0])
+    assert np.array_equal(got[1], want[1]), "P differs"
+    assert np.array_equal(got[2], want[2]), "Q differs"
+    assert np.array_equal(Ag.valid_words(), Ao.valid_words()), "decomposed matrix differs"
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+@pytest.mark.parametrize("kind", ["random", "lowrank", "sparse", "zerocols"])
+def test_ple_matches_oracle(oracle, m, n, kind):
+    A = _make(kind, m, n, 1000 + 7 * m + n)
+    Ao = A.copy()
+    want = oracle.ple(Ao)
+    for which in ("mzd_ple", "_mzd_ple", "_mzd_ple_russian"):
+        Ag = A.copy()
+        _same(m4ri_amd.mzd_ple(Ag, 0, which), want, Ag, Ao)
+
+
+@pytest.mark.parametrize("m,n,kind", [(5000, 5000, "random"), (9000, 3000, "random"), (3000, 9000, "random"), (6000, 6000, "lowrank"),
+                                     (4099, 8200, "zerocols"), (20000, 512, "random"), (70000, 448, "sparse")])
+def test_larger_ple_matches_oracle(oracle, m, n, kind):
+    if kind == "lowrank":
+        X, Y = Mzd.random(m, 1500, 5), Mzd.random(1500, n, 6)
+        A = m4ri_amd.mzd_mul(None, X, Y, 0)
+    else:
+        A = _make(kind, m, n, 77)
+    Ao, Ag = A.copy(), A.copy()
+    want = oracle.ple(Ao)
+    _same(m4ri_amd.mzd_ple(Ag), want, Ag, Ao)
+
+
+def test_ple_on_a_window_keeps_the_parent(oracle):
+    P0 = Mzd.random(900, 1000, 9)
+    for (r0, c0, m, n) in [(10, 64, 500, 333), (0, 0, 900, 130), (100, 128, 64, 64)]:
+        Po, Pg = Mzd(900, 1000, buf=P0.buf.copy()), Mzd(900, 1000, buf=P0.buf.copy())
+        wo, wg = Po.window(r0, c0, r0 + m, c0 + n), Pg.window(r0, c0, r0 + m, c0 + n)
+        want = oracle.ple(wo)
+        got = m4ri_amd.mzd_ple(wg)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        assert np.array_equal(Po.buf, Pg.buf)
+
+
+def test_ple_reconstructs(oracle):
+    """A == P * L * E * Q^T-ish identity through independent pieces: rebuild A from the GPU's decomposition with
+    numpy (the reference's own check in tests/test_ple.c:26-60 does the same with mzd_mul)."""
+    m, n = 300, 420
+    A = Mzd.random(m, n, 31)
+    D = A.copy()
+    r, P, Q = m4ri_amd.mzd_ple(D)
+    d = D.to_bits().astype(np.int64)
+    L = np.zeros((m, m), dtype=np.int64)
+    L[:, :r] = np.tril(d[:, :r], -1)
+    L[np.arange(m), np.arange(m)] = 1
+    E = np.zeros((m, n), dtype=np.int64)
+    for i in range(r):
+        E[i, Q[i]:] = d[i, Q[i]:]
+        E[i, Q[i]] = 1
+    LE = (L @ E) & 1
+    for i in range(r - 1, -1, -1):  # undo the row transpositions: A = P * (L E)
+        LE[[i, P[i]]] = LE[[P[i], i]]
+    assert np.array_equal(LE.astype(np.uint8), A.to_bits())

@@ -1,0 +1,101 @@
+"""Triangular solves on the GPU (include/m4ri_amd.h: mzd_trsm_{lower,upper}_left, their _mzd_ and _russian
+forms, reference m4ri/triangular.c:396-514 and m4ri/triangular_russian.c:50-330) against the oracle's
+substitution (pinned to the reference in test_trsm_oracle.py).  The solution is unique: bit-exact."""
+import numpy as np
+import pytest
+
+import m4ri_amd
+from m4ri_amd.mzd import Mzd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert m4ri_amd.lib().m4ri_amd_device_count() >= 1, "no HIP device visible: the gpu tests have nothing to run on"
+    m4ri_amd.init(0)
+
+
+SHAPES = [(1, 1), (2, 65), (57, 10), (64, 64), (65, 1), (100, 300), (128, 64), (200, 513), (511, 129), (1000, 70), (2049, 200),
+          (2500, 131), (4096, 4096), (3000, 10000)]
+
+
+@pytest.mark.parametrize("mb,nb", SHAPES)
+@pytest.mark.parametrize("upper", [False, True])
+def test_trsm_matches_oracle(oracle, mb, nb, upper):
+    T = Mzd.random(mb, mb, 100 + mb)  # diagonal and the other triangle are junk, never read
+    B = Mzd.random(mb, nb, 200 + nb)
+    want = (oracle.trsm_upper_left if upper else oracle.trsm_lower_left)(T, B.copy())
+    L = m4ri_amd.lib()
+    names = ("mzd_trsm_upper_left", "_mzd_trsm_upper_left", "_mzd_trsm_upper_left_russian") if upper else \
+            ("mzd_trsm_lower_left", "_mzd_trsm_lower_left", "_mzd_trsm_lower_left_russian")
+    for name in names:
+        got = B.copy()
+        getattr(L, name)(T.ptr, got.ptr, 0)
+        assert np.array_equal(got.valid_words(), want.valid_words()), (name, mb, nb)
+
+
+@pytest.mark.parametrize("upper", [False, True])
+def test_trsm_on_windows_keeps_the_parent(oracle, upper):
+    P, Q = Mzd.random(700, 900, 7), Mzd.random(600, 1100, 8)
+    for (mb, nb, c0) in [(300, 333, 64), (130, 65, 128), (513, 700, 0)]:
+        T = P.window(10, 64, 10 + mb, 64 + mb)
+        Qo, Qg = Mzd(600, 1100, buf=Q.buf.copy()), Mzd(600, 1100, buf=Q.buf.copy())
+        bo, bg = Qo.window(5, c0, 5 + mb, c0 + nb), Qg.window(5, c0, 5 + mb, c0 + nb)
+        if upper:
+            oracle.trsm_upper_left(T, bo)
+            m4ri_amd.mzd_trsm_upper_left(T, bg)
+        else:
+            oracle.trsm_lower_left(T, bo)
+            m4ri_amd.mzd_trsm_lower_left(T, bg)
+        assert np.array_equal(Qo.buf, Qg.buf)
+
+
+def test_trsm_on_pinned_matrices(oracle):
+    """The PLE pattern (ple.c:123-126): A01 <- A00^-1 A01, then A11 += A10 * A01, all windows of ONE pinned matrix."""
+    n, r1, n1 = 1500, 640, 704
+    A = Mzd.random(n, n, 51)
+    Ah = A.copy()
+    m4ri_amd.pin(A)
+
+    def blocks(M):
+        return M.window(0, 0, r1, r1), M.window(0, n1, r1, n), M.window(r1, 0, n, r1), M.window(r1, n1, n, n)
+
+    a00, a01, a10, a11 = blocks(A)
+    h00, h01, h10, h11 = blocks(Ah)
+    m4ri_amd.mzd_trsm_lower_left(a00, a01)
+    m4ri_amd.mzd_addmul(a11, a10, a01, 0)
+    oracle.trsm_lower_left(h00, h01)
+    oracle.addmul(h11, h10, h01, 0)
+    m4ri_amd.unpin(A)
+    assert np.array_equal(A.rows(), Ah.rows())
+
+
+def test_large_solve_is_an_inverse(oracle):
+    """16384-row solve against a wide right-hand side: L * X == B through the (independently tested) product."""
+    mb, nb = 16384, 20000
+    rng = Mzd.random(mb, mb, 61)
+    bits_lower = np.tril(np.ones((64, 64), dtype=np.uint8))  # build a clean unit lower triangular L word by word
+    L = Mzd.init(mb, mb)
+    w = rng.valid_words()
+    rows = np.arange(mb)
+    for j in range(L.width):  # word j of row r keeps bits < r - 64 j (all of it when r >= 64 (j + 1)), plus the diagonal
+        keep = np.clip(rows - 64 * j, 0, 64).astype(np.uint64)
+        mask = np.where(keep >= 64, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << keep) - np.uint64(1))
+        diag = np.where((rows // 64) == j, np.uint64(1) << (rows % 64).astype(np.uint64), np.uint64(0))
+        L.valid_words()[:, j] = (w[:, j] & mask) | diag
+    B = Mzd.random(mb, nb, 62)
+    X = B.copy()
+    m4ri_amd.mzd_trsm_lower_left(L, X)
+    assert m4ri_amd.mzd_mul(None, L, X, 0).equal(B)
+    U = Mzd.random(mb, mb, 63)
+    Y = B.copy()
+    m4ri_amd.mzd_trsm_upper_left(U, Y)
+    # U's junk lower triangle must not matter: solve again with it cleared
+    Uc = Mzd.init(mb, mb)
+    for j in range(U.width):
+        keep = np.clip(rows - 64 * j + 1, 0, 64).astype(np.uint64)   # bits <= r - 64 j are at or below the diagonal
+        low = np.where(keep >= 64, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << keep) - np.uint64(1))
+        diag = np.where((rows // 64) == j, np.uint64(1) << (rows % 64).astype(np.uint64), np.uint64(0))
+        Uc.valid_words()[:, j] = (U.valid_words()[:, j] & ~low) | diag
+    assert m4ri_amd.mzd_mul(None, Uc, Y, 0).equal(B)
