@@ -108,6 +108,28 @@ rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
 rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
 rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k);
 
+/* ---- the table primitives of M4RI's elimination routines -----------------------------
+ * mzd_make_table (m4ri/brilliantrussian.h:56, .c:163-211): T[i], i = 1 .. 2^k - 1, = the Gray-code combinations of
+ * rows r .. r+k-1 of M from word c/64 on (first word masked below column c, last word by M's column mask), and
+ * L[ord[i]] = i.  mzd_process_rows{,2..6} (brilliantrussian.h:74-190, .c:213-601): for every row in
+ * [startrow, endrow) the k-bit strip at column startcol is cut into N groups, group t looked up in L_t, and
+ * T_t's row XORed onto the row from word startcol/64 on.  Same bits as the reference for tables made by
+ * mzd_make_table (the k == 1 shortcut of mzd_process_rows, .c:220-296, reads T's row 1 without L). */
+void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L);
+void mzd_process_rows(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T, rci_t const *L);
+void mzd_process_rows2(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1);
+void mzd_process_rows3(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2);
+void mzd_process_rows4(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3);
+void mzd_process_rows5(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3, mzd_t const *T4,
+                       rci_t const *L4);
+void mzd_process_rows6(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3, mzd_t const *T4,
+                       rci_t const *L4, mzd_t const *T5, rci_t const *L5);
+
 /* Allocation used for C == NULL when the process has no libm4ri (standalone use, our tests):
  * same layout rules as mzd_init/mzd_free (mzd.c:142-157,179-185). */
 mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c);
@@ -154,6 +176,14 @@ int m4ri_amd_trsm_lower_left_dev(const word *L, int64_t t_stride, word *B, int64
                                  void *stream);
 int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
                                  void *stream);
+/* Device twins of mzd_process_rowsN / mzd_make_table (elim.hip): streaming, HBM-bound.  kbits[t]: bits of group
+ * t (lowest first); L[t]: 2^kbits[t] table row numbers; idx_scratch: 6 * (stoprow - startrow) int32; jstar: see
+ * elim.hip (all zeros when rows r .. r+k-1 exist).  Asynchronous on `stream`. */
+int m4ri_amd_process_rows_dev(word *M, int64_t stride, int64_t width, int64_t startrow, int64_t stoprow, int64_t startcol, int ntables,
+                              const int32_t *kbits, const word *const *T, const int64_t *t_stride, const int32_t *const *L,
+                              int32_t *idx_scratch, void *stream);
+int m4ri_amd_make_table_dev(const word *M, int64_t m_stride, int64_t m_rows, int64_t ncols, int64_t r, int64_t c, int k, const word *Tin,
+                            word *Tout, int64_t t_stride, const int32_t *jstar, void *stream);
 /* PLE of a device matrix in place (bits at column >= ncols zero in, zero out).  P (nrows entries) and Q (ncols
  * entries) are HOST arrays.  Blocking: the pivots of every 64-column block are read back. */
 int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out, void *stream);

@@ -92,6 +92,15 @@ SYMBOLS = {
     "_mzd_trsm_upper_left_russian": (None, [MzdPtr, MzdPtr, _I]),
     "m4ri_amd_trsm_lower_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
     "m4ri_amd_trsm_upper_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "mzd_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, _P]),
+    "mzd_process_rows": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 1),
+    "mzd_process_rows2": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 2),
+    "mzd_process_rows3": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 3),
+    "mzd_process_rows4": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 4),
+    "mzd_process_rows5": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 5),
+    "mzd_process_rows6": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 6),
+    "m4ri_amd_process_rows_dev": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    "m4ri_amd_make_table_dev": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _I64, _P, _P]),
     "mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "_mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "_mzd_ple_russian": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),

@@ -451,6 +451,124 @@ rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) {  // ple.c:33-39
 rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) { (void)cutoff; return run_ple(A, P, Q); }  // ple.c:62-171
 rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return run_ple(A, P, Q); }           // ple_russian.c:380-617
 
+// ---- the table primitives of the elimination routines (elim.hip) -------------------------
+static word *arena_raw(size_t words) {  // plain words from the staging arena (256-byte granules)
+  word *p = g_arena.base + g_arena.used;
+  g_arena.used += (words + 31) & ~(size_t)31;
+  if (g_arena.used > g_arena.cap) die("m4ri_amd: staging arena overrun (internal error)\n");
+  return p;
+}
+
+// how mzd_process_rowsN cuts the k-bit strip into N groups, lowest bits first (brilliantrussian.c:357-361,
+// :394-398, :440-445, :490-494, :546-552)
+static void split_k(int k, int n, int32_t *kb) {
+  if (n == 1) { kb[0] = k; return; }
+  if (n == 2) { kb[0] = k / 2; kb[1] = k - k / 2; return; }
+  const int rem = k % n;
+  for (int i = 0; i < n; ++i) kb[i] = k / n + ((i < n - 1 && rem >= n - 1 - i) ? 1 : 0);
+}
+
+static void run_process_rows(mzd_t *M, rci_t startrow, rci_t stoprow, rci_t startcol, int k, int nt, mzd_t const *const *T,
+                             rci_t const *const *L) {
+  if (stoprow <= startrow || M->ncols == 0) return;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  int32_t kb[6] = {0, 0, 0, 0, 0, 0};
+  split_k(k, nt, kb);
+  mzd_t W = *M;  // the rows that are touched, as a window of M
+  W.data  = M->data + (int64_t)startrow * M->rowstride;
+  W.nrows = stoprow - startrow;
+  W.flags |= FLAG_WINDOW;
+  size_t need = inout_words(&W) + 64 + (((size_t)3 * (size_t)W.nrows + 31) & ~(size_t)31);
+  for (int t = 0; t < nt; ++t) need += (find_pin(T[t]) ? 0 : dev_words(T[t]->nrows, T[t]->ncols)) + ((((size_t)1 << kb[t]) / 2 + 1 + 31) & ~(size_t)31);
+  arena_reserve(need);
+  InOut io = inout_begin(&W);
+  const word *dT[6];
+  int64_t ts[6];
+  const int32_t *dL[6];
+  for (int t = 0; t < nt; ++t) {
+    const DevMat d = operand(T[t], true);
+    dT[t] = d.p; ts[t] = d.stride;
+    const size_t n = (size_t)1 << kb[t];
+    int32_t *l = reinterpret_cast<int32_t *>(arena_raw(n / 2 + 1));
+    HIPDIE(hipMemcpyAsync(l, L[t], n * 4, hipMemcpyHostToDevice, nullptr));
+    dL[t] = l;
+  }
+  int32_t *idx = reinterpret_cast<int32_t *>(arena_raw((size_t)3 * (size_t)W.nrows));
+  HIPDIE(m4ri_amd_process_rows_dev(io.d.p, io.d.stride, M->width, 0, W.nrows, startcol, nt, kb, dT, ts, dL, idx, nullptr));
+  inout_end(io, &W);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+}
+
+void mzd_process_rows(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T, rci_t const *L) {  // brilliantrussian.c:213
+  run_process_rows(M, startrow, endrow, startcol, k, 1, &T, &L);
+}
+void mzd_process_rows2(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1) {  // :350
+  mzd_t const *T[2] = {T0, T1}; rci_t const *L[2] = {L0, L1};
+  run_process_rows(M, startrow, endrow, startcol, k, 2, T, L);
+}
+void mzd_process_rows3(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2) {  // :386
+  mzd_t const *T[3] = {T0, T1, T2}; rci_t const *L[3] = {L0, L1, L2};
+  run_process_rows(M, startrow, endrow, startcol, k, 3, T, L);
+}
+void mzd_process_rows4(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3) {  // :431
+  mzd_t const *T[4] = {T0, T1, T2, T3}; rci_t const *L[4] = {L0, L1, L2, L3};
+  run_process_rows(M, startrow, endrow, startcol, k, 4, T, L);
+}
+void mzd_process_rows5(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3, mzd_t const *T4,
+                       rci_t const *L4) {  // :481
+  mzd_t const *T[5] = {T0, T1, T2, T3, T4}; rci_t const *L[5] = {L0, L1, L2, L3, L4};
+  run_process_rows(M, startrow, endrow, startcol, k, 5, T, L);
+}
+void mzd_process_rows6(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
+                       rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3, mzd_t const *T4,
+                       rci_t const *L4, mzd_t const *T5, rci_t const *L5) {  // :537
+  mzd_t const *T[6] = {T0, T1, T2, T3, T4, T5}; rci_t const *L[6] = {L0, L1, L2, L3, L4, L5};
+  run_process_rows(M, startrow, endrow, startcol, k, 6, T, L);
+}
+
+void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L) {  // brilliantrussian.c:163-211
+  const int twokay = 1 << k;
+  std::vector<int32_t> jstar((size_t)twokay, 0);
+  L[0] = 0;
+  int js = 0;
+  for (int i = 1; i < twokay; ++i) {
+    L[i ^ (i >> 1)] = i;                                  // ord[i] = the reflected Gray code (graycode.c:31-62)
+    if (r + __builtin_ctz((unsigned)i) >= M->nrows) js = i;  // inc[i-1] = the bit that flips: that row does not exist (:181)
+    jstar[(size_t)i] = js;
+  }
+  if (M->ncols == 0 || c / 64 >= M->width) return;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  mzd_t W = *M;  // the k source rows
+  W.data  = M->data + (int64_t)r * M->rowstride;
+  W.nrows = (r + k <= M->nrows) ? k : (M->nrows > r ? M->nrows - r : 0);
+  W.flags |= FLAG_WINDOW;
+  arena_reserve((find_pin(&W) ? 0 : dev_words(W.nrows, W.ncols)) + dev_words(T->nrows, T->ncols) + (((size_t)twokay / 2 + 1 + 31) & ~(size_t)31) + 64);
+  DevMat dM{};
+  if (W.nrows > 0) dM = operand(&W, true);
+  DevMat dT;
+  dev_alloc(dT, T->nrows, T->ncols);
+  const int64_t home = c / 64, wide = M->width - home;
+  // the table's present content, unmasked (rows whose source row is missing keep it, and T[0] seeds the chain)
+  HIPDIE(hipMemcpy2D(dT.p + home, (size_t)dT.stride * 8, T->data + home, (size_t)T->rowstride * 8, (size_t)wide * 8, (size_t)twokay, hipMemcpyHostToDevice));
+  int32_t *dj = reinterpret_cast<int32_t *>(arena_raw((size_t)twokay / 2 + 1));
+  HIPDIE(hipMemcpyAsync(dj, jstar.data(), (size_t)twokay * 4, hipMemcpyHostToDevice, nullptr));
+  HIPDIE(m4ri_amd_make_table_dev(dM.p, dM.stride, W.nrows, M->ncols, 0, c, k, dT.p, dT.p, dT.stride, dj, nullptr));
+  HIPDIE(hipMemcpy2D(T->data + (int64_t)T->rowstride + home, (size_t)T->rowstride * 8, dT.p + dT.stride + home, (size_t)dT.stride * 8, (size_t)wide * 8,
+                     (size_t)(twokay - 1), hipMemcpyDeviceToHost));
+  HIPDIE(hipDeviceSynchronize());
+}
+
 void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena
   std::lock_guard<std::mutex> lk(g_api_mu);
   int dev = 0;

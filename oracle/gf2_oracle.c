@@ -485,3 +485,56 @@ int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q) {
   }
   return (int32_t)rank;
 }
+
+
+/* ---- elimination table primitives (m4ri/brilliantrussian.c:163-211, :213-601) -------------------------- */
+void gf2o_make_table(const gf2o_mat *M, int32_t r, int32_t c, int k, gf2o_mat *T, int32_t *L) {
+  const int64_t home = c / 64, wide = M->width - home;
+  const gf2o_word mask_end = M->high_bitmask, pure_begin = ~(gf2o_word)0 << (c % 64);
+  const gf2o_word mask_begin = (wide != 1) ? pure_begin : (pure_begin & mask_end);  /* :165-168 */
+  L[0] = 0;
+  for (int32_t i = 1; i < (1 << k); ++i) {
+    int b = 0;
+    while (!((i >> b) & 1)) ++b;                 /* inc[i-1]: the bit in which Gray code i differs from i-1 */
+    L[i ^ (i >> 1)] = i;                         /* ord[i] (graycode.c:31-62: reflected Gray code) */
+    if (r + b >= M->nrows || wide <= 0) continue; /* :181 */
+    gf2o_word *ti = T->data + (int64_t)i * T->rowstride + home;
+    const gf2o_word *ti1 = T->data + (int64_t)(i - 1) * T->rowstride + home;
+    const gf2o_word *m = M->data + (int64_t)(r + b) * M->rowstride + home;
+    for (int64_t j = 0; j < wide; ++j) {
+      gf2o_word x = m[j] ^ ti1[j];
+      if (j == 0) x &= mask_begin;
+      else if (j == wide - 1) x &= mask_end;
+      ti[j] = x;
+    }
+  }
+}
+
+void gf2o_process_rows(gf2o_mat *M, int32_t startrow, int32_t stoprow, int32_t startcol, int k, int nt, const gf2o_mat *const *T,
+                       const int32_t *const *L) {
+  int kb[6];
+  if (nt == 1) kb[0] = k;
+  else if (nt == 2) { kb[0] = k / 2; kb[1] = k - k / 2; }   /* :357-358 */
+  else {
+    const int rem = k % nt;                                 /* :392-398, :438-445, :488-494, :544-552 */
+    for (int i = 0; i < nt; ++i) kb[i] = k / nt + ((i < nt - 1 && rem >= nt - 1 - i) ? 1 : 0);
+  }
+  const int64_t block = startcol / 64;
+  for (int64_t r = startrow; r < stoprow; ++r) {
+    gf2o_word *row = M->data + r * M->rowstride;
+    /* mzd_read_bits(M, r, startcol, k), mzd.h:892-901 */
+    const int spot = startcol % 64, spill = spot + k - 64;
+    gf2o_word bits = spill <= 0 ? (row[block] << -spill) : ((row[block + 1] << (64 - spill)) | (row[block] >> spill));
+    bits >>= (64 - k);
+    int32_t x[6];
+    for (int t = 0; t < nt; ++t) {
+      const gf2o_word bm = kb[t] >= 64 ? ~(gf2o_word)0 : (((gf2o_word)1 << kb[t]) - 1);
+      x[t] = L[t][bits & bm];
+      bits = kb[t] >= 64 ? 0 : bits >> kb[t];
+    }
+    for (int t = 0; t < nt; ++t) {
+      const gf2o_word *tr = T[t]->data + (int64_t)x[t] * T[t]->rowstride;
+      for (int64_t j = block; j < M->width; ++j) row[j] ^= tr[j];
+    }
+  }
+}

@@ -80,6 +80,14 @@ void gf2o_trsm_upper_left(const gf2o_mat *U, gf2o_mat *B);
  * change when row operations happen, never their outcome. */
 int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q);
 
+/* table primitives of the elimination routines: m4ri/brilliantrussian.c:163-211 (mzd_make_table: the Gray-code
+ * chain T[i] = T[i-1] ^ M[r + inc[i-1]], first word masked below column c, last by the column mask, L[ord[i]] = i,
+ * steps whose row does not exist skipped) and :213-601 (mzd_process_rows, 2..6: nt tables, the k-bit strip cut as
+ * the reference cuts it, rows XORed from word startcol/64 on). */
+void gf2o_make_table(const gf2o_mat *M, int32_t r, int32_t c, int k, gf2o_mat *T, int32_t *L);
+void gf2o_process_rows(gf2o_mat *M, int32_t startrow, int32_t stoprow, int32_t startcol, int k, int nt, const gf2o_mat *const *T,
+                       const int32_t *const *L);
+
 /* FNV-1a over the valid bits, row-major, excess masked: a size-independent fingerprint used for
  * the large fixtures (the reference's own mzd_hash is unusable: debug_dump.h:35 shifts by data). */
 uint64_t gf2o_fingerprint(const gf2o_mat *A);

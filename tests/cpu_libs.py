@@ -42,6 +42,8 @@ class Oracle:
             "gf2o_trsm_lower_left": (None, [MzdPtr, MzdPtr]),
             "gf2o_trsm_upper_left": (None, [MzdPtr, MzdPtr]),
             "gf2o_ple": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
+            "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
+            "gf2o_process_rows": (None, [MzdPtr, _I, _I, _I, _I, _I, ctypes.c_void_p, ctypes.c_void_p]),
         }.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
@@ -74,6 +76,15 @@ class Oracle:
     def trsm_upper_left(self, U, B):
         self.L.gf2o_trsm_upper_left(U.ptr, B.ptr)
         return B
+
+    def make_table(self, M, r, c, k, T, L):
+        self.L.gf2o_make_table(M.ptr, r, c, k, T.ptr, L.ctypes.data)
+
+    def process_rows(self, M, startrow, stoprow, startcol, k, Ts, Ls):
+        nt = len(Ts)
+        tp = (MzdPtr * nt)(*[ctypes.pointer(t.struct) for t in Ts])
+        lp = (ctypes.c_void_p * nt)(*[l.ctypes.data for l in Ls])
+        self.L.gf2o_process_rows(M.ptr, startrow, stoprow, startcol, k, nt, tp, lp)
 
     def ple(self, A):
         """In place; returns (rank, P, Q) as numpy int32 arrays."""
