@@ -203,8 +203,8 @@ def measure_leaf_traffic(argv_size, cutoff, timeout_s=240):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="m4ri_amd_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--probe", "--size", str(argv_size),
-               "--cutoff", str(cutoff)]
+        cmd = [exe, "--pmc", counter, "GRBM_GUI_ACTIVE", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--probe",
+               "--size", str(argv_size), "--cutoff", str(cutoff)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("results.db")]
@@ -212,20 +212,32 @@ def measure_leaf_traffic(argv_size, cutoff, timeout_s=240):
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-300:]}"
             db = sqlite3.connect(dbs[0])
             names = dict(db.execute("select id, kernel_name from rocpd_info_kernel_symbol"))
-            ev2k = {ev: names.get(kid, "") for kid, ev in db.execute("select kernel_id, event_id from rocpd_kernel_dispatch")}
+            disp = {ev: (names.get(kid, ""), end - start) for kid, ev, start, end in
+                    db.execute("select kernel_id, event_id, start, end from rocpd_kernel_dispatch")}
             pmc = {pid: nm for pid, nm in db.execute("select id, name from rocpd_info_pmc")}
-            per_dispatch = {}
+            per_dispatch, cycles = {}, {}
             for ev, pid, val in db.execute("select event_id, pmc_id, value from rocpd_pmc_event"):
-                if pmc.get(pid) == counter and "m4rm" in ev2k.get(ev, ""):
+                if "m4rm" not in disp.get(ev, ("", 0))[0]:
+                    continue
+                if pmc.get(pid) == counter:
                     per_dispatch[ev] = per_dispatch.get(ev, 0.0) + val
+                elif pmc.get(pid) == "GRBM_GUI_ACTIVE":
+                    cycles[ev] = max(cycles.get(ev, 0.0), val)
             if not per_dispatch:
                 return None, f"no {counter} rows for a leaf kernel"
-            vals[counter] = max(per_dispatch.values())  # the batched leaf launch (strips, if any, are smaller)
+            ev = max(per_dispatch, key=per_dispatch.get)  # the batched leaf launch (strips, if any, are smaller)
+            vals[counter] = per_dispatch[ev]
+            if ev in cycles and disp[ev][1] > 0:
+                vals["gui_cycles"], vals["profiled_ns"] = cycles[ev], disp[ev][1]
         except Exception as e:  # noqa: BLE001
             return None, f"{counter}: {e!r}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"]}
+    detail = {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"]}
+    if "gui_cycles" in vals:  # the clock the launch really ran at (under the profiler): GRBM_GUI_ACTIVE / duration
+        detail.update({"gui_active_cycles": vals["gui_cycles"], "profiled_launch_ms": vals["profiled_ns"] * 1e-6,
+                       "effective_clock_hz": vals["gui_cycles"] / (vals["profiled_ns"] * 1e-9)})
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, detail
 
 
 def bytes_sched(m, l, n, levels):
@@ -634,6 +646,12 @@ def main():
                         "prices the launch against the LDS-array cycles it needs (DESIGN.md 3.1)",
             },
         }
+        lds = out["roofline"]["lds"]
+        if lds and isinstance(traffic_detail, dict) and traffic_detail.get("gui_active_cycles"):
+            # in cycles the clock drops out: LDS-array cycles the launch needs / cycles it took (same launch, profiled pass)
+            need = lds["bound_ms"] * 1e-3 * PEAK_CLOCK_HZ
+            lds["frac_in_cycles"] = need / traffic_detail["gui_active_cycles"]
+            lds["effective_clock_hz"] = traffic_detail["effective_clock_hz"]
         out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
         if verified is not None:
             out["verified"] = verified

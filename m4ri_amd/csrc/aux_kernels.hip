@@ -671,7 +671,13 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
 // A side, written in the leaf's packed chunk-major form (see winograd_down2_pack_kernel): 512
 // threads own a 32-row x 16-word tile of the great-grandchild grid; each of the 343 outputs goes
 // through a double-buffered LDS transpose (8-byte rows in, 8-byte row pairs of one chunk out).
-constexpr int DP3_ROWS = 32, DP3_W = 16, DP3_PITCH = 34, DP3_THREADS = 512;
+// LDS layout: 32 rows x 32 dwords, the 8-byte column slot of row r XOR-swizzled by (r >> 1) & 15.  A padded
+// pitch (34) made the transposed reads 2-way conflicted: the 16 row pairs a 32-lane read group touches sit
+// 68 dwords apart, i.e. on only 8 distinct banks (SQ_LDS_BANK_CONFLICT = 33 % of the kernel's LDS cycles,
+// profiles/r01d_bench65536_pmc_lds.summary.txt).  With the swizzle the 16 row pairs of one chunk land in 16
+// different slots and the group's two chunks (q even / odd) in the two dwords of a slot: 32 banks, no conflict;
+// the writes (16 lanes = the 16 slots of one row) stay conflict-free and 8-byte aligned.
+constexpr int DP3_ROWS = 32, DP3_W = 16, DP3_PITCH = 32, DP3_THREADS = 512;
 
 template <int ROT>
 __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
@@ -714,9 +720,11 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
       for (int j3 = 0; j3 < 7; ++j3) {
         const int k  = 49 * j1 + 7 * j2 + j3;
         uint32_t *tb = tile[k & 1];
-        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * v) = winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
+            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
         __syncthreads();  // one barrier per output: the other buffer is only rewritten after the next one
-        uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + q], w1 = tb[(r2 + 1) * DP3_PITCH + q];
+        const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);  // rows r2 and r2 + 1 share the swizzle
+        uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + rs], w1 = tb[(r2 + 1) * DP3_PITCH + rs];
         if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
         *reinterpret_cast<uint2 *>(o + (int64_t)k * a4_bs) = make_uint2(w0, w1);
       }

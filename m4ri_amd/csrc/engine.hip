@@ -97,6 +97,8 @@ struct Engine {
   word *apk             = nullptr;  // packed-A scratch of the current call (inside ws)
   size_t apk_words      = 0;
   word *part            = nullptr;  // slabs of split leaf launches (inside ws, PART_SLABS tiles)
+  word *df_pool         = nullptr;  // quarter-size temporaries of depth-first levels: a stack beside the workspace
+  size_t df_cap         = 0, df_used = 0;
   int profiling         = 0;        // 0 off, 1 per call, 2 cumulative over calls (m4ri_amd_set_profiling)
   m4ri_amd_stats stats  = {};
   struct Pending { hipEvent_t e0, e1; long call; };
@@ -556,15 +558,19 @@ int bfs_with_strips(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add,
 // sizes resident; when that does not fit, the TOP level runs depth-first like the reference
 // (strassen.c:111-150, in the product form of winograd_scatter): seven sub-products one after the
 // other, each through this function again with L - 1 levels, three quarter-size temporaries.
-int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) {
+int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, double budget) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
-  if (L == 0 || (double)bfs_words_bound(m, l, n, L) * 8.0 <= workspace_budget(e)) return bfs_with_strips(e, st, C, A, B, add, L);
+  if (L == 0 || (double)bfs_words_bound(m, l, n, L) * 8.0 <= budget) return bfs_with_strips(e, st, C, A, B, add, L);
   const int64_t me = m - m % 2, le = l - l % 128, ne = n - n % 128;  // halves on rows / whole words
   if (me == 0 || le == 0 || ne == 0) return bfs_with_strips(e, st, C, A, B, add, 0);
   const int64_t hm = me / 2, hl = le / 2, hn = ne / 2, wl = hl / 64, wn = hn / 64;
-  word *tmp = nullptr;  // X (hm x hl), Y (hl x hn), P (hm x hn): outside the workspace, which the sub-products re-carve
+  // X (hm x hl), Y (hl x hn), P (hm x hn): from the depth-first stack (outside the workspace, which the sub-products
+  // re-carve); engine_mul reserved it for the whole recursion, so nothing is allocated or synchronised here
   const size_t xw = (size_t)hm * wl, yw = (size_t)hl * wn, pw = (size_t)hm * wn;
-  HIPTRY(hipMalloc(reinterpret_cast<void **>(&tmp), (xw + yw + pw) * 8));
+  const size_t df_mark = e->df_used;
+  if (e->df_used + xw + yw + pw > e->df_cap) return (int)hipErrorOutOfMemory;  // cannot happen: df_words() is the same walk
+  word *tmp = e->df_pool + e->df_used;
+  e->df_used += (xw + yw + pw + 31) & ~(size_t)31;
   DMat X{tmp, hm, hl, wl}, Y{tmp + xw, hl, hn, wn}, P{tmp + xw + yw, hm, hn, wn};
   auto qa = [&](int i, int j) { return dview(A, i * hm, j * hl, hm, hl); };
   auto qb = [&](int i, int j) { return dview(B, i * hl, j * hn, hl, hn); };
@@ -588,7 +594,7 @@ int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) 
       default: rc = xor3v(X, qa(0, 0), qa(1, 0)); if (!rc) rc = xor3v(Y, qb(1, 1), qb(0, 1)); break;
     }
     if (rc) break;
-    rc = product(e, st, P, a, b, false, L - 1);
+    rc = product(e, st, P, a, b, false, L - 1, budget);
     if (rc) break;
     // product j goes to the quadrants winograd_scatter names
     static const int targets[7][4] = {{1, 1, 1, 1}, {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 1, 0, 1}, {0, 1, 1, 1}, {0, 0, 1, 1}};
@@ -599,8 +605,7 @@ int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) 
       touched[q >> 1][q & 1] = true;
     }
   }
-  if (rc == 0) rc = (int)hipStreamSynchronize(st);  // the temporaries go away below
-  (void)hipFree(tmp);
+  e->df_used = df_mark;  // later users of the stack are ordered behind these launches by the stream
   if (rc) return rc;
   // remainder strips of THIS level, by direct (chunked) leaf products like strassen.c:170-204
   if (n > ne) { if ((rc = reserve_apk(e, packed_a_words(m, l, 1)))) return rc;
@@ -612,12 +617,34 @@ int product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L) 
   return 0;
 }
 
+// words of the depth-first stack product() will use for these dimensions: the same decisions, no launches
+size_t df_words(const Engine *e, int64_t m, int64_t l, int64_t n, int L, double budget) {
+  if (L == 0 || (double)bfs_words_bound(m, l, n, L) * 8.0 <= budget) return 0;
+  const int64_t me = m - m % 2, le = l - l % 128, ne = n - n % 128;
+  if (me == 0 || le == 0 || ne == 0) return 0;
+  const int64_t hm = me / 2, hl = le / 2, hn = ne / 2;
+  const size_t here = (((size_t)hm * (hl / 64) + (size_t)hl * (hn / 64) + (size_t)hm * (hn / 64)) + 31) & ~(size_t)31;
+  return here + df_words(e, hm, hl, hn, L - 1, budget);
+}
+
 int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
   if (m == 0 || n == 0) return 0;
   const int L = plan_levels(m, l, n, cutoff);
   e->stats.levels = L;
-  return product(e, st, C, A, B, add, L);
+  // depth-first levels (workspace larger than the device has left) take their temporaries from a grow-only stack
+  // sized here, before the first launch: product() itself never allocates, frees or synchronises
+  const double budget = workspace_budget(e);
+  const size_t need   = df_words(e, m, l, n, L, budget);
+  if (need > e->df_cap) {
+    HIPTRY(hipDeviceSynchronize());
+    if (e->df_pool) HIPTRY(hipFree(e->df_pool));
+    e->df_pool = nullptr; e->df_cap = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&e->df_pool), need * sizeof(word)));
+    e->df_cap = need;
+  }
+  e->df_used = 0;
+  return product(e, st, C, A, B, add, L, budget);
 }
 
 void reset_stats(Engine *e) {
@@ -772,6 +799,8 @@ void m4ri_amd_release_workspace(void) {
   (void)hipFree(e->ws);
   e->ws = nullptr; e->ws_cap = 0; e->ws_used = 0;
   e->apk = nullptr; e->apk_words = 0; e->part = nullptr;
+  if (e->df_pool) (void)hipFree(e->df_pool);
+  e->df_pool = nullptr; e->df_cap = 0; e->df_used = 0;
 }
 
 }  // extern "C"

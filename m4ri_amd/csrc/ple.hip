@@ -11,11 +11,12 @@
 // column by column and tests/test_ple_oracle.py pins it against both reference routines.
 //
 // Schedule here -- right-looking, one 64-column word block at a time, everything on the device:
-//   1. slice kernel (ONE workgroup): the block's word of every remaining row is copied into a dense vector and
-//      eliminated column by column there (64 passes over <= nrows words: the only sequential part) -> the
-//      pivots of the block, the row swaps, and every row's multipliers, left in place in its slice word;
-//   2. the swaps are applied to the other words of the rows; the pivot rows (<= 64) are reduced among
-//      themselves on the words to the right (the reference's A10 step, ple_russian.c:306-325);
+//   1. the block's word of every remaining row is copied into a dense vector; ONE workgroup finds the block's
+//      pivots there column by column (candidates examined 1024 at a time, each reduced on the fly by the pivots
+//      found so far: the only sequential part, and for generic input independent of the row count);
+//   2. the row swaps are applied to the other words; a parallel pass replays the pivots on every row's slice
+//      word (-> multipliers in place); the pivot rows (<= 64) are reduced among themselves on the words to the
+//      right by a 64-row triangular solve (the reference's A10 step, ple_russian.c:306-325);
 //   3. rows below, words to the right:  C ^= M * U  with M = the rows' multipliers (<= 64 bits each) and U the
 //      block's pivot rows -- a rank-<=64 update by the engine's own M4RM leaf (the reference's table steps
 //      _mzd_ple_a11_N / _mzd_process_rows_ple_N, ple_russian_template.h, are this product by seven tables);
@@ -46,57 +47,63 @@ struct PleBlock {
   int32_t rank;
   int32_t pivcol[64];   // column of pivot t inside the block
   int32_t swaprow[64];  // absolute row that was swapped into position r0 + t
+  word vhigh[64];       // pivot t's slice word from the column after its pivot column on
 };
 
-// ---- 1. the block's slice: pivots, swaps, multipliers ------------------------------------------------------
-__global__ __launch_bounds__(SLICE_THREADS) void ple_slice_kernel(const word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0,
-                                                                  int64_t wb, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
+// ---- 0. the block's word of every remaining row -> dense vector -------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void ple_extract_kernel(const word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
+                                                                 word *__restrict__ V) {
+  const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
+  if (i < nrows - r0) V[i] = A[(r0 + i) * stride + wb];
+}
+
+// ---- 1. the block's pivots (ONE workgroup) ---------------------------------------------------------------------------
+// Column by column: the candidates are the rows from the current rank position down, examined 1024 at a time;
+// every thread reduces ITS candidate by the pivots found so far (<= 63 steps on one word, pivots in LDS) and
+// tests the column's bit; the first hit is the pivot (ple_russian.c:141-159 does the same lazily, row by row).
+// Rows are only read here: the full elimination of the slice is a parallel pass afterwards (ple_finish_kernel),
+// replaying the same steps from the original words -- a row's value when pivot l is applied does not depend on
+// when that happens.  For generic input the pivot sits in the first chunk, so the cost is independent of nrows.
+__global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
   __shared__ int s_min;
   __shared__ word s_vp;
-  const int tid   = threadIdx.x;
-  const int64_t n = nrows - r0;  // V[i] <-> row r0 + i
-  for (int64_t i = tid; i < n; i += SLICE_THREADS) V[i] = A[(r0 + i) * stride + wb];
+  __shared__ word s_high[64];  // pivot l from the column after its pivot column on
+  __shared__ int s_col[64];
+  const int tid = threadIdx.x;
   if (tid == 0) s_min = INT_MAX;
   __syncthreads();
-  int rank = 0, cprev = 0;
-  bool have = false;
-  word vp_high = 0;
+  int rank = 0;
   for (int c = 0; c < ncb && rank < n; ++c) {
-    // one pass: finish the previous pivot's elimination on the rows below it, and look for column c's pivot
-    int local = INT_MAX;
-    for (int64_t i = rank + tid; i < n; i += SLICE_THREADS) {
-      word v = V[i];
-      if (have && ((v >> cprev) & 1)) { v ^= vp_high; V[i] = v; }
-      if (((v >> c) & 1) && local == INT_MAX) local = (int)i;
-    }
-    have = false;
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(local, off, 64); local = o < local ? o : local; }
-    if ((tid & 63) == 0 && local != INT_MAX) atomicMin(&s_min, local);
-    __syncthreads();
-    const int p = s_min;
-    __syncthreads();
-    if (p != INT_MAX) {
-      if (tid == 0) {
-        const word vp = V[p];
-        V[p]    = V[rank];
-        V[rank] = vp;
-        s_vp    = vp;
-        s_min   = INT_MAX;
-        out->pivcol[rank]  = c;
-        out->swaprow[rank] = (int32_t)(r0 + p);
-      }
+    int p = INT_MAX;
+    for (int64_t base = rank; base < n; base += SLICE_THREADS) {
+      const int64_t i = base + tid;
+      word v = i < n ? V[i] : 0;
+      for (int l = 0; l < rank; ++l)
+        if ((v >> s_col[l]) & 1) v ^= s_high[l];
+      const bool hit = (v >> c) & 1;
+      const unsigned long long b = __ballot(hit);
+      if (b && (tid & 63) == 0) atomicMin(&s_min, (int)(base + (tid & ~63) + __builtin_ctzll(b)));
       __syncthreads();
-      vp_high = c < 63 ? (s_vp & (~(word)0 << (c + 1))) : 0;  // the pivot row from the NEXT column on
-      cprev   = c;
-      have    = true;
-      ++rank;
+      p = s_min;
+      if (p == (int)i) s_vp = v;  // the thread that examined row p publishes its reduced word
+      __syncthreads();
+      if (p != INT_MAX) break;
     }
+    if (p == INT_MAX) continue;
+    if (tid == 0) {
+      const word vp = s_vp;
+      V[p]    = V[rank];  // the displaced row keeps its original word: it is reduced with everybody else afterwards
+      V[rank] = vp;       // the pivot row's word is final (reduced by the earlier pivots, multipliers in place)
+      s_high[rank] = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
+      s_col[rank]  = c;
+      s_min        = INT_MAX;
+      out->pivcol[rank]  = c;
+      out->swaprow[rank] = (int32_t)(r0 + p);
+      out->vhigh[rank]   = s_high[rank];
+    }
+    __syncthreads();
+    ++rank;
   }
-  if (have)
-    for (int64_t i = rank + tid; i < n; i += SLICE_THREADS) {
-      const word v = V[i];
-      if ((v >> cprev) & 1) V[i] = v ^ vp_high;
-    }
   if (tid == 0) out->rank = rank;
 }
 
@@ -115,36 +122,26 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__rest
   }
 }
 
-// ---- 2b. slice words back into the matrix + the rows' multipliers gathered into `rank` low bits -----------------
-__global__ __launch_bounds__(ROW_THREADS) void ple_writeback_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
-                                                                   const word *__restrict__ V, const PleBlock *__restrict__ blk,
-                                                                   word *__restrict__ Mc) {
+// ---- 2b. the slice eliminated row by row (parallel), written back, multipliers gathered --------------------------------
+// rows below the pivots: replay the block's pivots on the row's word (the multiplier of pivot l is the bit at
+// its column when its turn comes, and stays there); pivot rows already hold their final word.
+// Mc[i - rank]: a row's multipliers in the low `rank` bits; Lc[t]: the same for pivot row t (bits j < t).
+__global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
+                                                                const word *__restrict__ V, const PleBlock *__restrict__ blk,
+                                                                word *__restrict__ Mc, word *__restrict__ Lc) {
   const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;  // V index
   if (i >= nrows - r0) return;
-  const word v = V[i];
+  const int rank = blk->rank;
+  word v = V[i];
+  if (i >= rank)
+    for (int l = 0; l < rank; ++l)
+      if ((v >> blk->pivcol[l]) & 1) v ^= blk->vhigh[l];
   A[(r0 + i) * stride + wb] = v;
-  const int rank = blk->rank;
-  if (i >= rank) {
-    word m = 0;
-    for (int t = 0; t < rank; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
-    Mc[i - rank] = m;
-  }
-}
-
-// ---- 2c. the pivot rows among themselves, words right of the block (ple_russian.c:306-325) ------------------------
-__global__ __launch_bounds__(ROW_THREADS) void ple_reduce_pivot_rows_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wb,
-                                                                           int64_t r0, const word *__restrict__ V,
-                                                                           const PleBlock *__restrict__ blk) {
-  const int64_t w = wb + 1 + (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
-  if (w >= width) return;
-  const int rank = blk->rank;
-  for (int t = 1; t < rank; ++t) {
-    const word mult = V[t];  // wave-uniform
-    word x = A[(r0 + t) * stride + w];
-    for (int j = 0; j < t; ++j)
-      if ((mult >> blk->pivcol[j]) & 1) x ^= A[(r0 + j) * stride + w];
-    A[(r0 + t) * stride + w] = x;
-  }
+  word m = 0;
+  const int lim = i < rank ? (int)i : rank;
+  for (int t = 0; t < lim; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
+  if (i >= rank) Mc[i - rank] = m;
+  else Lc[i] = m;
 }
 
 // ---- 4. compressing L: one workgroup per row ---------------------------------------------------------------------
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_compress_kernel(word *__restr
 
 // ---- per-device scratch ------------------------------------------------------------------------------------------
 struct Scratch {
-  word *V = nullptr, *Mc = nullptr, *pivmask = nullptr;
+  word *V = nullptr, *Mc = nullptr, *Lc = nullptr, *pivmask = nullptr;
   int32_t *Q = nullptr;
   PleBlock *blk = nullptr;
   PleBlock *hblk = nullptr;  // pinned host mirror
@@ -201,6 +198,7 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
   if (!s.blk) {
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.blk), sizeof(PleBlock)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hblk), sizeof(PleBlock), hipHostMallocDefault));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Lc), 64 * 8));
   }
   if (nrows > s.rows) {
     if (s.V) { HIPTRY(hipFree(s.V)); HIPTRY(hipFree(s.Mc)); }
@@ -242,7 +240,10 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
   int64_t r0 = 0;
   for (int64_t wb = 0; wb < width && r0 < nrows; ++wb) {
     const int ncb = (int)((ncols - wb * 64) < 64 ? (ncols - wb * 64) : 64);
-    hipLaunchKernelGGL(ple_slice_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, A, stride, nrows, r0, wb, ncb, s.V, s.blk);
+    const int64_t nleft = nrows - r0;
+    hipLaunchKernelGGL(ple_extract_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
+                       s.V);
+    hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
     HIPTRY(hipGetLastError());
     HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
     HIPTRY(hipStreamSynchronize(st));
@@ -251,12 +252,13 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
     const int64_t below = nrows - r0 - rank;
     hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
                        r0, s.blk);
-    hipLaunchKernelGGL(ple_writeback_kernel, dim3((unsigned)((nrows - r0 + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride,
-                       nrows, r0, wb, s.V, s.blk, s.Mc);
+    hipLaunchKernelGGL(ple_finish_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
+                       s.V, s.blk, s.Mc, s.Lc);
+    HIPTRY(hipGetLastError());
     if (wb + 1 < width) {
-      hipLaunchKernelGGL(ple_reduce_pivot_rows_kernel, dim3((unsigned)((width - wb - 1 + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A,
-                         stride, width, wb, r0, s.V, s.blk);
-      HIPTRY(hipGetLastError());
+      // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular
+      // solve with the <= 64 x 64 triangle of their multipliers
+      HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, st));
       if (below > 0)  // rows below, words to the right: C ^= M * U, inner dimension = the block's rank
         HIPTRY(m4ri_amd_m4rm_dev(A + (r0 + rank) * stride + wb + 1, stride, s.Mc, 1, A + r0 * stride + wb + 1, stride, below, rank,
                                  ncols - (wb + 1) * 64, 1, 0, st));

@@ -19,6 +19,20 @@ from test_golden_oracle import GOLD, load_kats, run_kat
 pytestmark = pytest.mark.gpu
 
 
+def sha_matches(M, op, m, l, n, seed_a, cutoff=0):
+    """SHA-256 of the valid words of host matrix M (row-major, excess masked) against the reference's for the
+    same inputs (tests/golden/sha256.json, make_golden.py --sha): beside the 64-bit FNV fingerprints."""
+    import hashlib
+    import json
+    p = os.path.join(GOLD, "sha256.json")
+    if not os.path.exists(p):
+        return True
+    for e in json.load(open(p)):
+        if (e["op"], e["m"], e["l"], e["n"], e["seed_a"], e["cutoff"]) == (op, m, l, n, seed_a, cutoff):
+            return hashlib.sha256(M.masked().tobytes()).hexdigest() == e["sha256"]
+    return True
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _gpu():
     L = m4ri_amd.lib()
@@ -256,6 +270,7 @@ def test_config3_65536_strassen_properties(oracle):
         z = np.load(xl)
         i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (n, n, n)][0]
         assert oracle.fingerprint(hC) == int(z["fp"][i])
+    assert sha_matches(hC, "mul", n, n, n, 3)
     assert freivalds(oracle, to_host(A, n, n), to_host(B, n, n), hC, n, n, n, 77)
     # different schedule (2 levels, 16384^3 leaves), same bits
     C2 = torch.empty_like(C)
@@ -283,6 +298,7 @@ def test_config5_rectangular_131072(oracle):
         i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (m, l, n)]
         if i:
             assert oracle.fingerprint(hC) == int(z["fp"][i[0]])
+    assert sha_matches(hC, "mul", m, l, n, 5)
     assert freivalds(oracle, to_host(A, m, l), to_host(B, l, n), hC, m, l, n, 78)
 
 
@@ -599,8 +615,10 @@ def test_large_ragged_shapes_vs_reference_fingerprints(oracle):
             m4ri_amd.m4rm_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n)
         else:
             m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=par)
-        assert oracle.fingerprint(to_host(C, m, n)) == int(fp), (str(op), m, l, n)
-        del A, B, C
+        hC = to_host(C, m, n)
+        assert oracle.fingerprint(hC) == int(fp), (str(op), m, l, n)
+        assert sha_matches(hC, str(op), m, l, n, int(sa), par), (str(op), m, l, n)
+        del A, B, C, hC
 
 
 @pytest.mark.parametrize("pinned", [False, True])
@@ -629,3 +647,4 @@ def test_large_windowed_addmul_vs_reference_parent_fingerprint(oracle, pinned):
     got = oracle.fingerprint(Pc)
     assert got == int(z["fp"][0])
     assert got != int(z["fp_reference_on_windows"][0])
+    assert sha_matches(Pc, "window_addmul_parent", A.nrows, A.ncols, B.ncols, 41)
