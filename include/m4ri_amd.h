@@ -13,6 +13,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -129,6 +130,19 @@ void mzd_process_rows5(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, i
 void mzd_process_rows6(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T0, rci_t const *L0, mzd_t const *T1,
                        rci_t const *L1, mzd_t const *T2, rci_t const *L2, mzd_t const *T3, rci_t const *L3, mzd_t const *T4,
                        rci_t const *L4, mzd_t const *T5, rci_t const *L5);
+
+/* ---- matrix I/O formats (pure host code, m4ri/io.h:44-193, io.c:49-357) -----------------
+ * Text rows "[1 1 :...|...]" (64-bit groups, ':' every four entries); a row-major string of '0'/'1'; the JCF sparse
+ * text format ("m n 2", number of non-zeros, then signed 1-based column indices, a negative index starts the next
+ * row); 1-bit grayscale PNG, one pixel per entry, black = 1 (written and parsed directly on zlib: libpng is what the
+ * reference uses, the files are the same).  Matrices returned are allocated like C == NULL results. */
+void mzd_fprint_row(FILE *stream, mzd_t const *M, const rci_t i);
+void mzd_fprint(FILE *stream, mzd_t const *M);
+void mzd_print(mzd_t const *M);
+mzd_t *mzd_from_str(rci_t m, rci_t n, const char *str);
+mzd_t *mzd_from_jcf(const char *fn, int verbose);
+mzd_t *mzd_from_png(const char *fn, int verbose);
+int mzd_to_png(const mzd_t *A, const char *fn, int compression_level, const char *comment, int verbose);
 
 /* Allocation used for C == NULL when the process has no libm4ri (standalone use, our tests):
  * same layout rules as mzd_init/mzd_free (mzd.c:142-157,179-185). */

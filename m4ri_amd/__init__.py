@@ -92,6 +92,13 @@ SYMBOLS = {
     "_mzd_trsm_upper_left_russian": (None, [MzdPtr, MzdPtr, _I]),
     "m4ri_amd_trsm_lower_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
     "m4ri_amd_trsm_upper_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "mzd_fprint_row": (None, [_P, MzdPtr, _I]),
+    "mzd_fprint": (None, [_P, MzdPtr]),
+    "mzd_print": (None, [MzdPtr]),
+    "mzd_from_str": (MzdPtr, [_I, _I, ctypes.c_char_p]),
+    "mzd_from_jcf": (MzdPtr, [ctypes.c_char_p, _I]),
+    "mzd_from_png": (MzdPtr, [ctypes.c_char_p, _I]),
+    "mzd_to_png": (_I, [MzdPtr, ctypes.c_char_p, _I, ctypes.c_char_p, _I]),
     "mzd_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, _P]),
     "mzd_process_rows": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 1),
     "mzd_process_rows2": (None, [MzdPtr, _I, _I, _I, _I] + [MzdPtr, _P] * 2),
@@ -241,6 +248,25 @@ def mzd_ple(A: Mzd, cutoff: int = 0, which: str = "mzd_ple"):
     mq.values, mq.length = Q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), A.ncols
     r = getattr(lib(), which)(A.ptr, ctypes.byref(mp), ctypes.byref(mq), cutoff)
     return int(r), P[:A.nrows], Q[:A.ncols]
+
+
+# ---- I/O formats (reference m4ri/io.h) ---------------------------------------------------------------
+def mzd_from_str(m: int, n: int, s: str) -> Mzd:
+    return from_struct_ptr(lib().mzd_from_str(m, n, s.encode()), lib().m4ri_amd_result_free)
+
+
+def mzd_from_jcf(path: str, verbose: int = 0):
+    r = lib().mzd_from_jcf(os.fsencode(path), verbose)
+    return from_struct_ptr(r, lib().m4ri_amd_result_free) if r else None
+
+
+def mzd_from_png(path: str, verbose: int = 0):
+    r = lib().mzd_from_png(os.fsencode(path), verbose)
+    return from_struct_ptr(r, lib().m4ri_amd_result_free) if r else None
+
+
+def mzd_to_png(A: Mzd, path: str, compression_level: int = -1, comment: str = "", verbose: int = 0) -> int:
+    return int(lib().mzd_to_png(A.ptr, os.fsencode(path), compression_level, comment.encode(), verbose))
 
 
 # ---- device-resident API -------------------------------------------------------------------------

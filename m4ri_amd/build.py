@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libm4ri_amd.so")
-SOURCES = ["m4rm_leaf.hip", "m4rm7_leaf.hip", "m4rm8_leaf.hip", "m4rm8q_leaf.hip", "aux_kernels.hip", "engine.hip", "mzd_api.hip", "multi.hip", "trsm.hip", "ple.hip", "elim.hip"]
+SOURCES = ["m4rm_leaf.hip", "m4rm7_leaf.hip", "m4rm8_leaf.hip", "m4rm8q_leaf.hip", "aux_kernels.hip", "engine.hip", "mzd_api.hip", "multi.hip", "trsm.hip", "ple.hip", "elim.hip", "io.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
 
@@ -55,9 +55,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lz"])
     return LIB
 
 
