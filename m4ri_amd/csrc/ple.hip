@@ -18,9 +18,9 @@
 //      word (-> multipliers in place); the pivot rows (<= 64) are reduced among themselves on the words to the
 //      right by a 64-row triangular solve (the reference's A10 step, ple_russian.c:306-325);
 //   3. rows below, words to the right:  C ^= M * U  with M = the rows' multipliers (<= 64 bits each) and U the
-//      block's pivot rows -- a rank-<=64 update by the engine's own M4RM leaf (the reference's table steps
-//      _mzd_ple_a11_N / _mzd_process_rows_ple_N, ple_russian_template.h, are this product by seven tables);
-//      it streams the trailing matrix once per 64 columns: HBM-bound;
+//      block's pivot rows -- a rank-<=64 update by a streaming kernel with sixteen 4-bit tables per column tile in
+//      LDS (the reference's table steps _mzd_ple_a11_N / _mzd_process_rows_ple_N, ple_russian_template.h, are this
+//      product by seven 8-bit tables); it reads and writes the trailing matrix once per 64 columns: HBM-bound;
 //   4. after the last block one gather pass compresses L (closed form of ple_russian.c:596-602: row r takes
 //      new[j] = old[Q[j]] for j <= min(r, rank - 1) and zeros at the vacated pivot columns).
 // The host only reads back the block's pivots (a few hundred bytes per 64 columns).
@@ -69,7 +69,10 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   __shared__ word s_vp;
   __shared__ word s_high[64];  // pivot l from the column after its pivot column on
   __shared__ int s_col[64];
-  const int tid = threadIdx.x;
+  __shared__ word s_head[SLICE_THREADS + 64];  // the first 1088 slice words: every candidate of the usual case (pivot in the
+  const int tid = threadIdx.x;                 // first chunk), read from LDS instead of a global load per column
+  const int nhead = (int)(n < SLICE_THREADS + 64 ? n : SLICE_THREADS + 64);
+  for (int i = tid; i < nhead; i += SLICE_THREADS) s_head[i] = V[i];
   if (tid == 0) s_min = INT_MAX;
   __syncthreads();
   int rank = 0;
@@ -77,9 +80,13 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
     int p = INT_MAX;
     for (int64_t base = rank; base < n; base += SLICE_THREADS) {
       const int64_t i = base + tid;
-      word v = i < n ? V[i] : 0;
-      for (int l = 0; l < rank; ++l)
-        if ((v >> s_col[l]) & 1) v ^= s_high[l];
+      word v = i < nhead ? s_head[i] : (i < n ? V[i] : 0);
+#pragma unroll 8
+      for (int l = 0; l < rank; ++l) {  // the pivots do not depend on v: unrolled, their LDS reads run ahead of the ALU chain
+        const word h = s_high[l];
+        const int pc = s_col[l];
+        v ^= ((v >> pc) & 1) ? h : 0;
+      }
       const bool hit = (v >> c) & 1;
       const unsigned long long b = __ballot(hit);
       if (b && (tid & 63) == 0) atomicMin(&s_min, (int)(base + (tid & ~63) + __builtin_ctzll(b)));
@@ -92,8 +99,11 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
     if (p == INT_MAX) continue;
     if (tid == 0) {
       const word vp = s_vp;
-      V[p]    = V[rank];  // the displaced row keeps its original word: it is reduced with everybody else afterwards
+      const word vr = rank < nhead ? s_head[rank] : V[rank];
+      V[p]    = vr;       // the displaced row keeps its original word: it is reduced with everybody else afterwards
       V[rank] = vp;       // the pivot row's word is final (reduced by the earlier pivots, multipliers in place)
+      if (p < nhead) s_head[p] = vr;
+      if (rank < nhead) s_head[rank] = vp;
       s_high[rank] = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
       s_col[rank]  = c;
       s_min        = INT_MAX;
@@ -142,6 +152,62 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
   for (int t = 0; t < lim; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
   if (i >= rank) Mc[i - rank] = m;
   else Lc[i] = m;
+}
+
+// ---- 3. rows below, words to the right: C ^= M * U, inner dimension <= 64 -----------------------------------------------
+// The trailing matrix is read and written once per 64 pivot columns: a streaming kernel, bounded by HBM (the
+// C-stationary multiply leaf is built for inner dimensions of thousands and reaches a tenth of the bandwidth
+// here).  A workgroup owns a tile of RU_TW words x RU_ROWS rows.  It first builds sixteen 4-bit tables of its
+// column tile from the (<= 64) pivot rows -- 16 x 16 entries x 128 B = 32 KiB of LDS, four workgroups per CU --
+// then streams its rows: 8 lanes per row, 16 bytes each, sixteen ds_read_b128 lookups per chunk (the reference's
+// _mzd_process_rows_ple_N does the same with seven 8-bit tables per 56 columns, ple_russian_template.h).
+constexpr int RU_TW = 16, RU_ROWS = 2048, RU_THREADS = 256;
+typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
+
+// C, U point at word column `wfirst` (even: 16-byte accesses) of the rows; words < skip_below (the block's own word when the
+// tile origin had to be rounded down to stay aligned) take no update.
+template <bool VEC>
+__global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__restrict__ C, int64_t c_stride, const word *__restrict__ M,
+                                                                     const word *__restrict__ U, int64_t u_stride, int64_t rows, int64_t wn,
+                                                                     int rank, int skip_below) {
+  __shared__ __attribute__((aligned(16))) word tab[16][16][RU_TW];  // [table][entry][word]
+  const int tid      = threadIdx.x;
+  const int64_t w0   = (int64_t)blockIdx.x * RU_TW;
+  const int64_t r_lo = (int64_t)blockIdx.y * RU_ROWS;
+  const int64_t r_hi = (r_lo + RU_ROWS) < rows ? (r_lo + RU_ROWS) : rows;
+  const int tw       = (int)((wn - w0) < RU_TW ? (wn - w0) : RU_TW);
+  // tables: entry e of table t = XOR of pivot rows 4t + b for the bits b of e (rows >= rank count as zero)
+  {
+    const int t = tid >> 4, e = tid & 15;
+    for (int w = 0; w < RU_TW; ++w) {
+      word x = 0;
+      if (w < tw && (w0 + w) >= skip_below)
+        for (int b = 0; b < 4; ++b)
+          if (((e >> b) & 1) && (4 * t + b) < rank) x ^= U[(int64_t)(4 * t + b) * u_stride + w0 + w];
+      tab[t][e][w] = x;
+    }
+  }
+  __syncthreads();
+  const int lane8 = tid & 7;           // 16-byte chunk of the 128-byte tile row
+  const int rsub  = tid >> 3;          // 32 rows per sweep
+  const bool two  = (2 * lane8 + 1) < tw, one = (2 * lane8) < tw;
+  const int ntab  = (rank + 3) >> 2;
+  if (!one) return;
+  for (int64_t r = r_lo + rsub; r < r_hi; r += RU_THREADS / 8) {
+    const word m = M[r];
+    word *cp     = C + r * c_stride + w0 + 2 * lane8;
+    word x0, x1;
+    if (VEC && two) { const word2 c = *reinterpret_cast<const word2 *>(cp); x0 = c.x; x1 = c.y; }
+    else { x0 = cp[0]; x1 = two ? cp[1] : 0; }
+#pragma unroll 4
+    for (int t = 0; t < ntab; ++t) {
+      const word2 v = *reinterpret_cast<const word2 *>(&tab[t][(m >> (4 * t)) & 15][2 * lane8]);
+      x0 ^= v.x;
+      x1 ^= v.y;
+    }
+    if (VEC && two) { word2 c; c.x = x0; c.y = x1; *reinterpret_cast<word2 *>(cp) = c; }
+    else { cp[0] = x0; if (two) cp[1] = x1; }
+  }
 }
 
 // ---- 4. compressing L: one workgroup per row ---------------------------------------------------------------------
@@ -259,9 +325,20 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
       // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular
       // solve with the <= 64 x 64 triangle of their multipliers
       HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, st));
-      if (below > 0)  // rows below, words to the right: C ^= M * U, inner dimension = the block's rank
-        HIPTRY(m4ri_amd_m4rm_dev(A + (r0 + rank) * stride + wb + 1, stride, s.Mc, 1, A + r0 * stride + wb + 1, stride, below, rank,
-                                 ncols - (wb + 1) * 64, 1, 0, st));
+      if (below > 0) {  // rows below, words to the right: C ^= M * U, inner dimension = the block's rank
+        const bool vec      = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
+        const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
+        const int64_t wn     = width - wfirst;
+        const int skip       = (int)(wb + 1 - wfirst);
+        const dim3 grid((unsigned)((wn + RU_TW - 1) / RU_TW), (unsigned)((below + RU_ROWS - 1) / RU_ROWS));
+        if (vec)
+          hipLaunchKernelGGL((ple_rank_update_kernel<true>), grid, dim3(RU_THREADS), 0, st, A + (r0 + rank) * stride + wfirst, stride, s.Mc,
+                             A + r0 * stride + wfirst, stride, below, wn, rank, skip);
+        else
+          hipLaunchKernelGGL((ple_rank_update_kernel<false>), grid, dim3(RU_THREADS), 0, st, A + (r0 + rank) * stride + wfirst, stride, s.Mc,
+                             A + r0 * stride + wfirst, stride, below, wn, rank, skip);
+        HIPTRY(hipGetLastError());
+      }
     }
     HIPTRY(hipGetLastError());
     for (int t = 0; t < rank; ++t) {
