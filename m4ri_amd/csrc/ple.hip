@@ -58,9 +58,9 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_extract_kernel(const word *__
 }
 
 // ---- 1. the block's pivots (ONE workgroup) ---------------------------------------------------------------------------
-// Column by column: the candidates are the rows from the current rank position down, examined 1024 at a time;
-// every thread reduces ITS candidate by the pivots found so far (<= 63 steps on one word, pivots in LDS) and
-// tests the column's bit; the first hit is the pivot (ple_russian.c:141-159 does the same lazily, row by row).
+// Column by column: the candidates are the rows from the current rank position down; the first 1024 of them live
+// in the lanes of the workgroup, already reduced by the pivots found so far (see "the window" below); the first lane
+// whose bit in the column is set holds the pivot (ple_russian.c:141-159 does the same lazily, row by row).
 // Rows are only read here: the full elimination of the slice is a parallel pass afterwards (ple_finish_kernel),
 // replaying the same steps from the original words -- a row's value when pivot l is applied does not depend on
 // when that happens.  For generic input the pivot sits in the first chunk, so the cost is independent of nrows.
@@ -69,34 +69,54 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   __shared__ word s_vp;
   __shared__ word s_high[64];  // pivot l from the column after its pivot column on
   __shared__ int s_col[64];
-  __shared__ word s_head[SLICE_THREADS + 64];  // the first 1088 slice words: every candidate of the usual case (pivot in the
-  const int tid = threadIdx.x;                 // first chunk), read from LDS instead of a global load per column
+  __shared__ word s_head[SLICE_THREADS + 64];  // the ORIGINAL words of the first 1088 rows, kept in step with the swaps
+  __shared__ word s_shift[SLICE_THREADS];      // the window moving one lane to the left
+  __shared__ int s_cnt[SLICE_THREADS];
+  const int tid   = threadIdx.x;
   const int nhead = (int)(n < SLICE_THREADS + 64 ? n : SLICE_THREADS + 64);
   for (int i = tid; i < nhead; i += SLICE_THREADS) s_head[i] = V[i];
   if (tid == 0) s_min = INT_MAX;
   __syncthreads();
-  int rank = 0;
+  // The window: lane t watches row rank + t and holds its word reduced by the first `cnt` pivots.  A new pivot costs
+  // the up-to-date lanes ONE step; then the window moves one lane to the left (the row the pivot displaced takes
+  // the pivot's place) and a fresh row enters at the top lane, stale (cnt = 0) -- it catches up only if a column
+  // ever has no hit among the up-to-date lanes, which for generic input never happens within a block.
+  word v  = tid < nhead ? s_head[tid] : 0;
+  int cnt = 0, rank = 0;
   for (int c = 0; c < ncb && rank < n; ++c) {
     int p = INT_MAX;
-    for (int64_t base = rank; base < n; base += SLICE_THREADS) {
-      const int64_t i = base + tid;
-      word v = i < nhead ? s_head[i] : (i < n ? V[i] : 0);
-#pragma unroll 8
-      for (int l = 0; l < rank; ++l) {  // the pivots do not depend on v: unrolled, their LDS reads run ahead of the ALU chain
-        const word h = s_high[l];
-        const int pc = s_col[l];
-        v ^= ((v >> pc) & 1) ? h : 0;
+    for (int pass = 0; pass < 2 && p == INT_MAX; ++pass) {
+      const bool valid = (int64_t)rank + tid < n;
+      if (pass == 1) {
+        const bool stale = valid && cnt < rank;
+        if (!__syncthreads_or(stale)) break;  // nobody to catch up: the window has no pivot for this column
+        if (stale) {
+          for (int l = cnt; l < rank; ++l) v ^= ((v >> s_col[l]) & 1) ? s_high[l] : 0;
+          cnt = rank;
+        }
       }
-      const bool hit = (v >> c) & 1;
+      const bool hit = valid && cnt == rank && ((v >> c) & 1);
       const unsigned long long b = __ballot(hit);
+      if (b && (tid & 63) == 0) atomicMin(&s_min, rank + (tid & ~63) + (int)__builtin_ctzll(b));
+      __syncthreads();
+      p = s_min;
+      if (p == rank + tid) s_vp = v;  // the lane that holds row p publishes its reduced word
+      __syncthreads();
+    }
+    // rows beyond the window: from their original words, all pivots replayed (ple_russian.c:141-159 walks on lazily too)
+    for (int64_t base = (int64_t)rank + SLICE_THREADS; p == INT_MAX && base < n; base += SLICE_THREADS) {
+      const int64_t i = base + tid;
+      word x = i < nhead ? s_head[i] : (i < n ? V[i] : 0);
+#pragma unroll 8
+      for (int l = 0; l < rank; ++l) x ^= ((x >> s_col[l]) & 1) ? s_high[l] : 0;
+      const unsigned long long b = __ballot((x >> c) & 1);
       if (b && (tid & 63) == 0) atomicMin(&s_min, (int)(base + (tid & ~63) + __builtin_ctzll(b)));
       __syncthreads();
       p = s_min;
-      if (p == (int)i) s_vp = v;  // the thread that examined row p publishes its reduced word
+      if (p == (int)i) s_vp = x;
       __syncthreads();
-      if (p != INT_MAX) break;
     }
-    if (p == INT_MAX) continue;
+    if (p == INT_MAX) continue;  // no pivot in this column
     if (tid == 0) {
       const word vp = s_vp;
       const word vr = rank < nhead ? s_head[rank] : V[rank];
@@ -112,6 +132,25 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
       out->vhigh[rank]   = s_high[rank];
     }
     __syncthreads();
+    // the window takes the pivot and moves on
+    const int pl = p - rank;  // lane that held the pivot row (>= SLICE_THREADS: it came from beyond the window)
+    if (cnt == rank) {
+      if (tid != pl) v ^= ((v >> c) & 1) ? s_high[rank] : 0;
+      cnt = rank + 1;
+    }
+    s_shift[tid] = v;
+    s_cnt[tid]   = cnt;
+    __syncthreads();
+    if (tid == 0 && pl > 0 && pl < SLICE_THREADS) { s_shift[pl] = v; s_cnt[pl] = cnt; }  // the displaced row sits where the pivot was
+    __syncthreads();
+    if (tid + 1 < SLICE_THREADS) {
+      v   = s_shift[tid + 1];
+      cnt = s_cnt[tid + 1];
+    } else {  // the row entering the window: original word, no pivot applied yet
+      const int64_t i = (int64_t)rank + 1 + tid;
+      v   = i < nhead ? s_head[i] : (i < n ? V[i] : 0);
+      cnt = 0;
+    }
     ++rank;
   }
   if (tid == 0) out->rank = rank;
@@ -193,20 +232,39 @@ __global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__res
   const bool two  = (2 * lane8 + 1) < tw, one = (2 * lane8) < tw;
   const int ntab  = (rank + 3) >> 2;
   if (!one) return;
-  for (int64_t r = r_lo + rsub; r < r_hi; r += RU_THREADS / 8) {
-    const word m = M[r];
-    word *cp     = C + r * c_stride + w0 + 2 * lane8;
-    word x0, x1;
-    if (VEC && two) { const word2 c = *reinterpret_cast<const word2 *>(cp); x0 = c.x; x1 = c.y; }
-    else { x0 = cp[0]; x1 = two ? cp[1] : 0; }
-#pragma unroll 4
-    for (int t = 0; t < ntab; ++t) {
-      const word2 v = *reinterpret_cast<const word2 *>(&tab[t][(m >> (4 * t)) & 15][2 * lane8]);
-      x0 ^= v.x;
-      x1 ^= v.y;
+  // four rows per trip: their loads are issued together (one row in flight per lane leaves HBM mostly idle)
+  constexpr int RSTEP = RU_THREADS / 8, UNR = 4;
+  for (int64_t rb = r_lo + rsub; rb < r_hi; rb += (int64_t)RSTEP * UNR) {
+    word m[UNR], x0[UNR], x1[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t r = rb + (int64_t)u * RSTEP;
+      m[u] = 0; x0[u] = 0; x1[u] = 0;
+      if (r < r_hi) {
+        m[u]          = M[r];
+        const word *cp = C + r * c_stride + w0 + 2 * lane8;
+        if (VEC && two) { const word2 c = *reinterpret_cast<const word2 *>(cp); x0[u] = c.x; x1[u] = c.y; }
+        else { x0[u] = cp[0]; x1[u] = two ? cp[1] : 0; }
+      }
     }
-    if (VEC && two) { word2 c; c.x = x0; c.y = x1; *reinterpret_cast<word2 *>(cp) = c; }
-    else { cp[0] = x0; if (two) cp[1] = x1; }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll 4
+      for (int t = 0; t < ntab; ++t) {
+        const word2 v = *reinterpret_cast<const word2 *>(&tab[t][(m[u] >> (4 * t)) & 15][2 * lane8]);
+        x0[u] ^= v.x;
+        x1[u] ^= v.y;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t r = rb + (int64_t)u * RSTEP;
+      if (r < r_hi) {
+        word *cp = C + r * c_stride + w0 + 2 * lane8;
+        if (VEC && two) { word2 c; c.x = x0[u]; c.y = x1[u]; *reinterpret_cast<word2 *>(cp) = c; }
+        else { cp[0] = x0[u]; if (two) cp[1] = x1[u]; }
+      }
+    }
   }
 }
 

@@ -238,8 +238,49 @@ def sha256_large():
     print("sha256.json:", len(out), "entries")
 
 
+PLE_CASES = [("random", 16384, 16384, 51), ("random", 32768, 32768, 52), ("random", 40000, 9000, 53), ("random", 9000, 40000, 54),
+             ("lowrank", 20000, 30000, 55), ("zerocols", 12000, 12000, 56)]
+TRSM_CASES = [(False, 16384, 20000, 61), (True, 16384, 20000, 62), (False, 30000, 4100, 63), (True, 5000, 70000, 64)]
+
+
+def ple_input(kind, m, n, seed):
+    A = Mzd.random(m, n, seed)
+    if kind == "lowrank":
+        A = ref.mul(None, Mzd.random(m, 5000, seed + 100), Mzd.random(5000, n, seed + 200), 0)
+    elif kind == "zerocols":
+        w = A.valid_words()
+        w[:, :3] = 0                      # three leading all-zero word columns: the first pivots sit at column 192
+        w[:, 40:42] = 0
+    return A
+
+
+def solver_fixtures():
+    """mzd_ple and mzd_trsm_{lower,upper}_left of the real reference at sizes where it recurses (ple.c:62-171,
+    triangular.c:406-514): SHA-256 over the result's valid words (PLE: followed by P and Q as int32) -> solvers.json"""
+    import hashlib
+    import json
+    out = []
+    for kind, m, n, seed in PLE_CASES:
+        A = ple_input(kind, m, n, seed)
+        t = time.time()
+        r, P, Q = ref.ple(A, "mzd_ple")
+        h = hashlib.sha256(A.masked().tobytes() + P.astype(np.int32).tobytes() + Q.astype(np.int32).tobytes()).hexdigest()
+        out.append({"what": "ple", "kind": kind, "m": m, "n": n, "seed": seed, "rank": r, "sha256": h})
+        print("ple", kind, m, n, r, h[:16], f"{time.time() - t:.1f}s", flush=True)
+    for upper, mb, nb, seed in TRSM_CASES:
+        T, B = Mzd.random(mb, mb, seed), Mzd.random(mb, nb, seed + 1000)
+        t = time.time()
+        (ref.L.mzd_trsm_upper_left if upper else ref.L.mzd_trsm_lower_left)(T.ptr, B.ptr, 0)
+        h = hashlib.sha256(B.masked().tobytes()).hexdigest()
+        out.append({"what": "trsm_upper" if upper else "trsm_lower", "m": mb, "n": nb, "seed": seed, "sha256": h})
+        print("trsm", upper, mb, nb, h[:16], f"{time.time() - t:.1f}s", flush=True)
+    json.dump(out, open(os.path.join(HERE, "solvers.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if "--sha" in sys.argv:
+    if "--solvers" in sys.argv:
+        solver_fixtures()
+    elif "--sha" in sys.argv:
         sha256_large()
     elif "--window-xl" in sys.argv:
         fingerprint_window_xl()
