@@ -154,10 +154,10 @@ def cpu_baseline(n_workload: int, budget_s: float = 75.0):
 # ---------------------------------------------------------------------------------------------------
 # models and measurements around the number
 # ---------------------------------------------------------------------------------------------------
-LEAF_KERNELS = {1: "m4rm_leaf_kernel", 2: "m4rm7_kernel", 3: "m4rm8_kernel", 4: "m4rm8q_kernel"}
+LEAF_KERNELS = {1: "m4rm_leaf_kernel", 3: "m4rm8_kernel", 4: "m4rm8q_kernel"}
 # (tile rows, tile columns, inner bits per stage, LDS-array clocks per stage): gathers at 256 B/clk/CU
 # + table writes at 128 B/clk/CU, both measured with tools/ubench.hip
-LEAF_LDS_MODEL = {2: (1024, 2048, 14, 2560), 3: (2048, 1024, 16, 2560), 4: (4096, 512, 32, 4608)}
+LEAF_LDS_MODEL = {3: (2048, 1024, 16, 2560), 4: (4096, 512, 32, 4608)}
 CU_COUNT, PEAK_CLOCK_HZ = 256, 2.4e9
 
 

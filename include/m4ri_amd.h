@@ -214,7 +214,7 @@ typedef struct m4ri_amd_stats {
   int32_t leaf_launches;    /* kernel launches of the M4RM leaf                     */
   int64_t leaf_products;    /* products those launches computed (batch members)     */
   int32_t leaf_m, leaf_l, leaf_n; /* shape of the batched leaves                     */
-  int32_t leaf_gen;         /* generation of the leaf kernel used: 1 m4rm_leaf, 2 m4rm7,
+  int32_t leaf_gen;         /* generation of the leaf kernel used: 1 m4rm_leaf,
                                3 m4rm8, 4 m4rm8q                                     */
   double leaf_ms;           /* sum of leaf launch durations (profiling on), else 0  */
   double leaf_bytes;        /* algorithmic bytes of the leaf launches:

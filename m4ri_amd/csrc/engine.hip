@@ -27,8 +27,6 @@
 
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
-hipError_t gf2_launch_m4rm7(hipStream_t stream, LeafArgs a, word *a7_ws, int rg, int ug, int pipe);
-hipError_t gf2_launch_a7_pack(hipStream_t stream, LeafArgs a, word *a7_ws);
 hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
@@ -44,7 +42,6 @@ hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, in
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
 int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
-int64_t gf2_m4rm7_a7_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
                                     int64_t p_bs, word *child, int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_up(hipStream_t s, int acc, const word *prod, word *parent, int64_t o_stride,
@@ -155,14 +152,14 @@ hipEvent_t take_event(Engine *e) {
 }
 
 // ---- leaf launch ------------------------------------------------------------------------------
-// Four generations of the leaf kernel exist (m4rm8q / m4rm8 / m4rm7 / m4rm_leaf); they differ in tile
-// shape (4096x512, 2048x1024, 1024x2048 and shorter) and in measured throughput on full tiles
-// (8192^3 batches: 6.7 / 5.3 / 4.7 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time
-// on padded rows.
+// Three leaf kernels (m4rm8q = generation 4, m4rm8 = generation 3, m4rm_leaf = generation 1; the k = 7
+// generation 2 was retired in round 2: generation 1 serves its 1024-row tiles 13 % slower and needs no packed A);
+// they differ in tile shape (4096x512, 2048x1024, 1024x2048 and shorter) and in measured throughput on full tiles
+// (8192^3 batches: 6.7 / 5.3 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time on padded rows.
 struct LeafKind { int gen; int rg; int rows; double rate; };
-const LeafKind LEAF_KINDS[6] = {{4, 32, 4096, 6.7}, {3, 32, 2048, 5.3}, {2, 32, 1024, 4.7},
+const LeafKind LEAF_KINDS[5] = {{4, 32, 4096, 6.7}, {3, 32, 2048, 5.3},
                                 {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
-constexpr int LEAF_KIND_FALLBACK = 3;  // generation 1, 1024 rows: needs no packed A
+constexpr int LEAF_KIND_FALLBACK = 2;  // generation 1, 1024 rows: needs no packed A
 
 LeafKind pick_leaf(int64_t m) {
   LeafKind best = LEAF_KINDS[LEAF_KIND_FALLBACK];
@@ -177,14 +174,13 @@ LeafKind pick_leaf(int64_t m) {
 
 // words of packed-A scratch a leaf launch of this shape may need (max over the packed kernels)
 size_t packed_a_words(int64_t m, int64_t l, int64_t batch) {
-  const size_t a = (size_t)gf2_m4rm7_a7_words(m, l, batch), b = (size_t)gf2_m4rm8_a4_words(m, l, batch);
-  return a > b ? a : b;
+  return (size_t)gf2_m4rm8_a4_words(m, l, batch);
 }
 
 // can a leaf launch of this shape use the packed-A kernel `kind` with the scratch the engine holds?
 bool packed_a_fits(const Engine *e, const LeafKind &kind, int64_t m, int64_t l, int64_t batch) {
-  if (kind.gen < 2 || batch <= 0) return false;
-  const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
+  if (kind.gen < 3 || batch <= 0) return false;
+  const size_t need = (size_t)gf2_m4rm8_a4_words(m, l, batch);
   return e->apk != nullptr && need <= e->apk_words && (uint64_t)need * 8 / (uint64_t)batch < (1ull << 32);
 }
 
@@ -202,7 +198,7 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   const int64_t wn   = words_of(n);
   const int64_t tw   = kind.gen == 4 ? 8 : kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
-  const int64_t sbits  = kind.gen == 4 ? 32 : kind.gen == 2 ? 14 : 16;  // inner bits per stage (barrier to barrier)
+  const int64_t sbits  = kind.gen == 4 ? 32 : 16;  // inner bits per stage (barrier to barrier)
   const int64_t stages = (l + sbits - 1) / sbits;
   int ksplit = ksplit_req;
   int64_t tail_tiles = 0;  // generation 4, hybrid plan: the last tail_tiles tiles go in a second launch ...
@@ -268,16 +264,15 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   a.batch = (int32_t)batch; a.ksplit = ksplit;
   a.mode  = (ksplit > 1 && slabs) ? 2 : (add || ksplit > 1) ? 1 : 0;
   a.Cpart = e->part;
-  // generations 2 and 3 consume A in a packed, chunk-major form (one streaming pass into the call's
+  // generations 3 and 4 consume A in a packed, chunk-major form (one streaming pass into the call's
   // scratch first); they need that scratch and 32-bit offsets inside one packed operand
   if (a_prepacked) {
     if (kind.gen < 3 || !packed_a_fits(e, kind, m, l, batch)) return (int)hipErrorInvalidValue;  // caller checked
-  } else if (kind.gen >= 2) {
+  } else if (kind.gen >= 3) {
     if (!packed_a_fits(e, kind, m, l, batch)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
-      const size_t need = kind.gen >= 3 ? (size_t)gf2_m4rm8_a4_words(m, l, batch) : (size_t)gf2_m4rm7_a7_words(m, l, batch);
-      if (kind.gen >= 3) HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen - 3));  // 0 / 1 / 2: the generation's index twists
-      else HIPTRY(gf2_launch_a7_pack(st, a, e->apk));
+      const size_t need = (size_t)gf2_m4rm8_a4_words(m, l, batch);
+      HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen - 3));  // 0 / 1: the generation's index twists
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
   }
@@ -304,7 +299,6 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
                                         0, tiles, ksplit, e->part));
   }
   else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
-  else if (kind.gen == 2) HIPTRY(gf2_launch_m4rm7(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));

@@ -1,7 +1,7 @@
 // m4rm8_leaf.hip -- M4RM leaf, generation 3: 8-bit tables with 128-byte entries, two tables
 // interleaved per LDS bank row, double-buffered, every wave symmetric.
 //
-// Generation 2 (m4rm7_leaf.hip) is bound by LDS-array cycles: per workgroup and stage 512 gathers
+// Generation 2 (k = 7, 256-byte entries; retired in round 2) was bound by LDS-array cycles: per workgroup and stage 512 gathers
 // (4 clk) + 64 table writes (8 clk) = 2560 clk for 14 inner bits of a 1024 x 2048 tile.  The same
 // 2560 clk buy 16 inner bits of a tile of the same area if the tile is 2048 rows x 1024 columns:
 // twice the rows share every table entry, entries are 128 B, and two 256-entry tables (k = 8) of a

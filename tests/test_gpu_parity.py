@@ -342,7 +342,7 @@ def test_fused_down_pack_paths(oracle, m, l, n, cutoff, a_shift, leaf_gen):
 @pytest.mark.parametrize("m,l,n,cutoff,leaf_gen,add", [
     (16384, 16384, 16384, 2048, 3, False),  # 343 leaves of 2048^3: three-level pass writes generation 3's packed A
     (32768, 8192, 8192, 1024, 4, False),    # 4096-row leaves: generation 4's rotated packed A
-    (8192, 10240, 8192, 1024, 2, False),    # 20-word leaf rows: plain three-level passes + generation 2's own pack
+    (8192, 10240, 8192, 1024, 1, False),    # 20-word leaf rows of 1024-row leaves: plain three-level passes, generation 1 (no packed A)
     (4096, 4096, 4096, 512, 1, True),       # accumulate through the three-level up pass
 ])
 def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
