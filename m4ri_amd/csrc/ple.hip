@@ -26,6 +26,7 @@
 // The host only reads back the block's pivots (a few hundred bytes per 64 columns).
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -196,44 +197,49 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
 // ---- 3. rows below, words to the right: C ^= M * U, inner dimension <= 64 -----------------------------------------------
 // The trailing matrix is read and written once per 64 pivot columns: a streaming kernel, bounded by HBM (the
 // C-stationary multiply leaf is built for inner dimensions of thousands and reaches a tenth of the bandwidth
-// here).  A workgroup owns a tile of RU_TW words x RU_ROWS rows.  It first builds sixteen 4-bit tables of its
-// column tile from the (<= 64) pivot rows -- 16 x 16 entries x 128 B = 32 KiB of LDS, four workgroups per CU --
-// then streams its rows: 8 lanes per row, 16 bytes each, sixteen ds_read_b128 lookups per chunk (the reference's
-// _mzd_process_rows_ple_N does the same with seven 8-bit tables per 56 columns, ple_russian_template.h).
-constexpr int RU_TW = 16, RU_ROWS = 2048, RU_THREADS = 256;
+// here).  A workgroup owns a tile of TW words x RU_ROWS rows.  It first builds sixteen 4-bit tables of its
+// column tile from the (<= 64) pivot rows -- 16 x 16 entries x 8 TW bytes of LDS -- then streams its rows: TW/2
+// lanes per row, 16 bytes each, sixteen ds_read_b128 lookups per chunk (the reference's _mzd_process_rows_ple_N
+// does the same with seven 8-bit tables per 56 columns, ple_russian_template.h).
+constexpr int RU_ROWS = 2048, RU_DEFAULT_TW = 32;
 typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
 
 // C, U point at word column `wfirst` (even: 16-byte accesses) of the rows; words < skip_below (the block's own word when the
-// tile origin had to be rounded down to stay aligned) take no update.
-template <bool VEC>
-__global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__restrict__ C, int64_t c_stride, const word *__restrict__ M,
-                                                                     const word *__restrict__ U, int64_t u_stride, int64_t rows, int64_t wn,
-                                                                     int rank, int skip_below) {
-  __shared__ __attribute__((aligned(16))) word tab[16][16][RU_TW];  // [table][entry][word]
+// tile origin had to be rounded down to stay aligned) take no update.  TW: tile width in words (TW/2 lanes per row).
+template <bool VEC, int TW, int THREADS>
+__global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restrict__ C, int64_t c_stride, const word *__restrict__ M,
+                                                                  const word *__restrict__ U, int64_t u_stride, int64_t rows, int64_t wn,
+                                                                  int rank, int skip_below) {
+  __shared__ __attribute__((aligned(16))) word tab[16][16][TW];  // [table][entry][word]
   const int tid      = threadIdx.x;
-  const int64_t w0   = (int64_t)blockIdx.x * RU_TW;
+  const int64_t w0   = (int64_t)blockIdx.x * TW;
   const int64_t r_lo = (int64_t)blockIdx.y * RU_ROWS;
   const int64_t r_hi = (r_lo + RU_ROWS) < rows ? (r_lo + RU_ROWS) : rows;
-  const int tw       = (int)((wn - w0) < RU_TW ? (wn - w0) : RU_TW);
-  // tables: entry e of table t = XOR of pivot rows 4t + b for the bits b of e (rows >= rank count as zero)
-  {
-    const int t = tid >> 4, e = tid & 15;
-    for (int w = 0; w < RU_TW; ++w) {
-      word x = 0;
-      if (w < tw && (w0 + w) >= skip_below)
-        for (int b = 0; b < 4; ++b)
-          if (((e >> b) & 1) && (4 * t + b) < rank) x ^= U[(int64_t)(4 * t + b) * u_stride + w0 + w];
-      tab[t][e][w] = x;
-    }
+  const int tw       = (int)((wn - w0) < TW ? (wn - w0) : TW);
+  // the tile's pivot rows through LDS first (coalesced, every word once), then the tables from there:
+  // entry e of table t = XOR of pivot rows 4t + b for the bits b of e (rows >= rank count as zero)
+  __shared__ word urow[64][TW];
+  for (int i = tid; i < 64 * TW; i += THREADS) {
+    const int w = i % TW, r = i / TW;
+    urow[r][w] = (r < rank && w < tw && (w0 + w) >= skip_below) ? U[(int64_t)r * u_stride + w0 + w] : 0;
   }
   __syncthreads();
-  const int lane8 = tid & 7;           // 16-byte chunk of the 128-byte tile row
-  const int rsub  = tid >> 3;          // 32 rows per sweep
-  const bool two  = (2 * lane8 + 1) < tw, one = (2 * lane8) < tw;
+  for (int i = tid; i < 256 * TW; i += THREADS) {
+    const int w = i % TW, te = i / TW, t = te >> 4, e = te & 15;
+    word x = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x ^= ((e >> b) & 1) ? urow[4 * t + b][w] : 0;
+    tab[t][e][w] = x;
+  }
+  __syncthreads();
+  constexpr int LPR = TW / 2;          // lanes per row: 16 bytes each
+  const int lane  = tid % LPR;         // 16-byte chunk of the tile row
+  const int rsub  = tid / LPR;
+  const bool two  = (2 * lane + 1) < tw, one = (2 * lane) < tw;
   const int ntab  = (rank + 3) >> 2;
   if (!one) return;
   // four rows per trip: their loads are issued together (one row in flight per lane leaves HBM mostly idle)
-  constexpr int RSTEP = RU_THREADS / 8, UNR = 4;
+  constexpr int RSTEP = THREADS / LPR, UNR = 4;
   for (int64_t rb = r_lo + rsub; rb < r_hi; rb += (int64_t)RSTEP * UNR) {
     word m[UNR], x0[UNR], x1[UNR];
 #pragma unroll
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__res
       m[u] = 0; x0[u] = 0; x1[u] = 0;
       if (r < r_hi) {
         m[u]          = M[r];
-        const word *cp = C + r * c_stride + w0 + 2 * lane8;
+        const word *cp = C + r * c_stride + w0 + 2 * lane;
         if (VEC && two) { const word2 c = *reinterpret_cast<const word2 *>(cp); x0[u] = c.x; x1[u] = c.y; }
         else { x0[u] = cp[0]; x1[u] = two ? cp[1] : 0; }
       }
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__res
     for (int u = 0; u < UNR; ++u) {
 #pragma unroll 4
       for (int t = 0; t < ntab; ++t) {
-        const word2 v = *reinterpret_cast<const word2 *>(&tab[t][(m[u] >> (4 * t)) & 15][2 * lane8]);
+        const word2 v = *reinterpret_cast<const word2 *>(&tab[t][(m[u] >> (4 * t)) & 15][2 * lane]);
         x0[u] ^= v.x;
         x1[u] ^= v.y;
       }
@@ -260,12 +266,26 @@ __global__ __launch_bounds__(RU_THREADS) void ple_rank_update_kernel(word *__res
     for (int u = 0; u < UNR; ++u) {
       const int64_t r = rb + (int64_t)u * RSTEP;
       if (r < r_hi) {
-        word *cp = C + r * c_stride + w0 + 2 * lane8;
+        word *cp = C + r * c_stride + w0 + 2 * lane;
         if (VEC && two) { word2 c; c.x = x0[u]; c.y = x1[u]; *reinterpret_cast<word2 *>(cp) = c; }
         else { cp[0] = x0[u]; if (two) cp[1] = x1[u]; }
       }
     }
   }
+}
+
+template <bool VEC>
+hipError_t launch_rank_update(hipStream_t st, int variant, word *C, int64_t cs, const word *M, const word *U, int64_t us, int64_t rows, int64_t wn,
+                              int rank, int skip) {
+  const unsigned gy = (unsigned)((rows + RU_ROWS - 1) / RU_ROWS);
+#define RU_LAUNCH(TW, TH)                                                                                                              \
+  hipLaunchKernelGGL((ple_rank_update_kernel<VEC, TW, TH>), dim3((unsigned)((wn + TW - 1) / TW), gy), dim3(TH), 0, st, C, cs, M, U, us, rows, wn, \
+                     rank, skip)
+  if (variant == 64) RU_LAUNCH(64, 1024);
+  else if (variant == 32) RU_LAUNCH(32, 512);
+  else RU_LAUNCH(16, 256);
+#undef RU_LAUNCH
+  return hipGetLastError();
 }
 
 // ---- 4. compressing L: one workgroup per row ---------------------------------------------------------------------
@@ -388,13 +408,9 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
         const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
         const int64_t wn     = width - wfirst;
         const int skip       = (int)(wb + 1 - wfirst);
-        const dim3 grid((unsigned)((wn + RU_TW - 1) / RU_TW), (unsigned)((below + RU_ROWS - 1) / RU_ROWS));
-        if (vec)
-          hipLaunchKernelGGL((ple_rank_update_kernel<true>), grid, dim3(RU_THREADS), 0, st, A + (r0 + rank) * stride + wfirst, stride, s.Mc,
-                             A + r0 * stride + wfirst, stride, below, wn, rank, skip);
-        else
-          hipLaunchKernelGGL((ple_rank_update_kernel<false>), grid, dim3(RU_THREADS), 0, st, A + (r0 + rank) * stride + wfirst, stride, s.Mc,
-                             A + r0 * stride + wfirst, stride, below, wn, rank, skip);
+        static const int variant = getenv("M4RI_AMD_RU_TW") ? atoi(getenv("M4RI_AMD_RU_TW")) : RU_DEFAULT_TW;
+        if (vec) HIPTRY(launch_rank_update<true>(st, variant, A + (r0 + rank) * stride + wfirst, stride, s.Mc, A + r0 * stride + wfirst, stride, below, wn, rank, skip));
+        else HIPTRY(launch_rank_update<false>(st, variant, A + (r0 + rank) * stride + wfirst, stride, s.Mc, A + r0 * stride + wfirst, stride, below, wn, rank, skip));
         HIPTRY(hipGetLastError());
       }
     }
