@@ -126,6 +126,7 @@ SYMBOLS = {
     "m4ri_amd_set_max_fuse": (_I, [_I]),
     "m4ri_amd_plan_levels": (_I, [_I64, _I64, _I64, _I]),
     "m4ri_amd_set_workspace_budget": (_I64, [_I64]),
+    "m4ri_amd_set_host_pipeline": (_I64, [_I64]),
     "m4ri_amd_pin": (_I, [MzdPtr]),
     "m4ri_amd_sync": (_I, [MzdPtr]),
     "m4ri_amd_host_modified": (_I, [MzdPtr]),
@@ -396,6 +397,11 @@ def plan_levels(m: int, l: int, n: int, cutoff: int = 0) -> int:
 def set_workspace_budget(nbytes: int) -> int:
     """Bytes the breadth-first workspace may take (0 = automatic); returns the previous value."""
     return int(lib().m4ri_amd_set_workspace_budget(int(nbytes)))
+
+
+def set_host_pipeline(min_bytes: int) -> int:
+    """A + B + C bytes from which host-memory products are pipelined over row slabs (0 = never); returns the previous value."""
+    return int(lib().m4ri_amd_set_host_pipeline(int(min_bytes)))
 
 
 def set_max_fuse(levels: int) -> int:

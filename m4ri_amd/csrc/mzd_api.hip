@@ -195,6 +195,76 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
   return cutoff;  // 0 = engine default; >0 normalised inside m4ri_amd_mul_dev
 }
 
+// Large products from host memory, pipelined over row slabs of A and C:
+//   upload B and slab 0 of A | product 0 || upload slab 1 | product 1 || download slab 0 of C, upload slab 2 | ...
+// The copies are blocking calls of this thread (pageable memory), the products run on a non-blocking stream, so the
+// two overlap: of 1.5 GiB over PCIe at 65536^3 only B, the first slab of A and the last slab of C stay exposed.  Same
+// bits as the one-shot schedule (a slab is an ordinary product C_k = A_k * B).  Returns false when the product is too small
+// to pay for it (the slabs run a little slower than the whole: rectangular, less Strassen depth in the row direction).
+size_t g_pipeline_min_bytes = (size_t)256 << 20;  // A + B + C bytes from which slabs are used; 0 disables (m4ri_amd_set_host_pipeline)
+hipStream_t g_compute_stream[ARENA_DEVICES];
+
+bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff) {
+  const int64_t m = A->nrows;
+  const size_t bytes = ((size_t)m * A->width + (size_t)B->nrows * B->width + (size_t)m * C->width) * 8;
+  if (g_pipeline_min_bytes == 0 || bytes < g_pipeline_min_bytes || m < 4 * 4096) return false;
+  int64_t srows = ((m / 4 + 4095) / 4096) * 4096;  // four slabs of whole 4096-row tiles (the last one takes what is left)
+  const int nslab = (int)((m + srows - 1) / srows);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  hipStream_t &cs = g_compute_stream[dev];
+  if (!cs) HIPDIE(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  size_t need = dev_words(B->nrows, B->ncols);
+  for (int k = 0; k < nslab; ++k) {
+    const int64_t rows = (k + 1) * srows <= m ? srows : m - k * srows;
+    need += dev_words(rows, A->ncols) + dev_words(rows, C->ncols);
+  }
+  arena_reserve(need);
+  auto slab_of = [&](const mzd_t *M, int k) {
+    mzd_t S = *M;
+    S.data  = M->data + (int64_t)k * srows * M->rowstride;
+    S.nrows = (rci_t)((k + 1) * srows <= m ? srows : m - k * srows);
+    S.flags |= FLAG_WINDOW;
+    return S;
+  };
+  std::vector<DevMat> dA((size_t)nslab), dC((size_t)nslab);
+  std::vector<hipEvent_t> up((size_t)nslab, nullptr), done((size_t)nslab, nullptr);
+  for (int k = 0; k < nslab; ++k) {
+    HIPDIE(hipEventCreateWithFlags(&up[(size_t)k], hipEventDisableTiming));
+    HIPDIE(hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming));
+  }
+  DevMat dB;
+  upload(dB, B);
+  auto upload_slab = [&](int k) {  // host rows -> device (blocking), tail masks on the null stream, then the event the product waits for
+    const mzd_t As = slab_of(A, k);
+    upload(dA[(size_t)k], &As);
+    const mzd_t Cs = slab_of(C, k);
+    if (add) upload(dC[(size_t)k], &Cs);
+    else dev_alloc(dC[(size_t)k], Cs.nrows, Cs.ncols);
+    HIPDIE(hipEventRecord(up[(size_t)k], nullptr));
+  };
+  auto download_slab = [&](int k) {
+    HIPDIE(hipEventSynchronize(done[(size_t)k]));
+    mzd_t Cs = slab_of(C, k);
+    if (!(C->flags & FLAG_WINDOW)) Cs.flags &= (uint8_t)~FLAG_WINDOW;  // a plain C: whole last words, like the one-shot path
+    download(dC[(size_t)k], &Cs);
+  };
+  upload_slab(0);
+  for (int k = 0; k < nslab; ++k) {
+    const mzd_t As = slab_of(A, k);
+    HIPDIE(hipStreamWaitEvent(cs, up[(size_t)k], 0));
+    HIPDIE(m4ri_amd_mul_dev(dC[(size_t)k].p, dC[(size_t)k].stride, dA[(size_t)k].p, dA[(size_t)k].stride, dB.p, dB.stride, As.nrows, A->ncols, B->ncols,
+                            add, cutoff, cs));
+    HIPDIE(hipEventRecord(done[(size_t)k], cs));
+    if (k + 1 < nslab) upload_slab(k + 1);  // overlaps product k
+    if (k >= 1) download_slab(k - 1);       // product k - 1 finished long ago; overlaps product k
+  }
+  download_slab(nslab - 1);
+  HIPDIE(hipDeviceSynchronize());
+  for (int k = 0; k < nslab; ++k) { (void)hipEventDestroy(up[(size_t)k]); (void)hipEventDestroy(done[(size_t)k]); }
+  return true;
+}
+
 // the whole product: strassen == true runs the Strassen-Winograd engine, false a single leaf
 mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff) {
   std::lock_guard<std::mutex> lk(g_api_mu);
@@ -209,6 +279,7 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   HIPDIE(m4ri_amd_init(dev));
   const bool same = (A == B);
   Pin *pinC = find_pin(C);
+  if (strassen && !same && !pinC && !find_pin(A) && !find_pin(B) && run_pipelined(C, A, B, add, cutoff)) return C;
   // a pinned C whose last word is shared with other columns of its parent is computed in staging and
   // merged under the column mask; otherwise the engine writes straight into the parent
   const bool c_staged = !pinC || (C->ncols % 64 != 0 && C->ncols != pinC->ncols);
@@ -402,6 +473,14 @@ mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // br
 mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear) {  // brilliantrussian.c:1032
   (void)k;
   return run(C, A, B, clear == 0, false, 0);
+}
+
+// A + B + C bytes from which the host entry points pipeline a product over row slabs (0: never); returns the previous value
+int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  const int64_t old = (int64_t)g_pipeline_min_bytes;
+  if (min_bytes >= 0) g_pipeline_min_bytes = (size_t)min_bytes;
+  return old;
 }
 
 // ---- triangular solves: the reference's names, host mzd_t in / out -------------

@@ -23,6 +23,15 @@ for n in (4096, 16384, 32768, 65536):
     gib = 3 * n * n / 8 / 2 ** 30
     print(f"mzd_mul host API n={n}: {best * 1e3:9.2f} ms  -> {n ** 3 / best:.3e} bit-op/s  ({gib:.2f} GiB over PCIe, "
           f"{gib / best:.1f} GiB/s if it were all transfer)", flush=True)
+    old = m4ri_amd.set_host_pipeline(0)   # the one-shot schedule: upload everything, multiply, download
+    m4ri_amd.mzd_mul(C, A, B, 0)
+    best = 1e9
+    for _ in range(3):
+        t = time.perf_counter()
+        m4ri_amd.mzd_mul(C, A, B, 0)
+        best = min(best, time.perf_counter() - t)
+    m4ri_amd.set_host_pipeline(old)
+    print(f"mzd_mul host API n={n}, slab pipeline off: {best * 1e3:9.2f} ms", flush=True)
     # the same call with all three matrices pinned (include/m4ri_amd.h part 3): nothing crosses PCIe
     for M in (A, B, C):
         m4ri_amd.pin(M)
