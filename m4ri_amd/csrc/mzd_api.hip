@@ -195,73 +195,107 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
   return cutoff;  // 0 = engine default; >0 normalised inside m4ri_amd_mul_dev
 }
 
-// Large products from host memory, pipelined over row slabs of A and C:
-//   upload B and slab 0 of A | product 0 || upload slab 1 | product 1 || download slab 0 of C, upload slab 2 | ...
-// The copies are blocking calls of this thread (pageable memory), the products run on a non-blocking stream, so the
-// two overlap: of 1.5 GiB over PCIe at 65536^3 only B, the first slab of A and the last slab of C stay exposed.  Same
-// bits as the one-shot schedule (a slab is an ordinary product C_k = A_k * B).  Returns false when the product is too small
-// to pay for it (the slabs run a little slower than the whole: rectangular, less Strassen depth in the row direction).
-size_t g_pipeline_min_bytes = (size_t)256 << 20;  // A + B + C bytes from which slabs are used; 0 disables (m4ri_amd_set_host_pipeline)
+// Large products from host memory, pipelined over blocks of C:  C_ij = A_i * B_j  on a gi x gj grid (2 x 2 when both m
+// and n allow it -- the blocks of a 65536^3 product then keep the full Strassen depth --, four row slabs of A and C
+// otherwise).  The copies are blocking calls of this thread (pageable memory), the products run on a non-blocking stream:
+//   upload A_0, B_0 | P_00 || upload B_1 | P_01 || upload A_1, download C_00 | P_10 || download C_01 | P_11 || ... | download
+// so of the 1.5 GiB over PCIe at 65536^3 only A_0, B_0 and the last block of C stay exposed.  Same bits as the one-shot
+// schedule (a block is an ordinary product).  Returns false when the product is too small to pay for it.
+size_t g_pipeline_min_bytes = (size_t)256 << 20;  // A + B + C bytes from which blocks are used; 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
 bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff) {
-  const int64_t m = A->nrows;
+  const int64_t m = A->nrows, n = B->ncols;
   const size_t bytes = ((size_t)m * A->width + (size_t)B->nrows * B->width + (size_t)m * C->width) * 8;
   if (g_pipeline_min_bytes == 0 || bytes < g_pipeline_min_bytes || m < 4 * 4096) return false;
-  int64_t srows = ((m / 4 + 4095) / 4096) * 4096;  // four slabs of whole 4096-row tiles (the last one takes what is left)
-  const int nslab = (int)((m + srows - 1) / srows);
+  // cuts: rows on whole 4096-row tiles, columns on whole words
+  std::vector<int64_t> rcut, ccut;
+  if (n >= 16384) {
+    rcut = {0, ((m / 2 + 4095) / 4096) * 4096, m};
+    ccut = {0, (n / 128) * 64, n};
+  } else {
+    const int64_t srows = ((m / 4 + 4095) / 4096) * 4096;
+    for (int64_t r = 0; r < m; r += srows) rcut.push_back(r);
+    rcut.push_back(m);
+    ccut = {0, n};
+  }
+  const int gi = (int)rcut.size() - 1, gj = (int)ccut.size() - 1;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   hipStream_t &cs = g_compute_stream[dev];
   if (!cs) HIPDIE(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-  size_t need = dev_words(B->nrows, B->ncols);
-  for (int k = 0; k < nslab; ++k) {
-    const int64_t rows = (k + 1) * srows <= m ? srows : m - k * srows;
-    need += dev_words(rows, A->ncols) + dev_words(rows, C->ncols);
-  }
+  size_t need = 0;
+  for (int i = 0; i < gi; ++i) need += dev_words(rcut[(size_t)i + 1] - rcut[(size_t)i], A->ncols);
+  for (int j = 0; j < gj; ++j) need += dev_words(B->nrows, ccut[(size_t)j + 1] - ccut[(size_t)j]);
+  for (int i = 0; i < gi; ++i)
+    for (int j = 0; j < gj; ++j) need += dev_words(rcut[(size_t)i + 1] - rcut[(size_t)i], ccut[(size_t)j + 1] - ccut[(size_t)j]);
   arena_reserve(need);
-  auto slab_of = [&](const mzd_t *M, int k) {
+  auto block_of = [&](const mzd_t *M, int64_t r0, int64_t r1, int64_t c0, int64_t c1) {  // mzd_init_window, mzd.c:159-177
     mzd_t S = *M;
-    S.data  = M->data + (int64_t)k * srows * M->rowstride;
-    S.nrows = (rci_t)((k + 1) * srows <= m ? srows : m - k * srows);
-    S.flags |= FLAG_WINDOW;
+    S.data  = M->data + r0 * M->rowstride + c0 / 64;
+    S.nrows = (rci_t)(r1 - r0);
+    S.ncols = (rci_t)(c1 - c0);
+    S.width = (S.ncols + 63) / 64;
+    S.high_bitmask = (~(word)0) >> ((64 - S.ncols % 64) % 64);
+    // the block is a window unless it reaches M's own last column of a non-window M (then whole last words may be written)
+    if ((M->flags & FLAG_WINDOW) || c1 != M->ncols) S.flags |= FLAG_WINDOW;
     return S;
   };
-  std::vector<DevMat> dA((size_t)nslab), dC((size_t)nslab);
-  std::vector<hipEvent_t> up((size_t)nslab, nullptr), done((size_t)nslab, nullptr);
-  for (int k = 0; k < nslab; ++k) {
-    HIPDIE(hipEventCreateWithFlags(&up[(size_t)k], hipEventDisableTiming));
-    HIPDIE(hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming));
-  }
-  DevMat dB;
-  upload(dB, B);
-  auto upload_slab = [&](int k) {  // host rows -> device (blocking), tail masks on the null stream, then the event the product waits for
-    const mzd_t As = slab_of(A, k);
-    upload(dA[(size_t)k], &As);
-    const mzd_t Cs = slab_of(C, k);
-    if (add) upload(dC[(size_t)k], &Cs);
-    else dev_alloc(dC[(size_t)k], Cs.nrows, Cs.ncols);
-    HIPDIE(hipEventRecord(up[(size_t)k], nullptr));
+  std::vector<DevMat> dA((size_t)gi), dB((size_t)gj), dC((size_t)gi * gj);
+  std::vector<hipEvent_t> upA((size_t)gi, nullptr), upB((size_t)gj, nullptr), upC((size_t)gi * gj, nullptr), done((size_t)gi * gj, nullptr);
+  auto ev = [](hipEvent_t &e) { HIPDIE(hipEventCreateWithFlags(&e, hipEventDisableTiming)); };
+  auto upload_a = [&](int i) {  // host rows -> device (blocking), tail masks on the null stream, then the event the products wait for
+    if (upA[(size_t)i]) return;
+    const mzd_t S = block_of(A, rcut[(size_t)i], rcut[(size_t)i + 1], 0, A->ncols);
+    upload(dA[(size_t)i], &S);
+    ev(upA[(size_t)i]);
+    HIPDIE(hipEventRecord(upA[(size_t)i], nullptr));
   };
-  auto download_slab = [&](int k) {
-    HIPDIE(hipEventSynchronize(done[(size_t)k]));
-    mzd_t Cs = slab_of(C, k);
-    if (!(C->flags & FLAG_WINDOW)) Cs.flags &= (uint8_t)~FLAG_WINDOW;  // a plain C: whole last words, like the one-shot path
-    download(dC[(size_t)k], &Cs);
+  auto upload_b = [&](int j) {
+    if (upB[(size_t)j]) return;
+    const mzd_t S = block_of(B, 0, B->nrows, ccut[(size_t)j], ccut[(size_t)j + 1]);
+    upload(dB[(size_t)j], &S);
+    ev(upB[(size_t)j]);
+    HIPDIE(hipEventRecord(upB[(size_t)j], nullptr));
   };
-  upload_slab(0);
-  for (int k = 0; k < nslab; ++k) {
-    const mzd_t As = slab_of(A, k);
-    HIPDIE(hipStreamWaitEvent(cs, up[(size_t)k], 0));
-    HIPDIE(m4ri_amd_mul_dev(dC[(size_t)k].p, dC[(size_t)k].stride, dA[(size_t)k].p, dA[(size_t)k].stride, dB.p, dB.stride, As.nrows, A->ncols, B->ncols,
-                            add, cutoff, cs));
-    HIPDIE(hipEventRecord(done[(size_t)k], cs));
-    if (k + 1 < nslab) upload_slab(k + 1);  // overlaps product k
-    if (k >= 1) download_slab(k - 1);       // product k - 1 finished long ago; overlaps product k
+  auto c_block = [&](int i, int j) { return block_of(C, rcut[(size_t)i], rcut[(size_t)i + 1], ccut[(size_t)j], ccut[(size_t)j + 1]); };
+  auto prepare_c = [&](int t) {
+    const mzd_t S = c_block(t / gj, t % gj);
+    if (add) upload(dC[(size_t)t], &S);
+    else dev_alloc(dC[(size_t)t], S.nrows, S.ncols);
+    ev(upC[(size_t)t]);
+    HIPDIE(hipEventRecord(upC[(size_t)t], nullptr));
+  };
+  auto download_c = [&](int t) {
+    HIPDIE(hipEventSynchronize(done[(size_t)t]));
+    mzd_t S = c_block(t / gj, t % gj);
+    download(dC[(size_t)t], &S);
+  };
+  const int nt = gi * gj;
+  upload_a(0);
+  upload_b(0);
+  prepare_c(0);
+  for (int t = 0; t < nt; ++t) {
+    const int i = t / gj, j = t % gj;
+    HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i], 0));
+    HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)j], 0));
+    HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
+    HIPDIE(m4ri_amd_mul_dev(dC[(size_t)t].p, dC[(size_t)t].stride, dA[(size_t)i].p, dA[(size_t)i].stride, dB[(size_t)j].p, dB[(size_t)j].stride,
+                            rcut[(size_t)i + 1] - rcut[(size_t)i], A->ncols, ccut[(size_t)j + 1] - ccut[(size_t)j], add, cutoff, cs));
+    ev(done[(size_t)t]);
+    HIPDIE(hipEventRecord(done[(size_t)t], cs));
+    if (t + 1 < nt) {  // what the next product needs: overlaps product t
+      upload_a((t + 1) / gj);
+      upload_b((t + 1) % gj);
+      prepare_c(t + 1);
+    }
+    if (t >= 1) download_c(t - 1);  // product t - 1 is finished or about to be; overlaps product t
   }
-  download_slab(nslab - 1);
+  download_c(nt - 1);
   HIPDIE(hipDeviceSynchronize());
-  for (int k = 0; k < nslab; ++k) { (void)hipEventDestroy(up[(size_t)k]); (void)hipEventDestroy(done[(size_t)k]); }
+  for (auto *v : {&upA, &upB, &upC, &done})
+    for (hipEvent_t e : *v)
+      if (e) (void)hipEventDestroy(e);
   return true;
 }
 

@@ -1,5 +1,6 @@
 """The host entry points' slab pipeline (mzd_api.hip: run_pipelined; m4ri_amd_set_host_pipeline): large products
-from host memory are cut into four row slabs of A and C so that PCIe copies run under the products.  A slab is an
+from host memory are cut into a 2 x 2 grid of blocks of C (or four row slabs when n is small) so that PCIe copies run under the
+products.  A block is an
 ordinary product, so every bit must equal the one-shot schedule's and the oracle's -- ragged last slabs, windows
 with non-zero excess (parent bits outside the window untouched), accumulate."""
 import numpy as np
@@ -20,7 +21,8 @@ def _gpu():
     m4ri_amd.set_host_pipeline(old)
 
 
-@pytest.mark.parametrize("m,l,n", [(16384, 1000, 900), (16384 + 37, 2000, 1500), (20000, 257, 4100), (40000, 640, 640), (16385, 64, 1)])
+@pytest.mark.parametrize("m,l,n", [(16384, 1000, 900), (16384 + 37, 2000, 1500), (20000, 257, 4100), (40000, 640, 640), (16385, 64, 1),
+                                   (16384, 300, 16384), (20001, 700, 17000 + 13), (16500, 64, 30000)])   # n >= 16384: the 2 x 2 grid
 def test_pipelined_products_match_oracle(oracle, m, l, n):
     A, B = Mzd.random(m, l, 1), Mzd.random(l, n, 2)
     want = oracle.mul(None, A, B, 0)
@@ -45,6 +47,14 @@ def test_pipelined_windows_keep_their_parents(oracle):
     oracle.addmul(co, a.copy(), b.copy(), 0)
     m4ri_amd.mzd_addmul(c, a, b, 0)
     assert np.array_equal(PC.buf, PCo.buf)
+    # the 2 x 2 grid on windows: the column cut falls inside the windows of B and C
+    QA, QB, QC = Mzd.random(17000, 600, 15), Mzd.random(600, 18000, 16), Mzd.random(17000, 18000, 17)
+    a, b, c = QA.window(5, 0, 5 + 16500, 513), QB.window(3, 64, 3 + 513, 64 + 16999), QC.window(400, 128, 400 + 16500, 128 + 16999)
+    QCo = Mzd(17000, 18000, buf=QC.buf.copy())
+    co = QCo.window(400, 128, 400 + 16500, 128 + 16999)
+    oracle.addmul(co, a.copy(), b.copy(), 0)
+    m4ri_amd.mzd_addmul(c, a, b, 0)
+    assert np.array_equal(QC.buf, QCo.buf)
 
 
 def test_pipelined_equals_one_shot_at_32768():
