@@ -12,11 +12,13 @@
 // All of these are streaming kernels: one 64-bit word (or a 16-byte pair) per lane, rows
 // contiguous -- bounded by HBM bandwidth; only the packed-output passes tile (an LDS transpose).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "gf2_common.h"
 
 namespace {
 
 constexpr int AUX_THREADS = 256;
+constexpr int PASS_NT_DEFAULT = 2;  // up3 reads its 343 products once: nontemporal loads measure 0.70 -> 0.60 ms at 65536^3; nontemporal stores in the down passes measure slower
 
 // ---- Winograd operand combinations ----------------------------------------------------------
 // With the parent split into quadrants X11 X12 / X21 X22 the 7 children of the A side are
@@ -299,6 +301,13 @@ inline unsigned grid_for(int64_t total) {
   return (unsigned)g;
 }
 
+// measurement knob: M4RI_AMD_PASS_NT = bit mask of three-level passes that use nontemporal accesses for the 343-way side
+// (1 down3 stores, 2 up3 loads, 4 down3_pack stores)
+inline int pass_nt() {
+  static const int v = getenv("M4RI_AMD_PASS_NT") ? atoi(getenv("M4RI_AMD_PASS_NT")) : PASS_NT_DEFAULT;
+  return v;
+}
+
 inline bool vec_ok(const void *p, int64_t stride, int64_t bs, int64_t cw, int64_t qcols) {
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (stride % 2 == 0) && (bs % 2 == 0) &&
          (cw % 2 == 0) && (qcols % 2 == 0);
@@ -573,7 +582,7 @@ __device__ __forceinline__ void winograd_scatter(const V pr, int j, V &c11, V &c
   }
 }
 
-template <bool BSIDE>
+template <bool BSIDE, bool NT>
 __global__ __launch_bounds__(AUX_THREADS) void winograd_down3_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,  // ancestor array
     word *__restrict__ gchild, int64_t c_bs,                       // great-grandchildren, stride == cw
@@ -608,14 +617,17 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_down3_kernel(
 #pragma unroll
           for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, BSIDE>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
 #pragma unroll
-        for (int j3 = 0; j3 < 7; ++j3)
-          c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs] = winograd_child<word, BSIDE>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        for (int j3 = 0; j3 < 7; ++j3) {
+          const word v = winograd_child<word, BSIDE>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+          if (NT) __builtin_nontemporal_store(v, &c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs]);
+          else c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs] = v;
+        }
       }
     }
   }
 }
 
-template <bool ACC>
+template <bool ACC, bool NT>
 __global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
     const word *__restrict__ prod, int64_t p_bs,                   // 343 products per ancestor, stride == cw
     word *__restrict__ anc, int64_t o_stride, int64_t o_bs,        // ancestor array
@@ -646,7 +658,8 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
         word c2[2][2] = {{0, 0}, {0, 0}};
 #pragma unroll
         for (int j3 = 0; j3 < 7; ++j3)
-          winograd_scatter<word>(q[(int64_t)(49 * j1 + 7 * j2 + j3) * p_bs], j3, c2[0][0], c2[0][1], c2[1][0], c2[1][1]);
+          winograd_scatter<word>(NT ? __builtin_nontemporal_load(&q[(int64_t)(49 * j1 + 7 * j2 + j3) * p_bs]) : q[(int64_t)(49 * j1 + 7 * j2 + j3) * p_bs],
+                                 j3, c2[0][0], c2[0][1], c2[1][0], c2[1][1]);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up3_kernel(
 // the writes (16 lanes = the 16 slots of one row) stay conflict-free and 8-byte aligned.
 constexpr int DP3_ROWS = 32, DP3_W = 16, DP3_PITCH = 32, DP3_THREADS = 512;
 
-template <int ROT>
+template <int ROT, bool NT>
 __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
     uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed great-grandchildren, a4_bs dwords each
@@ -726,7 +739,8 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
         const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);  // rows r2 and r2 + 1 share the swizzle
         uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + rs], w1 = tb[(r2 + 1) * DP3_PITCH + rs];
         if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
-        *reinterpret_cast<uint2 *>(o + (int64_t)k * a4_bs) = make_uint2(w0, w1);
+        if (NT) __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)w1 << 32), reinterpret_cast<unsigned long long *>(o + (int64_t)k * a4_bs));
+        else *reinterpret_cast<uint2 *>(o + (int64_t)k * a4_bs) = make_uint2(w0, w1);
       }
     }
   }
@@ -738,12 +752,12 @@ extern "C" hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const 
   const int64_t c_bs = crows * cw;
   if (nparents * c_bs == 0) return hipSuccess;
   const int64_t total = nparents * c_bs;
-  if (bside)
-    hipLaunchKernelGGL((winograd_down3_kernel<true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs,
-                       gchild, c_bs, nparents, crows, cw);
-  else
-    hipLaunchKernelGGL((winograd_down3_kernel<false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs,
-                       gchild, c_bs, nparents, crows, cw);
+#define D3_LAUNCH(BS, NT)                                                                                                      \
+  hipLaunchKernelGGL((winograd_down3_kernel<BS, NT>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs, gchild, c_bs, \
+                     nparents, crows, cw)
+  if (pass_nt() & 1) { if (bside) D3_LAUNCH(true, true); else D3_LAUNCH(false, true); }
+  else { if (bside) D3_LAUNCH(true, false); else D3_LAUNCH(false, false); }
+#undef D3_LAUNCH
   return hipGetLastError();
 }
 
@@ -752,12 +766,12 @@ extern "C" hipError_t gf2_launch_winograd_up3(hipStream_t s, int acc, const word
   const int64_t p_bs = crows * cw;
   if (nparents * p_bs == 0) return hipSuccess;
   const int64_t total = nparents * p_bs;
-  if (acc)
-    hipLaunchKernelGGL((winograd_up3_kernel<true>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride,
-                       o_bs, nparents, crows, cw);
-  else
-    hipLaunchKernelGGL((winograd_up3_kernel<false>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride,
-                       o_bs, nparents, crows, cw);
+#define U3_LAUNCH(AC, NT)                                                                                                            \
+  hipLaunchKernelGGL((winograd_up3_kernel<AC, NT>), dim3(grid_for(total)), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, nparents, \
+                     crows, cw)
+  if (pass_nt() & 2) { if (acc) U3_LAUNCH(true, true); else U3_LAUNCH(false, true); }
+  else { if (acc) U3_LAUNCH(true, false); else U3_LAUNCH(false, false); }
+#undef U3_LAUNCH
   return hipGetLastError();
 }
 
@@ -774,10 +788,11 @@ extern "C" hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *
   const int64_t tiles_r = crows / DP3_ROWS, tiles_w = cw / DP3_W;
   const int64_t grid = nparents * tiles_r * tiles_w;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-#define DP3_LAUNCH(R)                                                                                              \
-  hipLaunchKernelGGL((winograd_down3_pack_kernel<R>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs, \
+#define DP3_LAUNCH(R, NT)                                                                                              \
+  hipLaunchKernelGGL((winograd_down3_pack_kernel<R, NT>), dim3((unsigned)grid), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs, \
                      reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w)
-  if (rot == 2) DP3_LAUNCH(2); else if (rot == 1) DP3_LAUNCH(1); else DP3_LAUNCH(0);
+  if (pass_nt() & 4) { if (rot == 2) DP3_LAUNCH(2, true); else if (rot == 1) DP3_LAUNCH(1, true); else DP3_LAUNCH(0, true); }
+  else { if (rot == 2) DP3_LAUNCH(2, false); else if (rot == 1) DP3_LAUNCH(1, false); else DP3_LAUNCH(0, false); }
 #undef DP3_LAUNCH
   return hipGetLastError();
 }
