@@ -57,3 +57,21 @@ def test_row_processing_on_a_pinned_matrix(oracle):
         ec.call_process_rows(m4ri_amd.lib(), M, r + k, 3000, c, k, T, L)
     m4ri_amd.unpin(M)
     assert np.array_equal(M.rows(), Mo.rows())
+
+
+def test_edge_ranges_and_small_k(oracle):
+    """Empty row ranges, the last column block, k = 1 and k = 2 tables."""
+    M = Mzd.random(100, 200, 1)
+    T, L = ec.tables_for(oracle.make_table, M, 3, 5, 2, 1)
+    Mg = M.copy()
+    ec.call_process_rows(m4ri_amd.lib(), Mg, 50, 50, 5, 2, T, L)   # startrow == stoprow: nothing happens
+    assert np.array_equal(Mg.rows(), M.rows())
+    for (r, c, k, nt) in [(0, 0, 1, 1), (10, 191, 8, 1), (10, 192, 8, 2), (0, 130, 6, 3), (90, 100, 2, 2)]:
+        To, Lo = ec.tables_for(oracle.make_table, M, r, c, k, nt)
+        Tg, Lg = ec.tables_for(_gpu_make, M, r, c, k, nt)
+        for a, b, la, lb in zip(To, Tg, Lo, Lg):
+            assert np.array_equal(a.rows(), b.rows()) and np.array_equal(la, lb)
+        Mo, Mg = M.copy(), M.copy()
+        oracle.process_rows(Mo, 0, 100, c, k, To, Lo)
+        ec.call_process_rows(m4ri_amd.lib(), Mg, 0, 100, c, k, Tg, Lg)
+        assert np.array_equal(Mo.rows(), Mg.rows()), (r, c, k, nt)

@@ -107,3 +107,28 @@ def test_solvers_at_scale_vs_reference_sha256():
             T, B = Mzd.random(e["m"], e["m"], e["seed"]), Mzd.random(e["m"], e["n"], e["seed"] + 1000)
             (m4ri_amd.mzd_trsm_upper_left if e["what"] == "trsm_upper" else m4ri_amd.mzd_trsm_lower_left)(T, B)
             assert hashlib.sha256(B.masked().tobytes()).hexdigest() == e["sha256"], e
+
+
+def test_solver_edge_shapes(oracle):
+    """Empty and one-line matrices through every solver entry point (the reference treats them as no-ops)."""
+    for (m, n) in [(0, 0), (0, 5), (5, 0), (1, 1), (1, 200), (200, 1), (64, 64), (65, 1)]:
+        A = Mzd.random(m, n, 3)
+        Ao = A.copy()
+        want = oracle.ple(Ao) if m and n else (0, np.arange(m, dtype=np.int32), np.arange(n, dtype=np.int32))
+        got = m4ri_amd.mzd_ple(A)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and A.equal(Ao)
+    for (mb, nb) in [(0, 0), (0, 7), (3, 0), (1, 70), (2, 1)]:
+        T, B = Mzd.random(mb, mb, 4), Mzd.random(mb, nb, 5)
+        for fn, ofn in ((m4ri_amd.mzd_trsm_lower_left, oracle.trsm_lower_left), (m4ri_amd.mzd_trsm_upper_left, oracle.trsm_upper_left)):
+            X, Xo = B.copy(), B.copy()
+            if mb and nb:
+                ofn(T, Xo)
+            fn(T, X)
+            assert X.equal(Xo)
+    # all-zero and identity inputs: rank 0 / full rank with no row operations
+    Z = Mzd.init(300, 200)
+    r, P, Q = m4ri_amd.mzd_ple(Z)
+    assert r == 0 and np.array_equal(P, np.arange(300)) and np.array_equal(Q, np.arange(200)) and not Z.rows().any()
+    I = Mzd.from_bits(np.eye(130, dtype=np.uint8))
+    Io = I.copy()
+    assert m4ri_amd.mzd_ple(I)[0] == 130 and I.equal(Io)
