@@ -40,10 +40,11 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__r
 #pragma unroll
     for (int i = 1; i < 64; ++i) {
       if (i < mb) {
-        const word row = T[(int64_t)i * t_stride];  // wave-uniform
-        word acc       = 0;
+        const word row = T[(int64_t)i * t_stride];  // wave-uniform: a scalar load, so the tests below are scalar branches
+        word acc       = 0;                          // (half of the XORs are skipped outright instead of being masked)
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc ^= ((row >> k) & 1) ? x[k] : 0;
+        for (int k = 0; k < i; ++k)
+          if ((row >> k) & 1) acc ^= x[k];
         x[i] ^= acc;
       }
     }
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__r
         const word row = T[(int64_t)i * t_stride];
         word acc       = 0;
 #pragma unroll
-        for (int k = i + 1; k < 64; ++k) acc ^= (k < mb && ((row >> k) & 1)) ? x[k] : 0;
+        for (int k = i + 1; k < 64; ++k)
+          if (k < mb && ((row >> k) & 1)) acc ^= x[k];
         x[i] ^= acc;
       }
     }
