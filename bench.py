@@ -11,8 +11,12 @@ everything through libm4ri_amd.so's C ABI.  Inputs are in HBM before the timed r
 
 N = 1: Strassen-Winograd levels over batched M4RM leaves on one GPU (m4ri_amd_mul_dev).
 
-N > 1 (one process per GPU, torch.distributed.run, RCCL):
-  --variant strassen (default): the sub-products of the top Strassen-Winograd level(s) are spread over the
+N > 1 (one process per GPU, torch.distributed.run, RCCL); --variant auto (default) = slabs up to 4 ranks, strassen above:
+  --variant slabs: rank r holds rows [r m/N, (r+1) m/N) of A, of B and of C; ONE RCCL collective, the all-gather of
+      B's row slabs (all_gather_into_tensor), then every rank multiplies its slab of A by the whole B.  Gives up
+      log2(N) Strassen levels in the row direction, which is cheap at 2 and 4 ranks (and 2 ranks share one xGMI
+      link, which a Strassen-sharded exchange would saturate).
+  --variant strassen: the sub-products of the top Strassen-Winograd level(s) are spread over the
       ranks (m4ri_amd/csrc/multi.hip, m4ri_amd/sharding.py).  A, B and C are distributed slab-cyclically
       (rank r holds rows [cut(r), cut(r+1)) of every row block): every rank runs the level's additions on
       its own slabs, slabs of sub-product operands travel rank -> owner and slabs of products back, each as
@@ -285,7 +289,8 @@ def main():
                     help="mul: n^3 mzd_mul (the headline, configs[2]/[3]); leaf16384: configs[1]; "
                          "rect131072: 131072 x 8192 x 131072 (configs[4])")
     ap.add_argument("--cutoff", type=int, default=0)
-    ap.add_argument("--variant", default="strassen", choices=["strassen", "blocks"], help="N > 1: what is handed out to the ranks")
+    ap.add_argument("--variant", default="auto", choices=["auto", "strassen", "slabs", "blocks"],
+                    help="N > 1: what is handed out to the ranks (auto: slabs up to 4 ranks, strassen above)")
     ap.add_argument("--layout", default="distributed", choices=["distributed", "owner"], help="N > 1: where A, B live and C is left")
     ap.add_argument("--shard-levels", type=int, default=0, help="strassen variant: sharded levels (1, 2; 0 = automatic)")
     ap.add_argument("--grid", default="", help="blocks variant: gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
@@ -303,6 +308,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.variant == "auto":
+        args.variant = sharding.default_variant(world)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
@@ -343,6 +350,8 @@ def main():
         exchange = sharding.torch_exchange(dist, staged_device=("cuda" if args.backend == "gloo" else None))
     A = B = Cfull = None
     config_extra = {}
+    if args.variant == "blocks" and args.layout == "distributed" and world > 1:
+        args.layout = "owner"  # the blocks variant scatters from rank 0 by construction
     need_full_inputs = world == 1 or args.layout == "owner" or args.variant == "blocks"
     if need_full_inputs and (world == 1 or rank == 0):
         A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
@@ -361,6 +370,54 @@ def main():
                 m4ri_amd.mul_dev(Cfull.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, args.cutoff, stream)
         per_rank_product = [M, L, N]
         config_extra["parallelism"] = "1 GPU"
+
+    # ---------------------------------------------------------------- N > 1, row slabs + all-gather of B
+    elif args.variant == "slabs":
+        rc, bc = sharding.slab_cuts(M, world), sharding.slab_cuts(L, world)
+        mr, lr = rc[1], bc[1]                      # rows of this rank's slab of A / C, and of B
+        staged = args.backend == "gloo"
+        Bfull = torch.empty((L, w), dtype=torch.int64, device="cuda")
+        Cs = torch.empty((mr, w), dtype=torch.int64, device="cuda")
+        if args.layout == "distributed":           # the slabs are where the inputs live
+            As = torch.empty((mr, wl), dtype=torch.int64, device="cuda")
+            Bs = torch.empty((lr, w), dtype=torch.int64, device="cuda")
+            m4ri_amd.fill_rows_dev(As.data_ptr(), wl, rc[rank], mr, L, seeds[0], stream)
+            m4ri_amd.fill_rows_dev(Bs.data_ptr(), w, bc[rank], lr, N, seeds[1], stream)
+        else:
+            As = torch.empty((mr, wl), dtype=torch.int64, device="cuda")
+            Bs = None
+            if rank == 0:
+                Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+
+        def step():
+            if args.layout == "owner":             # rank 0 scatters the slabs of A and broadcasts B; C is gathered
+                sends, recvs = [], []
+                for r in range(1, world):
+                    if rank == 0:
+                        sends += [(r, A[rc[r]:rc[r + 1]].reshape(-1)), (r, B.reshape(-1))]
+                    elif rank == r:
+                        recvs += [(0, As.reshape(-1)), (0, Bfull.reshape(-1))]
+                if rank == 0:
+                    As.copy_(A[:mr])
+                    Bfull.copy_(B)
+                exchange(sends, recvs)
+            else:
+                sharding.all_gather_rows(dist, Bfull, Bs, staged=staged)   # the ONE collective of the variant
+            m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr(), wl, Bfull.data_ptr(), w, mr, L, N, False, args.cutoff, stream)
+            if args.layout == "owner":
+                sends, recvs = [], []
+                for r in range(1, world):
+                    if rank == 0:
+                        recvs.append((r, Cfull[rc[r]:rc[r + 1]].reshape(-1)))
+                    elif rank == r:
+                        sends.append((0, Cs.reshape(-1)))
+                if rank == 0:
+                    Cfull[:mr].copy_(Cs)
+                exchange(sends, recvs)
+        per_rank_product = [mr, L, N]
+        config_extra.update({"parallelism": f"row slabs x{world} + all-gather of B", "variant": "slabs", "layout": args.layout,
+                             "bytes_over_links_per_step": 8 * L * w * (world - 1) // world * (1 if args.layout == "distributed" else 0),
+                             "collective": "all_gather_into_tensor(B) -- RCCL" if args.layout == "distributed" else "send/recv scatter + gather"})
 
     # ---------------------------------------------------------------- N > 1, Strassen sub-products --
     elif args.variant == "strassen":
@@ -440,8 +497,6 @@ def main():
 
     # ---------------------------------------------------------------- N > 1, blocks of C -----------
     else:
-        if args.layout != "owner":
-            raise SystemExit("--variant blocks scatters blocks from rank 0 and gathers C there: use --layout owner")
         grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else ((world, 1, 1) if args.workload == "rect131072" else None)
         bplan = sharding.make_plan(world, rank, M, L, N, grid=grid)
         r0, r1 = bplan.row_range()
@@ -569,7 +624,10 @@ def main():
         full = torch.empty((M, w), dtype=torch.int64, device="cuda")
         m4ri_amd.mul_dev(full.data_ptr(), w, fullA.data_ptr(), wl, fullB.data_ptr(), w, M, L, N, False, 0, stream)
         torch.cuda.synchronize()
-        if args.variant == "strassen":
+        if args.variant == "slabs":
+            ok = bool(torch.equal(Cs, full[rc[rank]:rc[rank + 1]]))
+            what = f"rows {rc[rank]}:{rc[rank + 1]} of C"
+        elif args.variant == "strassen":
             ok = True
             for b, (g0, rows) in enumerate(runs_a):
                 ok = ok and bool(torch.equal(bufs["local_c"][b * sa * w:(b * sa + rows) * w].reshape(rows, w), full[g0:g0 + rows]))
@@ -660,7 +718,7 @@ def main():
             # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
             # this rank's products / step time); the compulsory bytes beside it
             pm, pl, pn = per_rank_product
-            nprod_rank = 1 if (world == 1 or args.variant == "blocks") else len(sharding.owned_products(plan, 0))
+            nprod_rank = 1 if (world == 1 or args.variant != "strassen") else len(sharding.owned_products(plan, 0))
             bs = float(bytes_sched(pm, pl, pn, int(stats.levels))) * nprod_rank
             out["roofline_schedule"] = {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

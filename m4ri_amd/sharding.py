@@ -222,3 +222,37 @@ def torch_exchange(dist, staged_device=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return exchange
+
+
+# ==================================================================================================
+# Row slabs: the simplest distributed product, C_r = A_r * B with B replicated by ONE all-gather.
+# Rank r holds rows [cut(r), cut(r+1)) of A, of B and (afterwards) of C -- the layout closes, products chain.
+# The only communication is the all-gather of B's row slabs (an RCCL collective; on the xGMI mesh every link
+# carries 1/W of B).  Each rank then multiplies its slab by the whole B with the full single-GPU engine; what the
+# variant gives up is Strassen depth in the row direction (a slab of m/W rows has log2(W) levels fewer), which is
+# why the Strassen-sharded variant overtakes it at 8 GPUs while the slabs win at 2 and 4.
+# ==================================================================================================
+def slab_cuts(rows: int, world: int):
+    """Row boundaries of the W slabs (equal slabs; the all-gather wants equal pieces: rows must divide)."""
+    assert rows % world == 0, (rows, world)
+    return [k * (rows // world) for k in range(world + 1)]
+
+
+def all_gather_rows(dist, full, mine, staged=False):
+    """full (W * k rows) <- the ranks' `mine` (k rows each) in rank order: dist.all_gather_into_tensor, or its
+    host-staged equivalent for backends that cannot move device tensors (gloo in the one-GPU tests)."""
+    import torch
+    if not staged:
+        dist.all_gather_into_tensor(full.view(-1), mine.contiguous().view(-1))
+        return
+    parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine.cpu() if mine.is_cuda else mine.contiguous())
+    k = mine.shape[0]
+    for r, t in enumerate(parts):
+        full[r * k:(r + 1) * k].copy_(t)
+
+
+def default_variant(world: int) -> str:
+    """slabs up to 4 ranks (one all-gather of B; 2 ranks share a single link, which the Strassen-sharded exchange
+    would saturate), the Strassen sub-products from 5 ranks on (arithmetic for n = 65536)."""
+    return "slabs" if world <= 4 else "strassen"

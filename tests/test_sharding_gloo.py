@@ -105,3 +105,34 @@ def test_plans_tile_the_product():
         assert area == m * n
     # the defaults never split the inner dimension: no exchange on the data path
     assert sharding.default_grid(8) == (4, 2, 1) and sharding.default_grid(4) == (2, 2, 1)
+
+
+def _slab_worker(rank, world, port, m, l, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_libs
+    orc = cpu_libs.oracle()
+    A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
+    rc, bc = sharding.slab_cuts(m, world), sharding.slab_cuts(l, world)
+    mine_b = torch.from_numpy(B.masked()[bc[rank]:bc[rank + 1]].view(np.int64).copy())
+    full_b = torch.empty((l, B.width), dtype=torch.int64)
+    sharding.all_gather_rows(dist, full_b, mine_b, staged=True)      # the variant's one collective (bench.py: RCCL all-gather)
+    Bg = Mzd(l, n)
+    Bg.valid_words()[:, :] = full_b.numpy().view(np.uint64)
+    As = A.window(rc[rank], 0, rc[rank + 1], l).copy()
+    C = orc.mul(None, As, Bg, 0)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=np.array([rc[rank], rc[rank + 1]]), words=C.masked())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_slabs_with_all_gather(tmp_path, oracle):
+    world, (m, l, n) = 2, (300, 256, 321)
+    mp.spawn(_slab_worker, args=(world, _free_port(), m, l, n, str(tmp_path)), nprocs=world, join=True)
+    want = oracle.mul(None, Mzd.random(m, l, 3), Mzd.random(l, n, 4), 0).masked()
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        r0, r1 = (int(x) for x in z["rows"])
+        assert np.array_equal(z["words"], want[r0:r1])
+    assert sharding.default_variant(2) == "slabs" and sharding.default_variant(4) == "slabs" and sharding.default_variant(8) == "strassen"

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Time the per-rank block products of the default multi-GPU grids on ONE GPU (what each rank of an
-N-GPU run computes at n = 65536), to estimate strong scaling without an 8-GPU node."""
+"""Time, on ONE GPU, the products a rank of an N-GPU run computes at n = 65536 -- the row slabs of the slabs
+variant, the sub-products of the Strassen-sharded variant (x how many the busiest rank multiplies) and the blocks of
+the blocks variant -- to estimate strong scaling without an 8-GPU node (compute only: the exchanges are arithmetic
+in DESIGN.md 7)."""
 import json
 import sys
 import time
@@ -12,8 +14,9 @@ import torch
 import m4ri_amd
 
 n = 65536
-SHAPES = {"N=1 (1,1,1)": (n, n, n), "N=2 (2,1,1)": (n // 2, n, n), "N=4 (2,2,1)": (n // 2, n, n // 2),
-          "N=8 (4,2,1)": (n // 4, n, n // 2), "N=8 (2,2,2) + exchange": (n // 2, n // 2, n // 2)}
+SHAPES = {"N=1 (1,1,1)": (n, n, n), "slabs N=2": (n // 2, n, n), "slabs N=4": (n // 4, n, n), "slabs N=8": (n // 8, n, n),
+          "strassen sub-product (n/2)^3 [N=8: x1]": (n // 2, n // 2, n // 2), "strassen sub-product (n/4)^3 [N=4: x13, N=2: x25]": (n // 4, n // 4, n // 4),
+          "blocks N=4 (2,2,1)": (n // 2, n, n // 2), "blocks N=8 (4,2,1)": (n // 4, n, n // 2)}
 m4ri_amd.init(0)
 out = {}
 for name, (m, l, k) in SHAPES.items():
