@@ -201,7 +201,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
 // column tile from the (<= 64) pivot rows -- 16 x 16 entries x 8 TW bytes of LDS -- then streams its rows: TW/2
 // lanes per row, 16 bytes each, sixteen ds_read_b128 lookups per chunk (the reference's _mzd_process_rows_ple_N
 // does the same with seven 8-bit tables per 56 columns, ple_russian_template.h).
-constexpr int RU_ROWS = 2048, RU_DEFAULT_TW = 32;
+#ifndef RU_UNR
+#define RU_UNR 4
+#endif
+constexpr int RU_ROWS_DEFAULT = 2048, RU_DEFAULT_TW = 32;
 typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
 
 // C, U point at word column `wfirst` (even: 16-byte accesses) of the rows; words < skip_below (the block's own word when the
@@ -209,7 +212,7 @@ typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
 template <bool VEC, int TW, int THREADS>
 __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restrict__ C, int64_t c_stride, const word *__restrict__ M,
                                                                   const word *__restrict__ U, int64_t u_stride, int64_t rows, int64_t wn,
-                                                                  int rank, int skip_below) {
+                                                                  int rank, int skip_below, int RU_ROWS) {
   __shared__ __attribute__((aligned(16))) word tab[16][16][TW];  // [table][entry][word]
   const int tid      = threadIdx.x;
   const int64_t w0   = (int64_t)blockIdx.x * TW;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
   const int ntab  = (rank + 3) >> 2;
   if (!one) return;
   // four rows per trip: their loads are issued together (one row in flight per lane leaves HBM mostly idle)
-  constexpr int RSTEP = THREADS / LPR, UNR = 4;
+  constexpr int RSTEP = THREADS / LPR, UNR = RU_UNR;
   for (int64_t rb = r_lo + rsub; rb < r_hi; rb += (int64_t)RSTEP * UNR) {
     word m[UNR], x0[UNR], x1[UNR];
 #pragma unroll
@@ -277,10 +280,18 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
 template <bool VEC>
 hipError_t launch_rank_update(hipStream_t st, int variant, word *C, int64_t cs, const word *M, const word *U, int64_t us, int64_t rows, int64_t wn,
                               int rank, int skip) {
+  // rows per workgroup: about 2048 workgroups per launch (8 per CU), between 256 and 2048 rows in whole 128-row trips --
+  // the trailing matrix shrinks from 1 GiB to nothing over a decomposition, and a fixed 2048 rows left the late
+  // launches with a handful of workgroups (65536^2: 135 -> 110 ms over all 1023 launches); M4RI_AMD_RU_ROWS overrides
+  static const int forced = getenv("M4RI_AMD_RU_ROWS") ? atoi(getenv("M4RI_AMD_RU_ROWS")) : 0;
+  const int tw_ = variant == 64 ? 64 : variant == 32 ? 32 : 16;
+  int64_t want = rows * ((wn + tw_ - 1) / tw_) / 2048;
+  want = (want + 127) / 128 * 128;
+  const int RU_ROWS = forced > 0 ? forced : (int)(want < 256 ? 256 : want > RU_ROWS_DEFAULT ? RU_ROWS_DEFAULT : want);
   const unsigned gy = (unsigned)((rows + RU_ROWS - 1) / RU_ROWS);
 #define RU_LAUNCH(TW, TH)                                                                                                              \
   hipLaunchKernelGGL((ple_rank_update_kernel<VEC, TW, TH>), dim3((unsigned)((wn + TW - 1) / TW), gy), dim3(TH), 0, st, C, cs, M, U, us, rows, wn, \
-                     rank, skip)
+                     rank, skip, RU_ROWS)
   if (variant == 64) RU_LAUNCH(64, 1024);
   else if (variant == 32) RU_LAUNCH(32, 512);
   else RU_LAUNCH(16, 256);
