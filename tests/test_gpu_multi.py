@@ -103,3 +103,21 @@ def test_bench_ranks_on_one_gpu(world, variant, layout):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("-> OK") == world, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("m,l,n,seeds,world", [(65536, 65536, 65536, (3, 4), 8),        # BASELINE.json configs[3]: the sharded execution path
+                                               (131072, 8192, 131072, (5, 6), 8)])      # BASELINE.json configs[4]
+def test_baseline_sizes_through_the_sharded_path_vs_reference_sha256(m, l, n, seeds, world):
+    """The two 8-GPU configurations of BASELINE.json at full size through the multi-device path (8 ranks on this one
+    GPU: own streams, slabs, peer copies, sub-products), against the SHA-256 of the real reference's product
+    (tests/golden/sha256.json)."""
+    import hashlib
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "sha256.json")
+    want = [e["sha256"] for e in json.load(open(path)) if (e["op"], e["m"], e["l"], e["n"], e["seed_a"], e["seed_b"]) == ("mul", m, l, n, *seeds)]
+    assert want, "no golden SHA-256 for this product"
+    m4ri_amd.set_devices([0] * world)
+    A, B = Mzd.random(m, l, seeds[0]), Mzd.random(l, n, seeds[1])
+    C = Mzd.init(m, n)
+    m4ri_amd.mul_multi(C, A, B, False, 0, 0)
+    assert hashlib.sha256(C.masked().tobytes()).hexdigest() == want[0]
