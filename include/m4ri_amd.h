@@ -98,6 +98,12 @@ void _mzd_trsm_lower_left_russian(mzd_t const *L, mzd_t *B, int k);
 void mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff);
 void _mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff);
 void _mzd_trsm_upper_left_russian(mzd_t const *U, mzd_t *B, int k);
+/* The right-hand forms, B <- B U^-1 / B <- B L^-1 (X T = B): m4ri/triangular.h:50, :64, :82, :100 (triangular.c:41-130,
+ * :301-393).  Same rules: unique solution, diagonal and other triangle never read, windows allowed. */
+void mzd_trsm_upper_right(mzd_t const *U, mzd_t *B, const int cutoff);
+void _mzd_trsm_upper_right(mzd_t const *U, mzd_t *B, const int cutoff);
+void mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff);
+void _mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff);
 
 /* ---- PLE decomposition -----------------------------------------------------------
  * A = P L E Q in place: returns the rank r; afterwards the first r columns of A hold L below the diagonal (unit
@@ -190,6 +196,11 @@ int m4ri_amd_trsm_lower_left_dev(const word *L, int64_t t_stride, word *B, int64
                                  void *stream);
 int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
                                  void *stream);
+/* B (mb x nb) <- B U^-1 / B L^-1, T (nb x nb, device) unit triangular: the right-hand twins. */
+int m4ri_amd_trsm_upper_right_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                  void *stream);
+int m4ri_amd_trsm_lower_right_dev(const word *L, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                  void *stream);
 /* Device twins of mzd_process_rowsN / mzd_make_table (elim.hip): streaming, HBM-bound.  kbits[t]: bits of group
  * t (lowest first); L[t]: 2^kbits[t] table row numbers; idx_scratch: 6 * (stoprow - startrow) int32; jstar: see
  * elim.hip (all zeros when rows r .. r+k-1 exist).  Asynchronous on `stream`. */

@@ -90,6 +90,12 @@ SYMBOLS = {
     "mzd_trsm_upper_left": (None, [MzdPtr, MzdPtr, _I]),
     "_mzd_trsm_upper_left": (None, [MzdPtr, MzdPtr, _I]),
     "_mzd_trsm_upper_left_russian": (None, [MzdPtr, MzdPtr, _I]),
+    "mzd_trsm_upper_right": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_upper_right": (None, [MzdPtr, MzdPtr, _I]),
+    "mzd_trsm_lower_right": (None, [MzdPtr, MzdPtr, _I]),
+    "_mzd_trsm_lower_right": (None, [MzdPtr, MzdPtr, _I]),
+    "m4ri_amd_trsm_upper_right_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "m4ri_amd_trsm_lower_right_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
     "m4ri_amd_trsm_lower_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
     "m4ri_amd_trsm_upper_left_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I, _P]),
     "mzd_fprint_row": (None, [_P, MzdPtr, _I]),

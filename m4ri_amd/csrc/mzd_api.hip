@@ -396,18 +396,21 @@ void inout_end(InOut &io, mzd_t *M) {
   }
 }
 
-// B <- T^-1 B for a unit triangular T (triangular.c:406-455, :467-514); T's other triangle and diagonal are never read
-void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff) {
+// B <- T^-1 B (left) or B <- B T^-1 (right) for a unit triangular T (triangular.c:41-514); T's other triangle and
+// diagonal are never read
+void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff, bool right = false) {
   std::lock_guard<std::mutex> lk(g_api_mu);
-  if (B->nrows <= 1 || B->ncols == 0) return;  // one row: X = B
+  if (B->nrows == 0 || B->ncols == 0 || (!right && B->nrows <= 1) || (right && B->ncols <= 1)) return;  // one unknown per system: X = B
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
   arena_reserve((find_pin(T) ? 0 : dev_words(T->nrows, T->ncols)) + inout_words(B));
   const DevMat dT = operand(T, true);
   InOut io        = inout_begin(B);
-  if (upper) HIPDIE(m4ri_amd_trsm_upper_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
-  else       HIPDIE(m4ri_amd_trsm_lower_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  if (right && upper) HIPDIE(m4ri_amd_trsm_upper_right_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  else if (right)     HIPDIE(m4ri_amd_trsm_lower_right_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  else if (upper)     HIPDIE(m4ri_amd_trsm_upper_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
+  else                HIPDIE(m4ri_amd_trsm_lower_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
   inout_end(io, B);
   HIPDIE(hipDeviceSynchronize());
   g_api_stats.calls += 1;
@@ -533,6 +536,19 @@ void mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff) {  // trian
 }
 void _mzd_trsm_upper_left(mzd_t const *U, mzd_t *B, const int cutoff) { run_trsm(true, U, B, cutoff < 0 ? 0 : cutoff); }  // triangular.c:467
 void _mzd_trsm_upper_left_russian(mzd_t const *U, mzd_t *B, int k) { (void)k; run_trsm(true, U, B, 0); }  // triangular_russian.c:50
+
+void mzd_trsm_upper_right(mzd_t const *U, mzd_t *B, const int cutoff) {  // triangular.c:41-50
+  if (U->nrows != B->ncols) die("mzd_trsm_upper_right: U nrows (%d) need to match B ncols (%d).\n", U->nrows, B->ncols);
+  if (U->nrows != U->ncols) die("mzd_trsm_upper_right: U must be square and is found to be (%d) x (%d).\n", U->nrows, U->ncols);
+  run_trsm(true, U, B, cutoff < 0 ? 0 : cutoff, true);
+}
+void _mzd_trsm_upper_right(mzd_t const *U, mzd_t *B, const int cutoff) { run_trsm(true, U, B, cutoff < 0 ? 0 : cutoff, true); }  // triangular.c:61
+void mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff) {  // triangular.c:301-310
+  if (L->nrows != B->ncols) die("mzd_trsm_lower_right: L nrows (%d) need to match B ncols (%d).\n", L->nrows, B->ncols);
+  if (L->nrows != L->ncols) die("mzd_trsm_lower_right: L must be square and is found to be (%d) x (%d).\n", L->nrows, L->ncols);
+  run_trsm(false, L, B, cutoff < 0 ? 0 : cutoff, true);
+}
+void _mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff) { run_trsm(false, L, B, cutoff < 0 ? 0 : cutoff, true); }  // triangular.c:312
 
 // ---- PLE decomposition: the reference's names, host mzd_t / mzp_t in and out ---------
 static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q) {

@@ -97,9 +97,72 @@ int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb
   return solve(true, T00, ts, B0, bs, mb1, nb, cutoff, st);
 }
 
+// ---- right-hand solves: B <- B * T^-1 (X * T = B) -----------------------------------------------------------------
+// (triangular.c:41-130 upper, :301-393 lower).  The unknowns of a row are its own bits, so the base case works
+// inside one 64-bit word per row: x_j = b_j ^ parity(x & col_j(T)) for the columns in dependency order (ascending for
+// an upper triangle, descending for a lower one) -- a thread per row, the 64 column masks of the triangle built once
+// per workgroup in LDS.  Above 64 columns: halves on a word boundary, the update one engine product.
+template <bool UPPER>
+__global__ __launch_bounds__(256) void trsm_right_base_kernel(const word *__restrict__ T, int64_t t_stride, word *__restrict__ B,
+                                                              int64_t b_stride, int64_t mb, int nb) {
+  __shared__ word col[64];  // col[j]: bit i = T[i][j] for the rows i that x_j depends on
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x;
+    word c = 0;
+    if (j < nb)
+      for (int i = UPPER ? 0 : j + 1; i < (UPPER ? j : nb); ++i) c |= ((T[(int64_t)i * t_stride] >> j) & 1) << i;
+    col[j] = c;
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= mb) return;
+  word x = B[r * b_stride];
+  if (UPPER) {
+    for (int j = 1; j < nb; ++j) x ^= (word)(__popcll(x & col[j]) & 1) << j;
+  } else {
+    for (int j = nb - 2; j >= 0; --j) x ^= (word)(__popcll(x & col[j]) & 1) << j;
+  }
+  B[r * b_stride] = x;
+}
+
+int solve_right(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb, int64_t nb, int cutoff, hipStream_t st) {
+  if (mb <= 0 || nb <= 1) return 0;
+  if (nb <= 64) {
+    const unsigned g = (unsigned)((mb + 255) / 256);
+    if (upper) hipLaunchKernelGGL((trsm_right_base_kernel<true>), dim3(g), dim3(256), 0, st, T, ts, B, bs, mb, (int)nb);
+    else       hipLaunchKernelGGL((trsm_right_base_kernel<false>), dim3(g), dim3(256), 0, st, T, ts, B, bs, mb, (int)nb);
+    return (int)hipGetLastError();
+  }
+  const int64_t nb1 = (((nb - 1) / 64 + 1) >> 1) * 64;  // triangular.c:72, :319
+  word *B0 = B, *B1 = B + nb1 / 64;
+  const word *T00 = T, *T11 = T + nb1 * ts + nb1 / 64;
+  if (upper) {
+    const word *U01 = T + nb1 / 64;  // nb1 x (nb - nb1)
+    if (int rc = solve_right(true, T00, ts, B0, bs, mb, nb1, cutoff, st)) return rc;
+    HIPTRY(m4ri_amd_mul_dev(B1, bs, B0, bs, U01, ts, mb, nb1, nb - nb1, 1, cutoff, st));
+    return solve_right(true, T11, ts, B1, bs, mb, nb - nb1, cutoff, st);
+  }
+  const word *L10 = T + nb1 * ts;    // (nb - nb1) x nb1
+  if (int rc = solve_right(false, T11, ts, B1, bs, mb, nb - nb1, cutoff, st)) return rc;
+  HIPTRY(m4ri_amd_mul_dev(B0, bs, B1, bs, L10, ts, mb, nb - nb1, nb1, 1, cutoff, st));
+  return solve_right(false, T00, ts, B0, bs, mb, nb1, cutoff, st);
+}
+
 }  // namespace
 
 extern "C" {
+
+// B (mb x nb) <- B * U^-1 / B * L^-1, T (nb x nb) unit triangular (diagonal and other triangle never read)
+int m4ri_amd_trsm_upper_right_dev(const word *U, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                  void *stream) {
+  if (mb < 0 || nb < 0 || cutoff < 0) return (int)hipErrorInvalidValue;
+  return solve_right(true, U, t_stride, B, b_stride, mb, nb, cutoff, (hipStream_t)stream);
+}
+int m4ri_amd_trsm_lower_right_dev(const word *L, int64_t t_stride, word *B, int64_t b_stride, int64_t mb, int64_t nb, int cutoff,
+                                  void *stream) {
+  if (mb < 0 || nb < 0 || cutoff < 0) return (int)hipErrorInvalidValue;
+  return solve_right(false, L, t_stride, B, b_stride, mb, nb, cutoff, (hipStream_t)stream);
+}
 
 // B (mb x nb bits, stride b_stride) <- L^-1 B, L (mb x mb, stride t_stride) unit lower triangular: only the
 // bits strictly below its diagonal are read.  Device pointers; bits of B at column >= nb must be zero on

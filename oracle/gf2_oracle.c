@@ -538,3 +538,25 @@ void gf2o_process_rows(gf2o_mat *M, int32_t startrow, int32_t stoprow, int32_t s
     }
   }
 }
+
+
+/* ---- right-hand triangular solves (m4ri/triangular.c:41-130, :301-393): X T = B, column by column ------------ */
+static void o_flip(gf2o_mat *M, int64_t r, int64_t c) { M->data[r * M->rowstride + c / 64] ^= (gf2o_word)1 << (c % 64); }
+
+void gf2o_trsm_upper_right(const gf2o_mat *U, gf2o_mat *B) {  /* x_j = b_j + sum_{i<j} x_i U[i,j] */
+  for (int64_t r = 0; r < B->nrows; ++r)
+    for (int64_t j = 1; j < B->ncols; ++j) {
+      int p = 0;
+      for (int64_t i = 0; i < j; ++i) p ^= o_bit(B, r, i) & o_bit(U, i, j);
+      if (p) o_flip(B, r, j);
+    }
+}
+
+void gf2o_trsm_lower_right(const gf2o_mat *L, gf2o_mat *B) {  /* x_j = b_j + sum_{i>j} x_i L[i,j], j descending (triangular.c:366-393) */
+  for (int64_t r = 0; r < B->nrows; ++r)
+    for (int64_t j = (int64_t)B->ncols - 2; j >= 0; --j) {
+      int p = 0;
+      for (int64_t i = j + 1; i < B->ncols; ++i) p ^= o_bit(B, r, i) & o_bit(L, i, j);
+      if (p) o_flip(B, r, j);
+    }
+}

@@ -70,6 +70,9 @@ gf2o_mat *gf2o_addmul(gf2o_mat *C, const gf2o_mat *A, const gf2o_mat *B, int cut
  * the whole matrix -- the solution is unique, so this equals the reference's recursive / Russian schedules */
 void gf2o_trsm_lower_left(const gf2o_mat *L, gf2o_mat *B);
 void gf2o_trsm_upper_left(const gf2o_mat *U, gf2o_mat *B);
+/* right-hand forms, B <- B T^-1 (m4ri/triangular.c:41-130, :301-393): column substitution */
+void gf2o_trsm_upper_right(const gf2o_mat *U, gf2o_mat *B);
+void gf2o_trsm_lower_right(const gf2o_mat *L, gf2o_mat *B);
 
 /* PLE decomposition in place, the semantics of _mzd_ple_russian (m4ri/ple_russian.c:380-617): columns left
  * to right, pivot = the first row at or below the current rank position with a set bit in the column after

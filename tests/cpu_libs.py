@@ -41,6 +41,8 @@ class Oracle:
             "gf2o_free": (None, [MzdPtr]),
             "gf2o_trsm_lower_left": (None, [MzdPtr, MzdPtr]),
             "gf2o_trsm_upper_left": (None, [MzdPtr, MzdPtr]),
+            "gf2o_trsm_upper_right": (None, [MzdPtr, MzdPtr]),
+            "gf2o_trsm_lower_right": (None, [MzdPtr, MzdPtr]),
             "gf2o_ple": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
             "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
             "gf2o_process_rows": (None, [MzdPtr, _I, _I, _I, _I, _I, ctypes.c_void_p, ctypes.c_void_p]),
@@ -93,6 +95,14 @@ class Oracle:
         r = self.L.gf2o_ple(A.ptr, P.ctypes.data, Q.ctypes.data)
         return int(r), P[:A.nrows], Q[:A.ncols]
 
+    def trsm_upper_right(self, U, B):
+        self.L.gf2o_trsm_upper_right(U.ptr, B.ptr)
+        return B
+
+    def trsm_lower_right(self, L_, B):
+        self.L.gf2o_trsm_lower_right(L_.ptr, B.ptr)
+        return B
+
     def fill(self, A, seed):
         self.L.gf2o_fill_splitmix(A.ptr, seed)
 
@@ -139,7 +149,8 @@ class Reference:
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         for name in ("mzd_trsm_lower_left", "_mzd_trsm_lower_left", "_mzd_trsm_lower_left_russian",
-                     "mzd_trsm_upper_left", "_mzd_trsm_upper_left", "_mzd_trsm_upper_left_russian"):
+                     "mzd_trsm_upper_left", "_mzd_trsm_upper_left", "_mzd_trsm_upper_left_russian",
+                     "mzd_trsm_upper_right", "_mzd_trsm_upper_right", "mzd_trsm_lower_right", "_mzd_trsm_lower_right"):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = None, [MzdPtr, MzdPtr, _I]
         for name in ("_mzd_ple_russian", "_mzd_pluq_russian", "mzd_ple", "mzd_pluq"):

@@ -99,3 +99,58 @@ def test_large_solve_is_an_inverse(oracle):
         diag = np.where((rows // 64) == j, np.uint64(1) << (rows % 64).astype(np.uint64), np.uint64(0))
         Uc.valid_words()[:, j] = (U.valid_words()[:, j] & ~low) | diag
     assert m4ri_amd.mzd_mul(None, Uc, Y, 0).equal(B)
+
+
+RIGHT_SHAPES = [(1, 1), (65, 2), (10, 57), (64, 64), (1, 65), (300, 100), (64, 128), (513, 200), (129, 511), (70, 1000), (200, 2049),
+                (131, 2500), (400, 4096)]
+
+
+def _unit_diag(T):
+    for i in range(T.nrows):
+        T.valid_words()[i, i // 64] |= np.uint64(1) << np.uint64(i % 64)
+    return T
+
+
+@pytest.mark.parametrize("mb,nb", RIGHT_SHAPES)
+@pytest.mark.parametrize("upper", [False, True])
+def test_right_trsm_matches_oracle(oracle, mb, nb, upper):
+    """B <- B T^-1 (mzd_trsm_{upper,lower}_right and their _mzd_ forms; m4ri/triangular.c:41-130, :301-393)."""
+    T = _unit_diag(Mzd.random(nb, nb, 300 + nb))
+    B = Mzd.random(mb, nb, 400 + mb)
+    want = (oracle.trsm_upper_right if upper else oracle.trsm_lower_right)(T, B.copy())
+    L = m4ri_amd.lib()
+    for name in (("mzd_trsm_upper_right", "_mzd_trsm_upper_right") if upper else ("mzd_trsm_lower_right", "_mzd_trsm_lower_right")):
+        got = B.copy()
+        getattr(L, name)(T.ptr, got.ptr, 0)
+        assert np.array_equal(got.valid_words(), want.valid_words()), (name, mb, nb)
+
+
+@pytest.mark.parametrize("upper", [False, True])
+def test_right_trsm_on_windows_keeps_the_parent(oracle, upper):
+    P, Q = _unit_diag(Mzd.random(900, 900, 17)), Mzd.random(600, 1100, 18)
+    for (mb, nb, c0) in [(300, 333, 64), (130, 65, 128), (513, 700, 0)]:
+        T = P.window(64, 64, 64 + nb, 64 + nb)   # the window's diagonal is the parent's
+        Qo, Qg = Mzd(600, 1100, buf=Q.buf.copy()), Mzd(600, 1100, buf=Q.buf.copy())
+        bo, bg = Qo.window(5, c0, 5 + mb, c0 + nb), Qg.window(5, c0, 5 + mb, c0 + nb)
+        (oracle.trsm_upper_right if upper else oracle.trsm_lower_right)(T, bo)
+        getattr(m4ri_amd.lib(), "mzd_trsm_upper_right" if upper else "mzd_trsm_lower_right")(T.ptr, bg.ptr, 0)
+        assert np.array_equal(Qo.buf, Qg.buf)
+
+
+def test_large_right_solve_is_an_inverse():
+    """20000 x 8192 right-hand solves: X * T == B through the (independently tested) product, T's junk triangle cleared."""
+    mb, nb = 20000, 8192
+    B = Mzd.random(mb, nb, 71)
+    rows = np.arange(nb)
+    R = Mzd.random(nb, nb, 72)
+    for upper in (True, False):
+        Tc = Mzd.init(nb, nb)
+        for j in range(Tc.width):
+            keep = np.clip(rows - 64 * j + (1 if upper else 0), 0, 64).astype(np.uint64)   # bits <= r (upper) / < r (lower) of word j
+            low = np.where(keep >= 64, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << keep) - np.uint64(1))
+            diag = np.where((rows // 64) == j, np.uint64(1) << (rows % 64).astype(np.uint64), np.uint64(0))
+            w = R.valid_words()[:, j]
+            Tc.valid_words()[:, j] = ((w & ~low) if upper else (w & low)) | diag
+        X = B.copy()
+        (m4ri_amd.mzd_trsm_upper_right if False else getattr(m4ri_amd.lib(), "mzd_trsm_upper_right" if upper else "mzd_trsm_lower_right"))(Tc.ptr, X.ptr, 0)
+        assert m4ri_amd.mzd_mul(None, X, Tc, 0).equal(B), "upper" if upper else "lower"

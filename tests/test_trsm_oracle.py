@@ -45,3 +45,23 @@ def test_trsm_on_windows(oracle, reference, upper):
             oracle.trsm_lower_left(T, bo)
             reference.L.mzd_trsm_lower_left(T.ptr, br.ptr, 0)
         assert np.array_equal(Qo.buf, Qr.buf)
+
+
+@pytest.mark.parametrize("mb,nb", [(1, 1), (65, 2), (10, 57), (64, 64), (1, 65), (300, 100), (64, 128), (513, 200), (129, 511), (70, 1000),
+                                   (200, 2049), (131, 2500)])
+@pytest.mark.parametrize("upper", [False, True])
+def test_right_trsm_matches_reference(oracle, reference, mb, nb, upper):
+    """B <- B T^-1 (m4ri/triangular.c:41-130, :301-393: recursion, trtri + product between 65 and 2048 columns, parity
+    tricks in the 64-column base): the oracle's column substitution gives the same bits."""
+    T = Mzd.random(nb, nb, 300 + nb)   # the other triangle is junk; the diagonal is set: between 65 and 2048 columns the reference
+    for i in range(nb):                # inverts a copy of the triangle INCLUDING its diagonal (triangular.c:52-59, mzd_extract_u)
+        T.valid_words()[i, i // 64] |= np.uint64(1) << np.uint64(i % 64)
+    B = Mzd.random(mb, nb, 400 + mb)
+    Bo, Br = B.copy(), B.copy()
+    if upper:
+        oracle.trsm_upper_right(T, Bo)
+        reference.L.mzd_trsm_upper_right(T.ptr, Br.ptr, 0)
+    else:
+        oracle.trsm_lower_right(T, Bo)
+        reference.L.mzd_trsm_lower_right(T.ptr, Br.ptr, 0)
+    assert np.array_equal(Bo.valid_words(), Br.valid_words())
