@@ -109,11 +109,19 @@ void _mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff);
  * A = P L E Q in place: returns the rank r; afterwards the first r columns of A hold L below the diagonal (unit
  * diagonal implied), E sits in the rows 0..r-1 from each row's pivot column on, P (A->nrows entries) and Q
  * (A->ncols entries) hold the row / column transpositions -- exactly the reference's output, which is fixed by
- * its pivoting rule (first row with a set bit, columns left to right), not by its schedule.  `cutoff`, `k`:
- * hints.  m4ri/ple.h:103, :137; m4ri/ple_russian.h:81 (ple.c:33-171, ple_russian.c:380-617). */
+ * its pivoting rule (first row with a set bit, columns left to right), not by its schedule -- except the entries
+ * of Q behind the rank, which mzd_ple / _mzd_ple fill by their recursion on column halves and _mzd_ple_russian
+ * leaves as the identity; both are reproduced (M4RI_AMD_PLE_CUTOFF below).  `cutoff`, `k`: hints.  m4ri/ple.h:103, :137; m4ri/ple_russian.h:81 (ple.c:33-171, ple_russian.c:380-617). */
 rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
 rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
 rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k);
+/* A = P L U Q in place (m4ri/ple.h:70, :120; ple_russian.h:98; ple.c:41-60): the PLE above, then the columns of the
+ * first r rows permuted so that U is upper triangular with its pivots on the diagonal
+ * (mzd_apply_p_right_trans_tri, m4ri/mzp.h:202, mzp.c:279-293, exported as well). */
+rci_t mzd_pluq(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
+rci_t _mzd_pluq(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
+rci_t _mzd_pluq_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k);
+void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q);
 
 /* ---- the table primitives of M4RI's elimination routines -----------------------------
  * mzd_make_table (m4ri/brilliantrussian.h:56, .c:163-211): T[i], i = 1 .. 2^k - 1, = the Gray-code combinations of
@@ -210,8 +218,20 @@ int m4ri_amd_process_rows_dev(word *M, int64_t stride, int64_t width, int64_t st
 int m4ri_amd_make_table_dev(const word *M, int64_t m_stride, int64_t m_rows, int64_t ncols, int64_t r, int64_t c, int k, const word *Tin,
                             word *Tout, int64_t t_stride, const int32_t *jstar, void *stream);
 /* PLE of a device matrix in place (bits at column >= ncols zero in, zero out).  P (nrows entries) and Q (ncols
- * entries) are HOST arrays.  Blocking: the pivots of every 64-column block are read back. */
-int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out, void *stream);
+ * entries) are HOST arrays.  Blocking: the pivots of every 64-column block are read back.
+ * recursion_cutoff: 0 gives _mzd_ple_russian's Q (the pivot columns, then the identity); M4RI_AMD_PLE_CUTOFF gives
+ * _mzd_ple's, whose recursion on column halves (m4ri/ple.c:62-171) leaves other transpositions behind the rank --
+ * which ones depends on the recursion's shape, i.e. on __M4RI_PLE_CUTOFF of the reference build (m4ri/ple.h:40:
+ * 524288 words for any L3 cache of 4 MiB or more).  Matrix, P, rank and pivots are the same either way. */
+#define M4RI_AMD_PLE_CUTOFF 524288
+int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
+                     int64_t recursion_cutoff, void *stream);
+/* PLUQ in place (m4ri/ple.c:50-60): the PLE, then the column step below on the first `rank` rows.  Blocking. */
+int m4ri_amd_pluq_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
+                      int64_t recursion_cutoff, void *stream);
+/* Row r <- its columns under the transpositions (i, Q[i]), i = r+1 .. ncols-1 ascending (mzd_apply_p_right_trans_tri,
+ * m4ri/mzp.c:279-293).  Q: HOST array, ncols entries, Q[i] >= i.  Blocking. */
+int m4ri_amd_apply_p_right_trans_tri_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *Q, void *stream);
 /* Deterministic fill: word (r, j) = splitmix64 stream `seed`, output number r*width + j, last word
  * masked -- the order mzd_randomize_custom fills a matrix in (mzd.c:1282-1292). */
 int m4ri_amd_fill_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, uint64_t seed, void *stream);

@@ -117,7 +117,13 @@ SYMBOLS = {
     "mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "_mzd_ple": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "_mzd_ple_russian": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
-    "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mzd_pluq": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "_mzd_pluq": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "_mzd_pluq_russian": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
+    "mzd_apply_p_right_trans_tri": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
+    "m4ri_amd_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
+    "m4ri_amd_apply_p_right_trans_tri_dev": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
     "m4ri_amd_mzd_free": (None, [MzdPtr]),
     "m4ri_amd_result_free": (None, [MzdPtr]),
@@ -255,6 +261,15 @@ def mzd_ple(A: Mzd, cutoff: int = 0, which: str = "mzd_ple"):
     mq.values, mq.length = Q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), A.ncols
     r = getattr(lib(), which)(A.ptr, ctypes.byref(mp), ctypes.byref(mq), cutoff)
     return int(r), P[:A.nrows], Q[:A.ncols]
+
+
+def mzd_apply_p_right_trans_tri(A: Mzd, Q) -> None:
+    """Row r of A <- its columns under the transpositions (i, Q[i]), i > r (reference m4ri/mzp.h:202)."""
+    import numpy as np
+    q = np.ascontiguousarray(Q, dtype=np.int32)
+    mq = Mzp()
+    mq.values, mq.length = q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(q)
+    lib().mzd_apply_p_right_trans_tri(A.ptr, ctypes.byref(mq))
 
 
 # ---- I/O formats (reference m4ri/io.h) ---------------------------------------------------------------

@@ -551,7 +551,7 @@ void mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff) {  // tria
 void _mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff) { run_trsm(false, L, B, cutoff < 0 ? 0 : cutoff, true); }  // triangular.c:312
 
 // ---- PLE decomposition: the reference's names, host mzd_t / mzp_t in and out ---------
-static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q) {
+static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q, bool pluq, bool russian) {
   std::lock_guard<std::mutex> lk(g_api_mu);
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
@@ -564,7 +564,8 @@ static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q) {
   arena_reserve(inout_words(A));
   InOut io = inout_begin(A);
   int32_t rank = 0;
-  HIPDIE(m4ri_amd_ple_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, Q->values, &rank, nullptr));
+  HIPDIE((pluq ? m4ri_amd_pluq_dev : m4ri_amd_ple_dev)(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, Q->values, &rank,
+                                                       russian ? 0 : M4RI_AMD_PLE_CUTOFF, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
   g_api_stats.calls += 1;
@@ -575,10 +576,34 @@ rci_t mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) {  // ple.c:33-39
   (void)cutoff;
   if (P->length != A->nrows) die("mzd_ple: Permutation P length (%d) must match A nrows (%d)\n", P->length, A->nrows);
   if (Q->length != A->ncols) die("mzd_ple: Permutation Q length (%d) must match A ncols (%d)\n", Q->length, A->ncols);
-  return run_ple(A, P, Q);
+  return run_ple(A, P, Q, false, false);
 }
-rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) { (void)cutoff; return run_ple(A, P, Q); }  // ple.c:62-171
-rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return run_ple(A, P, Q); }           // ple_russian.c:380-617
+rci_t _mzd_ple(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) { (void)cutoff; return run_ple(A, P, Q, false, false); }  // ple.c:62-171
+rci_t _mzd_ple_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return run_ple(A, P, Q, false, true); }           // ple_russian.c:380-617
+
+rci_t mzd_pluq(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) {  // ple.c:41-48
+  (void)cutoff;
+  if (P->length != A->nrows) die("mzd_pluq: Permutation P length (%d) must match A nrows (%d)\n", P->length, A->nrows);
+  if (Q->length != A->ncols) die("mzd_pluq: Permutation Q length (%d) must match A ncols (%d)\n", Q->length, A->ncols);
+  return run_ple(A, P, Q, true, false);
+}
+rci_t _mzd_pluq(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff) { (void)cutoff; return run_ple(A, P, Q, true, false); }  // ple.c:50-60
+rci_t _mzd_pluq_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return run_ple(A, P, Q, true, true); }         // ple_russian.c:625-629
+
+void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q) {  // mzp.c:279-293
+  if (Q->length != A->ncols) die("mzd_apply_p_right_trans_tri: Permutation length (%d) must match A ncols (%d)\n", Q->length, A->ncols);
+  if (A->nrows == 0 || A->ncols == 0) return;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  HIPDIE(m4ri_amd_apply_p_right_trans_tri_dev(io.d.p, io.d.stride, A->nrows, A->ncols, Q->values, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+}
 
 // ---- the table primitives of the elimination routines (elim.hip) -------------------------
 static word *arena_raw(size_t words) {  // plain words from the staging arena (256-byte granules)

@@ -338,12 +338,65 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_compress_kernel(word *__restr
   }
 }
 
+
+// ---- the column step of PLUQ: mzd_apply_p_right_trans_tri (m4ri/mzp.c:279-293) ----------------------------------------
+// Row r takes the column transpositions (i, Q[i]) for i = r+1 .. ncols-1 in ascending order.  As a gather: new
+// row[c] = old row[s_r[c]], and the source maps of consecutive rows differ by one transposition of VALUES,
+// s_{r-1} = (r  Q[r]) o s_r  (the swap of row r-1's first step acts before all the others).  The host walks r downwards
+// keeping s and its inverse, which turns every step into two writes (position, value); the device rebuilds the maps of
+// a group of rows from the group's base map plus a prefix of that write list, then gathers: a wave per output word,
+// lane = bit, source bits from the row's copy in LDS, the word assembled by a ballot.
+constexpr int QT_THREADS = 256;
+
+__global__ __launch_bounds__(QT_THREADS) void qtri_build_kernel(const uint32_t *__restrict__ base, uint32_t *__restrict__ S,
+                                                                 uint32_t *__restrict__ base_next, int64_t ncols, const int2 *__restrict__ writes,
+                                                                 const int32_t *__restrict__ cnt, int g) {
+  const int i   = blockIdx.x;
+  uint32_t *dst = i < g ? S + (int64_t)i * ncols : base_next;
+  for (int64_t c = threadIdx.x; c < ncols; c += QT_THREADS) dst[c] = base[c];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = cnt[i];
+    for (int t = 0; t < n; ++t) dst[writes[t].x] = (uint32_t)writes[t].y;  // in order: later steps overwrite earlier ones
+  }
+}
+
+template <bool LDSROW>
+__global__ __launch_bounds__(QT_THREADS) void qtri_gather_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wend, int64_t ncols,
+                                                                  int64_t row_hi, const uint32_t *__restrict__ S, const word *__restrict__ rowcopy) {  // rowcopy: rows row_hi-g+1 .. row_hi
+  extern __shared__ word lrow[];
+  const int i       = blockIdx.x;
+  const int64_t rho = row_hi - i;
+  word *row         = A + rho * stride;
+  const word *src;
+  if (LDSROW) {
+    for (int64_t w = threadIdx.x; w < width; w += QT_THREADS) lrow[w] = row[w];
+    __syncthreads();
+    src = lrow;
+  } else {
+    src = rowcopy + (int64_t)(gridDim.x - 1 - i) * width;
+  }
+  const uint32_t *s = S + (int64_t)i * ncols;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t w = rho / 64 + wave; w < wend; w += QT_THREADS / 64) {
+    const int64_t c = w * 64 + lane;
+    int bit         = 0;
+    if (c < ncols) {
+      const uint32_t sc = s[c];
+      bit               = (int)((src[sc >> 6] >> (sc & 63)) & 1);
+    }
+    const word v = __ballot(bit);
+    if (lane == 0) row[w] = v;
+  }
+}
+
 // ---- per-device scratch ------------------------------------------------------------------------------------------
 struct Scratch {
   word *V = nullptr, *Mc = nullptr, *Lc = nullptr, *pivmask = nullptr;
   int32_t *Q = nullptr;
   PleBlock *blk = nullptr;
   PleBlock *hblk = nullptr;  // pinned host mirror
+  int *lastrow = nullptr, *hlastrow = nullptr;
   int64_t rows = 0, cols = 0;
 };
 std::mutex g_ple_mu;
@@ -354,6 +407,8 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.blk), sizeof(PleBlock)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hblk), sizeof(PleBlock), hipHostMallocDefault));
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Lc), 64 * 8));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.lastrow), sizeof(int)));
+    HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hlastrow), sizeof(int), hipHostMallocDefault));
   }
   if (nrows > s.rows) {
     if (s.V) { HIPTRY(hipFree(s.V)); HIPTRY(hipFree(s.Mc)); }
@@ -372,29 +427,26 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
   return 0;
 }
 
-}  // namespace
+// ---- the driver ---------------------------------------------------------------------------------------------------
+struct PleRun {
+  word *A;
+  int64_t stride, nrows, ncols, width;
+  int32_t *P, *Q;
+  hipStream_t st;
+  Scratch *s;
+  int64_t r0;      // rows finished so far = pivots found so far
+  int64_t cutoff;  // __M4RI_PLE_CUTOFF of the reference build being matched (words); 0: no recursion
+};
 
-extern "C" {
-
-// PLE of the device matrix A (nrows x ncols, bits at column >= ncols zero) in place.  P (nrows entries) and Q
-// (ncols entries) are HOST arrays; returns the rank in *rank_out.  Blocking (reads the pivots back per block).
-int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out, void *stream) {
-  if (nrows < 0 || ncols < 0 || !P || !Q || !rank_out) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  for (int64_t i = 0; i < nrows; ++i) P[i] = (int32_t)i;  // ple_russian.c:412-414
-  for (int64_t j = 0; j < ncols; ++j) Q[j] = (int32_t)j;
-  *rank_out = 0;
-  if (nrows == 0 || ncols == 0) return 0;
-  std::lock_guard<std::mutex> lk(g_ple_mu);
-  int dev = 0;
-  HIPTRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
-  Scratch &s = g_scratch[dev];
-  if (int rc = reserve(s, nrows, ncols)) return rc;
-  const int64_t width = words_of(ncols);
-  int64_t r0 = 0;
-  for (int64_t wb = 0; wb < width && r0 < nrows; ++wb) {
-    const int ncb = (int)((ncols - wb * 64) < 64 ? (ncols - wb * 64) : 64);
+// Columns [c0, c1) (c0 on a word boundary) in blocks of 64: the t-th pivot found goes to Q[c0 + t].
+int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
+  Scratch &s = *R.s;
+  word *A = R.A;
+  const int64_t stride = R.stride, nrows = R.nrows, ncols = R.ncols, width = R.width, first = R.r0;
+  hipStream_t st = R.st;
+  for (int64_t wb = c0 / 64; wb * 64 < c1 && R.r0 < nrows; ++wb) {
+    const int64_t r0 = R.r0;
+    const int ncb = (int)((c1 - wb * 64) < 64 ? (c1 - wb * 64) : 64);
     const int64_t nleft = nrows - r0;
     hipLaunchKernelGGL(ple_extract_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
                        s.V);
@@ -425,14 +477,96 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
         HIPTRY(hipGetLastError());
       }
     }
-    HIPTRY(hipGetLastError());
     for (int t = 0; t < rank; ++t) {
-      P[r0 + t] = s.hblk->swaprow[t];
-      Q[r0 + t] = (int32_t)(wb * 64 + s.hblk->pivcol[t]);
+      R.P[r0 + t]                = s.hblk->swaprow[t];
+      R.Q[c0 + (r0 - first) + t] = (int32_t)(wb * 64 + s.hblk->pivcol[t]);
     }
-    r0 += rank;
+    R.r0 += rank;
   }
-  const int rank = (int)r0;
+  *found = R.r0 - first;
+  return 0;
+}
+
+// mzd_first_zero_row (mzd.c:1826-1841) of rows [row0, row0 + R) x words [w0, w1): one past the last row with a set bit.
+// Workgroup b takes the b-th chunk of 256 rows from the bottom and leaves at once when a chunk below it (an earlier
+// workgroup) has already reported; a wave per row, lanes across the words.
+__global__ __launch_bounds__(256) void ple_last_row_kernel(const word *__restrict__ A, int64_t stride, int64_t row0, int64_t R, int64_t w0, int64_t w1,
+                                                           int *out) {
+  const int64_t hi = R - (int64_t)blockIdx.x * 256, lo = hi > 256 ? hi - 256 : 0;
+  if (*(volatile int *)out >= hi) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t rel = hi - 1 - wave; rel >= lo; rel -= 4) {
+    const word *row = A + (row0 + rel) * stride;
+    bool any = false;
+    for (int64_t w = w0; w < w1 && !any; w += 64) {
+      const word v = (w + lane < w1) ? row[w + lane] : 0;
+      any = __ballot(v != 0) != 0;
+    }
+    if (any) {
+      if (lane == 0) atomicMax(out, (int)(rel + 1));
+      return;  // the wave's remaining rows lie further up in the matrix (smaller rel): nothing more to add
+    }
+  }
+}
+
+// The recursion of _mzd_ple (ple.c:62-171) as far as it can be seen from outside.  The elimination itself runs in blocks
+// of 64 columns, left to right, always updating every column to the right, so when the walk reaches a node of the
+// reference's recursion tree the node's window already holds the Schur complement the reference would see; what the
+// tree decides is only the contents of Q BEHIND the rank: a node resets its part of Q to the identity (:68), a window
+// without a set bit returns at once (:66-69), windows of <= 64 columns or <= cutoff words are one flat run (:74-81),
+// the others split their columns in halves (:96) and afterwards copy the right half's pivots down behind the left
+// half's (:146) while the right half's own entries stay.  rows: the node's A->nrows.
+int ple_rec(PleRun &R, int64_t rows, int64_t c0, int64_t c1, int64_t *found) {
+  const int64_t ncols = c1 - c0, width = words_of(ncols);
+  for (int64_t c = c0; c < c1; ++c) R.Q[c] = (int32_t)c;
+  *found = 0;
+  if (rows <= 0) return 0;
+  Scratch &s = *R.s;
+  HIPTRY(hipMemsetAsync(s.lastrow, 0, sizeof(int), R.st));
+  hipLaunchKernelGGL(ple_last_row_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, R.st, R.A, R.stride, R.r0, rows, c0 / 64, c0 / 64 + width,
+                     s.lastrow);
+  HIPTRY(hipGetLastError());
+  HIPTRY(hipMemcpyAsync(s.hlastrow, s.lastrow, sizeof(int), hipMemcpyDeviceToHost, R.st));
+  HIPTRY(hipStreamSynchronize(R.st));
+  const int64_t e = *s.hlastrow;
+  if (e == 0) return 0;
+  if (ncols <= 64 || width * rows <= R.cutoff) return ple_blocks(R, c0, c1, found);
+  const int64_t n1 = (((ncols - 1) / 64 + 1) >> 1) * 64;
+  int64_t r1 = 0, r2 = 0;
+  if (int rc = ple_rec(R, e, c0, c0 + n1, &r1)) return rc;
+  if (int rc = ple_rec(R, e - r1, c0 + n1, c1, &r2)) return rc;
+  for (int64_t t = 0; t < r2; ++t) R.Q[c0 + r1 + t] = R.Q[c0 + n1 + t];
+  *found = r1 + r2;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// PLE of the device matrix A (nrows x ncols, bits at column >= ncols zero) in place.  P (nrows entries) and Q
+// (ncols entries) are HOST arrays; returns the rank in *rank_out.  Blocking (reads the pivots back per block).
+// recursion_cutoff == 0: _mzd_ple_russian's Q (identity behind the rank); > 0: _mzd_ple's (ple.c:62-171), whose column
+// halving leaves other values behind the rank -- see ple_rec above.
+int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
+                     int64_t recursion_cutoff, void *stream) {
+  if (nrows < 0 || ncols < 0 || !P || !Q || !rank_out || recursion_cutoff < 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < nrows; ++i) P[i] = (int32_t)i;  // ple_russian.c:412-414
+  for (int64_t j = 0; j < ncols; ++j) Q[j] = (int32_t)j;
+  *rank_out = 0;
+  if (nrows == 0 || ncols == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_ple_mu);
+  int dev = 0;
+  HIPTRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  Scratch &s = g_scratch[dev];
+  if (int rc = reserve(s, nrows, ncols)) return rc;
+  const int64_t width = words_of(ncols);
+  PleRun run{A, stride, nrows, ncols, width, P, Q, st, &s, 0, recursion_cutoff};
+  int64_t found = 0;
+  if (int rc = recursion_cutoff ? ple_rec(run, nrows, 0, ncols, &found) : ple_blocks(run, 0, ncols, &found)) return rc;
+  const int rank = (int)run.r0;
   *rank_out      = rank;
   if (rank > 0) {
     std::vector<word> pm((size_t)width, 0);
@@ -448,6 +582,98 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
     }
   }
   return 0;
+}
+
+// The column step of PLUQ on a device matrix: row r <- its columns under the transpositions (i, Q[i]), i > r, ascending
+// (mzd_apply_p_right_trans_tri, mzp.c:279-293).  Q: HOST array of ncols entries with Q[i] >= i.  Blocking.
+int m4ri_amd_apply_p_right_trans_tri_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *Q, void *stream) {
+  if (nrows < 0 || ncols < 0 || !Q) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t top = -1, cmax = 0;
+  for (int64_t i = 0; i < ncols; ++i) {
+    if (Q[i] < i || Q[i] >= ncols) return (int)hipErrorInvalidValue;
+    if (Q[i] != i) { top = i; if (Q[i] > cmax) cmax = Q[i]; }
+  }
+  const int64_t rows = nrows < top ? nrows : top;  // rows >= top take identity swaps only
+  if (rows <= 0) return 0;
+  const int64_t width = words_of(ncols), wend = cmax / 64 + 1;
+  std::vector<int32_t> s((size_t)ncols), inv((size_t)ncols);
+  for (int64_t c = 0; c < ncols; ++c) s[(size_t)c] = inv[(size_t)c] = (int32_t)c;
+  std::vector<int2> writes;
+  auto step = [&](int64_t k) {  // s <- (k Q[k]) o s
+    const int32_t a = (int32_t)k, b = Q[k];
+    if (a == b) return;
+    const int32_t pa = inv[(size_t)a], pb = inv[(size_t)b];
+    s[(size_t)pa] = b; s[(size_t)pb] = a;
+    inv[(size_t)a] = pb; inv[(size_t)b] = pa;
+    writes.push_back(make_int2(pa, b));
+    writes.push_back(make_int2(pb, a));
+  };
+  for (int64_t k = top; k > rows - 1; --k) step(k);  // s = the map of row rows-1, the first one that exists
+  writes.clear();
+  int64_t G = ((int64_t)1 << 24) / ncols;
+  G = G < 16 ? 16 : (G > 256 ? 256 : G);
+  struct Group { int64_t hi; int g; size_t woff, coff; };
+  std::vector<Group> groups;
+  std::vector<int32_t> cnts;
+  std::vector<int32_t> base0(s);  // map of the first group's top row
+  for (int64_t hi = rows - 1; hi >= 0; hi -= G) {
+    const int g = (int)(hi + 1 < G ? hi + 1 : G);
+    Group gr{hi, g, writes.size(), cnts.size()};
+    for (int i = 0; i <= g; ++i) {  // entry i: writes that take the base to row hi - i (entry g: to the next group's base)
+      if (i > 0) step(hi - i + 1);
+      cnts.push_back((int32_t)(writes.size() - gr.woff));
+    }
+    groups.push_back(gr);
+  }
+  uint32_t *d_base[2] = {nullptr, nullptr}, *d_S = nullptr;
+  int2 *d_writes = nullptr;
+  int32_t *d_cnt = nullptr;
+  word *d_rowcopy = nullptr;
+  const bool ldsrow = width * 8 <= 64 * 1024;
+  int rc = 0;
+  auto run = [&]() -> int {
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_base[0]), (size_t)ncols * 4));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_base[1]), (size_t)ncols * 4));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_S), (size_t)G * ncols * 4));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_writes), (writes.size() + 1) * sizeof(int2)));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), cnts.size() * 4));
+    if (!ldsrow) HIPTRY(hipMalloc(reinterpret_cast<void **>(&d_rowcopy), (size_t)G * width * 8));
+    HIPTRY(hipMemcpyAsync(d_base[0], base0.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, st));
+    if (!writes.empty()) HIPTRY(hipMemcpyAsync(d_writes, writes.data(), writes.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    HIPTRY(hipMemcpyAsync(d_cnt, cnts.data(), cnts.size() * 4, hipMemcpyHostToDevice, st));
+    int cur = 0;
+    for (const Group &gr : groups) {
+      hipLaunchKernelGGL(qtri_build_kernel, dim3((unsigned)gr.g + 1), dim3(QT_THREADS), 0, st, d_base[cur], d_S, d_base[cur ^ 1], ncols,
+                         d_writes + gr.woff, d_cnt + gr.coff, gr.g);
+      if (ldsrow) {
+        hipLaunchKernelGGL((qtri_gather_kernel<true>), dim3((unsigned)gr.g), dim3(QT_THREADS), (size_t)width * 8, st, A, stride, width, wend, ncols, gr.hi,
+                           d_S, nullptr);
+      } else {
+        const word *lo = A + (gr.hi - gr.g + 1) * stride;
+        HIPTRY(hipMemcpy2DAsync(d_rowcopy, (size_t)width * 8, lo, (size_t)stride * 8, (size_t)width * 8, (size_t)gr.g, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL((qtri_gather_kernel<false>), dim3((unsigned)gr.g), dim3(QT_THREADS), 0, st, A, stride, width, wend, ncols, gr.hi, d_S,
+                           d_rowcopy);
+      }
+      HIPTRY(hipGetLastError());
+      cur ^= 1;
+    }
+    HIPTRY(hipStreamSynchronize(st));
+    return 0;
+  };
+  rc = run();
+  for (void *p : {(void *)d_base[0], (void *)d_base[1], (void *)d_S, (void *)d_writes, (void *)d_cnt, (void *)d_rowcopy})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+// PLUQ in place (ple.c:50-60): the PLE above, then the column step on the first `rank` rows (all rows when the rank
+// is 0 or full).
+int m4ri_amd_pluq_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
+                      int64_t recursion_cutoff, void *stream) {
+  if (int rc = m4ri_amd_ple_dev(A, stride, nrows, ncols, P, Q, rank_out, recursion_cutoff, stream)) return rc;
+  const int32_t r = *rank_out;
+  return m4ri_amd_apply_p_right_trans_tri_dev(A, stride, (r && r < nrows) ? r : nrows, ncols, Q, stream);
 }
 
 }  // extern "C"

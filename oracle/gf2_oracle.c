@@ -460,30 +460,102 @@ static void o_col_swap_in_row(gf2o_mat *A, int64_t r, int64_t a, int64_t b) {
   row[b / 64] ^= x << (b % 64);
 }
 
-int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q) {
-  const int64_t nrows = A->nrows, ncols = A->ncols;
-  for (int64_t i = 0; i < nrows; ++i) P[i] = (int32_t)i;  /* ple_russian.c:412-414 */
-  for (int64_t j = 0; j < ncols; ++j) Q[j] = (int32_t)j;
-  int64_t rank = 0;
-  for (int64_t c = 0; c < ncols && rank < nrows; ++c) {
+/* mzd_first_zero_row (mzd.c:1826-1841) of the window rows [row0, row0 + R) x columns [c0, c1), c0 on a word boundary:
+ * one past the last row with a set bit.  (For a one-word window the reference ORs the word unmasked; every caller
+ * here has zero excess bits or takes the base case either way, so the mask is always applied.) */
+static int64_t o_first_zero_row(const gf2o_mat *A, int64_t row0, int64_t R, int64_t c0, int64_t c1) {
+  const int64_t w0 = c0 / 64, w1 = (c1 + 63) / 64;
+  const gf2o_word last = (c1 % 64) ? (~(gf2o_word)0 >> (64 - c1 % 64)) : ~(gf2o_word)0;
+  for (int64_t i = R - 1; i >= 0; --i) {
+    const gf2o_word *row = A->data + (row0 + i) * A->rowstride;
+    gf2o_word any = 0;
+    for (int64_t w = w0; w < w1; ++w) any |= (w == w1 - 1) ? (row[w] & last) : row[w];
+    if (any) return i + 1;
+  }
+  return 0;
+}
+
+/* Columns [c0, c1) eliminated one by one -- what _mzd_ple_russian (ple_russian.c:380-617) computes on that window when
+ * the columns before it are done: the t-th pivot found goes to Q[c0 + t]; *rank is the running row count. */
+static int64_t o_ple_columns(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t *rank, int64_t c0, int64_t c1) {
+  const int64_t nrows = A->nrows, first = *rank;
+  for (int64_t c = c0; c < c1 && *rank < nrows; ++c) {
     int64_t piv = -1;
-    for (int64_t i = rank; i < nrows; ++i)
+    for (int64_t i = *rank; i < nrows; ++i)
       if (o_bit(A, i, c)) { piv = i; break; }            /* ple_russian.c:141-159: first row with the bit set */
     if (piv < 0) continue;
-    P[rank] = (int32_t)piv;                              /* :162-166 */
-    Q[rank] = (int32_t)c;
-    o_row_swap(A, piv, rank);
-    for (int64_t r = rank + 1; r < nrows; ++r)
-      if (o_bit(A, r, c)) o_row_add_from(A, r, rank, c + 1);  /* :150, :180-183: the multiplier stays at column c */
-    ++rank;
+    P[*rank] = (int32_t)piv;                             /* :162-166 */
+    Q[c0 + (*rank - first)] = (int32_t)c;
+    o_row_swap(A, piv, *rank);
+    for (int64_t r = *rank + 1; r < nrows; ++r)
+      if (o_bit(A, r, c)) o_row_add_from(A, r, *rank, c + 1);  /* :150, :180-183: the multiplier stays at column c */
+    ++*rank;
   }
-  /* compressing L (:596-602): row r takes the column swaps (j, Q[j]) for j = 0 .. min(r, rank - 1), in order */
-  for (int64_t r = 0; r < nrows; ++r) {
+  return *rank - first;
+}
+
+/* compressing L (ple_russian.c:596-602, ple.c:151): row r takes the column swaps (j, Q[j]) for j = 0 .. min(r, rank - 1) */
+static void o_compress_l(gf2o_mat *A, const int32_t *Q, int64_t rank) {
+  for (int64_t r = 0; r < A->nrows; ++r) {
     const int64_t last = r < rank - 1 ? r : rank - 1;
     for (int64_t j = 0; j <= last; ++j)
       if (Q[j] != j) o_col_swap_in_row(A, r, j, Q[j]);
   }
+}
+
+int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q) {
+  for (int64_t i = 0; i < A->nrows; ++i) P[i] = (int32_t)i;  /* ple_russian.c:412-414 */
+  for (int64_t j = 0; j < A->ncols; ++j) Q[j] = (int32_t)j;
+  int64_t rank = 0;
+  o_ple_columns(A, P, Q, &rank, 0, A->ncols);
+  o_compress_l(A, Q, rank);
   return (int32_t)rank;
+}
+
+/* The block recursion of _mzd_ple (ple.c:62-171) on the window rows [*rank, *rank + R) x columns [c0, c1).  The
+ * decomposed matrix, P and the first `rank` entries of Q do not depend on it (they are fixed by the pivoting rule),
+ * but the entries of Q BEHIND the rank do: a node resets its part of Q to the identity (:68), a window without a set
+ * bit returns at once (:69), small windows take the column-by-column base case (:74-81), and the others split their
+ * columns in halves (:96), recurse on the left half and on the Schur complement of the right half, and copy the right
+ * half's pivots down behind the left half's (:146) -- the right half's own entries stay where they were. */
+static int64_t o_ple_rec(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t *rank, int64_t R, int64_t c0, int64_t c1, int64_t cutoff) {
+  const int64_t ncols = c1 - c0, width = (ncols + 63) / 64;
+  const int64_t e = o_first_zero_row(A, *rank, R, c0, c1);   /* :66 */
+  for (int64_t c = c0; c < c1; ++c) Q[c] = (int32_t)c;        /* :68 */
+  if (!e) return 0;                                           /* :69 */
+  if (ncols <= 64 || width * R <= cutoff) return o_ple_columns(A, P, Q, rank, c0, c1);  /* :74-81 */
+  const int64_t n1 = (((ncols - 1) / 64 + 1) >> 1) * 64;      /* :96 */
+  const int64_t r1 = o_ple_rec(A, P, Q, rank, e, c0, c0 + n1, cutoff);       /* :105: A0 = the first e rows */
+  const int64_t r2 = o_ple_rec(A, P, Q, rank, e - r1, c0 + n1, c1, cutoff);  /* :135: A11 = rows r1 .. e */
+  for (int64_t t = 0; t < r2; ++t) Q[c0 + r1 + t] = Q[c0 + n1 + t];          /* :146 */
+  return r1 + r2;
+}
+
+int32_t gf2o_ple_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff) {
+  for (int64_t i = 0; i < A->nrows; ++i) P[i] = (int32_t)i;
+  int64_t rank = 0;
+  o_ple_rec(A, P, Q, &rank, A->nrows, 0, A->ncols, cutoff);
+  o_compress_l(A, Q, rank);
+  return (int32_t)rank;
+}
+
+static void o_apply_q_tri(gf2o_mat *A, int64_t rows, const int32_t *Q) {
+  for (int64_t row = 0; row < rows; ++row)
+    for (int64_t i = row + 1; i < A->ncols; ++i)            /* mzp.c:285-288: rows [.., min(row_bound, i)) take swap i */
+      if (Q[i] != i) o_col_swap_in_row(A, row, i, Q[i]);
+}
+
+/* ---- PLUQ (m4ri/ple.c:50-60, ple_russian.c:625-629, m4ri/mzp.c:279-293) ---------------------------------------- */
+int32_t gf2o_pluq(gf2o_mat *A, int32_t *P, int32_t *Q) {     /* _mzd_pluq_russian */
+  const int32_t r = gf2o_ple(A, P, Q);
+  o_apply_q_tri(A, A->nrows, Q);
+  return r;
+}
+
+int32_t gf2o_pluq_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff) {  /* _mzd_pluq */
+  const int32_t r = gf2o_ple_recursive(A, P, Q, cutoff);
+  o_apply_q_tri(A, (r && r < A->nrows) ? r : A->nrows, Q);  /* ple.c:52-58: the window A0 of the first r rows, or all of A */
+  return r;
 }
 
 

@@ -83,6 +83,18 @@ void gf2o_trsm_lower_right(const gf2o_mat *L, gf2o_mat *B);
  * change when row operations happen, never their outcome. */
 int32_t gf2o_ple(gf2o_mat *A, int32_t *P, int32_t *Q);
 
+/* _mzd_ple (m4ri/ple.c:62-171): the same decomposition through the reference's column-halving recursion, which
+ * leaves its own values in Q behind the rank (see gf2_oracle.c).  cutoff: __M4RI_PLE_CUTOFF (ple.h:40), in words. */
+#define GF2O_PLE_CUTOFF 524288
+int32_t gf2o_ple_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff);
+
+/* PLUQ decomposition in place: the PLE, then the column transpositions of Q applied to the rows of U above their
+ * pivots -- mzd_apply_p_right_trans_tri (m4ri/mzp.c:279-293): row r takes the swaps (i, Q[i]) for i = r+1 .. ncols-1 in
+ * ascending order.  gf2o_pluq = _mzd_pluq_russian (ple_russian.c:625-629), gf2o_pluq_recursive = _mzd_pluq
+ * (ple.c:50-60: on the recursive PLE, and only the first `rank` rows when 0 < rank < nrows). */
+int32_t gf2o_pluq(gf2o_mat *A, int32_t *P, int32_t *Q);
+int32_t gf2o_pluq_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff);
+
 /* table primitives of the elimination routines: m4ri/brilliantrussian.c:163-211 (mzd_make_table: the Gray-code
  * chain T[i] = T[i-1] ^ M[r + inc[i-1]], first word masked below column c, last by the column mask, L[ord[i]] = i,
  * steps whose row does not exist skipped) and :213-601 (mzd_process_rows, 2..6: nt tables, the k-bit strip cut as

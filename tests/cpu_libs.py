@@ -44,6 +44,9 @@ class Oracle:
             "gf2o_trsm_upper_right": (None, [MzdPtr, MzdPtr]),
             "gf2o_trsm_lower_right": (None, [MzdPtr, MzdPtr]),
             "gf2o_ple": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
+            "gf2o_pluq": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
+            "gf2o_ple_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+            "gf2o_pluq_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
             "gf2o_process_rows": (None, [MzdPtr, _I, _I, _I, _I, _I, ctypes.c_void_p, ctypes.c_void_p]),
         }.items():
@@ -88,11 +91,18 @@ class Oracle:
         lp = (ctypes.c_void_p * nt)(*[l.ctypes.data for l in Ls])
         self.L.gf2o_process_rows(M.ptr, startrow, stoprow, startcol, k, nt, tp, lp)
 
-    def ple(self, A):
-        """In place; returns (rank, P, Q) as numpy int32 arrays."""
+    PLE_CUTOFF = 524288  # __M4RI_PLE_CUTOFF (m4ri/ple.h:40) of any build with an L3 of 4 MiB or more
+
+    def ple(self, A, pluq=False, recursive=False, cutoff=PLE_CUTOFF):
+        """In place; returns (rank, P, Q) as numpy int32 arrays.  recursive: _mzd_ple / _mzd_pluq (the column-halving
+        recursion, ple.c:62-171) instead of _mzd_ple_russian / _mzd_pluq_russian -- same matrix for the PLE, same P,
+        same pivots, different leftovers in Q behind the rank."""
         import numpy as np
         P, Q = np.zeros(max(1, A.nrows), dtype=np.int32), np.zeros(max(1, A.ncols), dtype=np.int32)
-        r = self.L.gf2o_ple(A.ptr, P.ctypes.data, Q.ctypes.data)
+        if recursive:
+            r = (self.L.gf2o_pluq_recursive if pluq else self.L.gf2o_ple_recursive)(A.ptr, P.ctypes.data, Q.ctypes.data, cutoff)
+        else:
+            r = (self.L.gf2o_pluq if pluq else self.L.gf2o_ple)(A.ptr, P.ctypes.data, Q.ctypes.data)
         return int(r), P[:A.nrows], Q[:A.ncols]
 
     def trsm_upper_right(self, U, B):

@@ -251,6 +251,10 @@ def ple_input(kind, m, n, seed):
         w = A.valid_words()
         w[:, :3] = 0                      # three leading all-zero word columns: the first pivots sit at column 192
         w[:, 40:42] = 0
+    elif kind == "defects":               # scattered pivot-free columns, rows that vanish, zero rows: see tests/test_ple_oracle.py
+        sys.path.insert(0, os.path.dirname(HERE))
+        from test_ple_oracle import _defects
+        A = _defects(m, n, seed, m // 16, m // 64)
     return A
 
 
@@ -277,8 +281,31 @@ def solver_fixtures():
     json.dump(out, open(os.path.join(HERE, "solvers.json"), "w"), indent=1)
 
 
+PLUQ_CASES = [("random", 16384, 16384, 71), ("lowrank", 20000, 30000, 72), ("zerocols", 12000, 12000, 73), ("random", 9000, 40000, 74),
+              ("lowrank", 30000, 9000, 75), ("defects", 16384, 16384, 76), ("defects", 12000, 30000, 77), ("defects", 30000, 12000, 78)]
+
+
+def pluq_fixtures():
+    """mzd_pluq of the real reference (ple.c:41-60: PLE, then mzd_apply_p_right_trans_tri): appended to solvers.json."""
+    import hashlib
+    import json
+    path = os.path.join(HERE, "solvers.json")
+    out = [e for e in json.load(open(path)) if e["what"] != "pluq" and e.get("kind") != "defects"]
+    for kind, m, n, seed in PLUQ_CASES:
+        for what in (("pluq", "ple") if kind == "defects" else ("pluq",)):
+            A = ple_input(kind, m, n, seed)
+            t = time.time()
+            r, P, Q = ref.ple(A, "mzd_" + what)
+            h = hashlib.sha256(A.masked().tobytes() + P.astype(np.int32).tobytes() + Q.astype(np.int32).tobytes()).hexdigest()
+            out.append({"what": what, "kind": kind, "m": m, "n": n, "seed": seed, "rank": r, "sha256": h})
+            print(what, kind, m, n, r, h[:16], f"{time.time() - t:.1f}s", flush=True)
+    json.dump(out, open(path, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if "--solvers" in sys.argv:
+    if "--pluq" in sys.argv:
+        pluq_fixtures()
+    elif "--solvers" in sys.argv:
         solver_fixtures()
     elif "--sha" in sys.argv:
         sha256_large()

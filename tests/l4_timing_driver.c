@@ -1,6 +1,6 @@
 /* tests/l4_timing_driver.c -- what LD_PRELOAD=libm4ri_amd.so does to M4RI's own L4 routines (our own client
  * code against M4RI's public API; linked against the interposable reference build like dropin_driver.c):
- * times mzd_trsm_upper_left, mzd_ple and mzd_solve_left at one size.  Run it with and without the preload;
+ * times mzd_trsm_upper_left, mzd_ple, mzd_pluq and mzd_solve_left at one size.  Run it with and without the preload;
  * the internal mzd_addmul / _mzd_addmul calls of those routines then run on the GPU or on the CPU. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -37,14 +37,21 @@ int main(int argc, char **argv) {
   t = now();
   rci_t r = mzd_ple(A2, P, Q, 0);
   printf("  mzd_ple             %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
+  mzd_t *A4 = mzd_copy(NULL, A);
+  for (rci_t i = 0; i < n; ++i) mzd_row(A4, i)[(n / 3) / 64] = 0; /* 64 empty columns: pivots move, the column step has work */
+  t = now();
+  r = mzd_pluq(A4, P, Q, 0);
+  printf("  mzd_pluq            %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
   mzd_t *A3 = mzd_copy(NULL, A), *Y = mzd_copy(NULL, B);
   t = now();
   int st = mzd_solve_left(A3, Y, 0, 0);
   printf("  mzd_solve_left      %d x %d : %.3f s (status %d)\n", n, n, now() - t, st);
   /* fingerprints so that the two runs can be compared */
-  word f1 = 0, f2 = 0;
+  word f1 = 0, f2 = 0, f3 = 0, f4 = 0;
   for (rci_t i = 0; i < n; ++i)
-    for (wi_t w = 0; w < X->width; ++w) { f1 = f1 * 1099511628211ull ^ mzd_row(X, i)[w]; f2 = f2 * 1099511628211ull ^ mzd_row(A2, i)[w]; }
-  printf("  fingerprints: trsm %016llx ple %016llx\n", (unsigned long long)f1, (unsigned long long)f2);
+    for (wi_t w = 0; w < X->width; ++w) { f1 = f1 * 1099511628211ull ^ mzd_row(X, i)[w]; f2 = f2 * 1099511628211ull ^ mzd_row(A2, i)[w];
+      f3 = f3 * 1099511628211ull ^ mzd_row(A4, i)[w]; f4 = f4 * 1099511628211ull ^ mzd_row(Y, i)[w]; }
+  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx\n", (unsigned long long)f1, (unsigned long long)f2,
+         (unsigned long long)f3, (unsigned long long)f4);
   return 0;
 }

@@ -6,7 +6,7 @@ import pytest
 
 import m4ri_amd
 from m4ri_amd.mzd import Mzd
-from test_ple_oracle import SHAPES, _make
+from test_ple_oracle import RECURSIVE_CASES, SHAPES, _defects, _make
 
 pytestmark = pytest.mark.gpu
 
@@ -44,8 +44,81 @@ def test_larger_ple_matches_oracle(oracle, m, n, kind):
     else:
         A = _make(kind, m, n, 77)
     Ao, Ag = A.copy(), A.copy()
-    want = oracle.ple(Ao)
+    want = oracle.ple(Ao, recursive=True)
     _same(m4ri_amd.mzd_ple(Ag), want, Ag, Ao)
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+@pytest.mark.parametrize("kind", ["random", "lowrank", "sparse", "zerocols"])
+def test_pluq_matches_oracle(oracle, m, n, kind):
+    """mzd_pluq / _mzd_pluq / _mzd_pluq_russian (ple.c:41-60, ple_russian.c:625-629): PLE + the column step."""
+    A = _make(kind, m, n, 2000 + 7 * m + n)
+    Ao = A.copy()
+    want = oracle.ple(Ao, pluq=True)
+    for which in ("mzd_pluq", "_mzd_pluq", "_mzd_pluq_russian"):
+        Ag = A.copy()
+        _same(m4ri_amd.mzd_ple(Ag, 0, which), want, Ag, Ao)
+
+
+@pytest.mark.parametrize("m,n,kind", [(5000, 5000, "random"), (3000, 9000, "random"), (6000, 6000, "lowrank"), (4099, 8200, "zerocols"),
+                                     (9000, 3000, "lowrank"), (40, 530000, "random")])
+def test_larger_pluq_matches_oracle(oracle, m, n, kind):
+    """Several row groups of the column step; the last shape is wider than the LDS row copy (global row copies)."""
+    if kind == "lowrank":
+        A = m4ri_amd.mzd_mul(None, Mzd.random(m, 1500, 5), Mzd.random(1500, n, 6), 0)
+    else:
+        A = _make(kind, m, n, 78)
+    if n > 100000:  # push pivots far to the right: only a few columns carry data
+        w = A.valid_words()
+        w[:, : w.shape[1] - 3] = 0
+        w[:, 5] = Mzd.random(m, 64, 3).valid_words()[:, 0]
+    Ao, Ag = A.copy(), A.copy()
+    want = oracle.ple(Ao, pluq=True, recursive=True)
+    _same(m4ri_amd.mzd_ple(Ag, 0, "mzd_pluq"), want, Ag, Ao)
+
+
+@pytest.mark.parametrize("m,n", [(1, 2), (5, 64), (64, 65), (100, 300), (300, 100), (700, 1000), (2000, 1500)])
+def test_apply_p_right_trans_tri(m, n):
+    """mzd_apply_p_right_trans_tri (mzp.c:279-293) with arbitrary transpositions Q[i] >= i: row r takes the swaps
+    i > r in ascending order -- replayed with numpy on the bit matrix."""
+    rng = np.random.default_rng(m * 1000 + n)
+    A = Mzd.random(m, n, 11)
+    Q = np.array([rng.integers(i, n) if rng.random() < 0.7 else i for i in range(n)], dtype=np.int32)
+    b = A.to_bits()
+    for i in range(n):
+        if Q[i] != i:
+            rows = slice(0, min(m, i))
+            b[rows, [i, Q[i]]] = b[rows, [Q[i], i]]
+    m4ri_amd.mzd_apply_p_right_trans_tri(A, Q)
+    assert np.array_equal(A.to_bits(), b)
+
+
+@pytest.mark.parametrize("m,n,dup,zero", RECURSIVE_CASES)
+def test_recursive_flavours_match_oracle(oracle, m, n, dup, zero):
+    """Above __M4RI_PLE_CUTOFF mzd_ple / _mzd_ple / mzd_pluq / _mzd_pluq leave the transpositions of the reference's
+    column-halving recursion in Q behind the rank (and mzd_pluq applies them); _mzd_ple_russian / _mzd_pluq_russian leave
+    the identity.  Both against the oracle's two restatements, which tests/test_ple_oracle.py pins to the reference."""
+    A = _defects(m, n, 3000 + m + n, dup, zero)
+    for pluq in (False, True):
+        Ao, Af = A.copy(), A.copy()
+        want_rec, want_flat = oracle.ple(Ao, pluq=pluq, recursive=True), oracle.ple(Af, pluq=pluq)
+        for which in (("mzd_pluq", "_mzd_pluq") if pluq else ("mzd_ple", "_mzd_ple")):
+            Ag = A.copy()
+            _same(m4ri_amd.mzd_ple(Ag, 0, which), want_rec, Ag, Ao)
+        Ag = A.copy()
+        _same(m4ri_amd.mzd_ple(Ag, 0, "_mzd_pluq_russian" if pluq else "_mzd_ple_russian"), want_flat, Ag, Af)
+
+
+def test_pluq_on_a_window_keeps_the_parent(oracle):
+    P0 = Mzd.random(900, 1000, 9)
+    P0.valid_words()[:, 2] = 0
+    for (r0, c0, m, n) in [(10, 64, 500, 333), (0, 0, 900, 130), (100, 128, 64, 64), (3, 0, 300, 1000)]:
+        Po, Pg = Mzd(900, 1000, buf=P0.buf.copy()), Mzd(900, 1000, buf=P0.buf.copy())
+        wo, wg = Po.window(r0, c0, r0 + m, c0 + n), Pg.window(r0, c0, r0 + m, c0 + n)
+        want = oracle.ple(wo, pluq=True)
+        got = m4ri_amd.mzd_ple(wg, 0, "mzd_pluq")
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        assert np.array_equal(Po.buf, Pg.buf)
 
 
 def test_ple_on_a_window_keeps_the_parent(oracle):
@@ -91,7 +164,7 @@ def test_solvers_at_scale_vs_reference_sha256():
     if not os.path.exists(path):
         pytest.skip("tests/golden/solvers.json not generated")
     for e in json.load(open(path)):
-        if e["what"] == "ple":
+        if e["what"] in ("ple", "pluq"):
             m, n, seed = e["m"], e["n"], e["seed"]
             A = Mzd.random(m, n, seed)
             if e["kind"] == "lowrank":
@@ -100,7 +173,9 @@ def test_solvers_at_scale_vs_reference_sha256():
                 w = A.valid_words()
                 w[:, :3] = 0
                 w[:, 40:42] = 0
-            r, P, Q = m4ri_amd.mzd_ple(A)
+            elif e["kind"] == "defects":
+                A = _defects(m, n, seed, m // 16, m // 64)
+            r, P, Q = m4ri_amd.mzd_ple(A, 0, "mzd_" + e["what"])
             h = hashlib.sha256(A.masked().tobytes() + P.astype(np.int32).tobytes() + Q.astype(np.int32).tobytes()).hexdigest()
             assert (r, h) == (e["rank"], e["sha256"]), e
         else:

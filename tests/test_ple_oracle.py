@@ -50,3 +50,58 @@ def test_ple_is_independent_of_k(oracle, reference):
         Ar = A.copy()
         got = reference.ple(Ar, k=k)
         assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and Ar.equal(Ao)
+
+
+@pytest.mark.parametrize("m,n", [(1, 70), (70, 1), (13, 17), (64, 64), (65, 63), (127, 129), (200, 70), (70, 200), (300, 300), (513, 511), (1000, 200),
+                                 (200, 1000), (1025, 1025)])
+@pytest.mark.parametrize("kind", ["random", "lowrank", "sparse", "zerocols"])
+def test_pluq_matches_reference(oracle, reference, m, n, kind):
+    """PLE + the column step of PLUQ (ple.c:50-60, mzp.c:279-293) against mzd_pluq and _mzd_pluq_russian."""
+    A = _make(kind, m, n, 2000 + 7 * m + n)
+    Ao, Ar, Ar2 = A.copy(), A.copy(), A.copy()
+    want = oracle.ple(Ao, pluq=True)
+    for Ax, which in ((Ar, "mzd_pluq"), (Ar2, "_mzd_pluq_russian")):
+        got = reference.ple(Ax, which)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), which
+        assert np.array_equal(Ax.valid_words(), Ao.valid_words()), which
+
+
+def _defects(m, n, seed, dup_rows=0, zero_rows=0):
+    """Random matrix with columns that repeat their left neighbour (so no pivot there) scattered over the whole width, a
+    zero word column, optionally copies of the first rows at the bottom (they vanish during the elimination: windows
+    of the recursion end in zero rows) and zero rows below those."""
+    A = Mzd.random(m, n, seed)
+    w = A.valid_words()
+    rng = np.random.default_rng(seed)
+    for c in sorted(rng.choice(np.arange(1, n), size=max(3, n // 40), replace=False)):
+        src, dst = int(c) - 1, int(c)
+        bit = (w[:, src // 64] >> np.uint64(src % 64)) & np.uint64(1)
+        w[:, dst // 64] = (w[:, dst // 64] & ~(np.uint64(1) << np.uint64(dst % 64))) | (bit << np.uint64(dst % 64))
+    w[:, (n // 3) // 64] = 0
+    if dup_rows:
+        w[m - zero_rows - dup_rows: m - zero_rows] = w[:dup_rows]
+    if zero_rows:
+        w[m - zero_rows:] = 0
+    return A
+
+
+RECURSIVE_CASES = [(4200, 8256, 0, 0), (9000, 4200, 0, 0), (6000, 11000, 0, 0), (8400, 4800, 700, 300), (5000, 9000, 400, 0), (3000, 12000, 0, 500)]
+
+
+@pytest.mark.parametrize("m,n,dup,zero", RECURSIVE_CASES)
+def test_recursive_ple_and_pluq_match_reference(oracle, reference, m, n, dup, zero):
+    """Above __M4RI_PLE_CUTOFF (width * nrows > 524288 words) mzd_ple / mzd_pluq recurse on column halves (ple.c:62-171) and
+    leave their own values in Q behind the rank; mzd_pluq then applies those transpositions too.  The oracle's
+    restatement of that recursion against the reference: matrix, P, the whole of Q, rank."""
+    A = _defects(m, n, 3000 + m + n, dup, zero)
+    for pluq, which in ((False, "mzd_ple"), (True, "mzd_pluq")):
+        Ao, Ar = A.copy(), A.copy()
+        want = reference.ple(Ar, which)
+        got = oracle.ple(Ao, pluq=pluq, recursive=True)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), which
+        assert np.array_equal(got[2][: got[0]], want[2][: got[0]]), which + ": pivots"
+        assert np.array_equal(got[2], want[2]), which + ": Q behind the rank"
+        assert np.array_equal(Ar.valid_words(), Ao.valid_words()), which
+    if n < 12000:  # (the last case has all its pivots in the left half: there it is the early return on a zero window that matters)
+        flat = oracle.ple(A.copy())
+        assert flat[0] == want[0] and not np.array_equal(flat[2], want[2]), "the case does not exercise the leftovers of the recursion"
