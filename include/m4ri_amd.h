@@ -123,6 +123,21 @@ rci_t _mzd_pluq(mzd_t *A, mzp_t *P, mzp_t *Q, const int cutoff);
 rci_t _mzd_pluq_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k);
 void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q);
 
+/* ---- echelon forms (the drivers over the elimination kernels) ---------------------------
+ * Row echelon form (full == 0) or reduced row echelon form (full != 0) of A in place; returns the rank.  The three
+ * drivers of the reference (Four-Russians strips, PLE/PLUQ based, density heuristic) leave the same matrix -- their
+ * common pivoting rule fixes it -- so all of them map to one device routine (echelon.hip); `k`, `heuristic` and
+ * `threshold` are hints.  m4ri/echelonform.h:50, :63, :79; m4ri/brilliantrussian.h:215 (echelonform.c:29-139,
+ * brilliantrussian.c:603-841). */
+rci_t mzd_echelonize(mzd_t *A, int full);
+rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k);
+rci_t mzd_echelonize_pluq(mzd_t *A, int full);
+rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const double threshold);
+/* A <- A * P / A * P^T: the column transpositions (i, P[i]) on every row, i descending / ascending.
+ * m4ri/mzp.h:142, :153 (mzp.c:193-260). */
+void mzd_apply_p_right(mzd_t *A, mzp_t const *P);
+void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P);
+
 /* ---- the table primitives of M4RI's elimination routines -----------------------------
  * mzd_make_table (m4ri/brilliantrussian.h:56, .c:163-211): T[i], i = 1 .. 2^k - 1, = the Gray-code combinations of
  * rows r .. r+k-1 of M from word c/64 on (first word masked below column c, last word by M's column mask), and
@@ -229,6 +244,9 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
 /* PLUQ in place (m4ri/ple.c:50-60): the PLE, then the column step below on the first `rank` rows.  Blocking. */
 int m4ri_amd_pluq_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
                       int64_t recursion_cutoff, void *stream);
+/* Device twins of mzd_echelonize* and mzd_apply_p_right{,_trans} (echelon.hip).  P: HOST array.  Blocking. */
+int m4ri_amd_echelonize_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int full, int32_t *rank_out, void *stream);
+int m4ri_amd_apply_p_right_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *P, int64_t length, int trans, void *stream);
 /* Row r <- its columns under the transpositions (i, Q[i]), i = r+1 .. ncols-1 ascending (mzd_apply_p_right_trans_tri,
  * m4ri/mzp.c:279-293).  Q: HOST array, ncols entries, Q[i] >= i.  Blocking. */
 int m4ri_amd_apply_p_right_trans_tri_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *Q, void *stream);

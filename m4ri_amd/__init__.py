@@ -121,9 +121,17 @@ SYMBOLS = {
     "_mzd_pluq": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "_mzd_pluq_russian": (_I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]),
     "mzd_apply_p_right_trans_tri": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_apply_p_right": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_apply_p_right_trans": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_echelonize": (_I, [MzdPtr, _I]),
+    "mzd_echelonize_m4ri": (_I, [MzdPtr, _I, _I]),
+    "mzd_echelonize_pluq": (_I, [MzdPtr, _I]),
+    "_mzd_echelonize_m4ri": (_I, [MzdPtr, _I, _I, _I, ctypes.c_double]),
     "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
     "m4ri_amd_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
     "m4ri_amd_apply_p_right_trans_tri_dev": (_I, [_P, _I64, _I64, _I64, _P, _P]),
+    "m4ri_amd_echelonize_dev": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
+    "m4ri_amd_apply_p_right_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
     "m4ri_amd_mzd_free": (None, [MzdPtr]),
     "m4ri_amd_result_free": (None, [MzdPtr]),
@@ -261,6 +269,24 @@ def mzd_ple(A: Mzd, cutoff: int = 0, which: str = "mzd_ple"):
     mq.values, mq.length = Q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), A.ncols
     r = getattr(lib(), which)(A.ptr, ctypes.byref(mp), ctypes.byref(mq), cutoff)
     return int(r), P[:A.nrows], Q[:A.ncols]
+
+
+def mzd_echelonize(A: Mzd, full: int, which: str = "mzd_echelonize", k: int = 0) -> int:
+    """(Reduced) row echelon form of A in place, returns the rank (reference m4ri/echelonform.h:50, :63, :79)."""
+    if which == "mzd_echelonize_m4ri":
+        return int(lib().mzd_echelonize_m4ri(A.ptr, int(full), k))
+    if which == "_mzd_echelonize_m4ri":
+        return int(lib()._mzd_echelonize_m4ri(A.ptr, int(full), k, 0, 1.0))
+    return int(getattr(lib(), which)(A.ptr, int(full)))
+
+
+def mzd_apply_p_right(A: Mzd, P, trans: bool = False) -> None:
+    """A <- A * P (or A * P^T): the column transpositions (i, P[i]) on every row (reference m4ri/mzp.h:142, :153)."""
+    import numpy as np
+    p = np.ascontiguousarray(P, dtype=np.int32)
+    mp = Mzp()
+    mp.values, mp.length = p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(p)
+    (lib().mzd_apply_p_right_trans if trans else lib().mzd_apply_p_right)(A.ptr, ctypes.byref(mp))
 
 
 def mzd_apply_p_right_trans_tri(A: Mzd, Q) -> None:

@@ -605,6 +605,46 @@ void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q) {  // mzp.c:279-293
   g_api_stats.calls += 1;
 }
 
+// ---- echelon forms and the column permutations (echelon.hip) -----------------------------------------------------
+static rci_t run_echelonize(mzd_t *A, int full) {
+  if (A->nrows == 0 || A->ncols == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  int32_t rank = 0;
+  HIPDIE(m4ri_amd_echelonize_dev(io.d.p, io.d.stride, A->nrows, A->ncols, full, &rank, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return rank;
+}
+rci_t mzd_echelonize(mzd_t *A, int full) { return run_echelonize(A, full); }                  // echelonform.c:29-31
+rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k) { (void)k; return run_echelonize(A, full); }  // echelonform.c:33-35
+rci_t mzd_echelonize_pluq(mzd_t *A, int full) { return run_echelonize(A, full); }             // echelonform.c:37-139
+rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const double threshold) {  // brilliantrussian.c:603-841
+  (void)k; (void)heuristic; (void)threshold;
+  return run_echelonize(A, full);
+}
+
+static void run_apply_p_right(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:193-260
+  if (A->nrows == 0 || A->ncols == 0) return;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  HIPDIE(m4ri_amd_apply_p_right_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, P->length, trans, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+}
+void mzd_apply_p_right(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 0); }
+void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 1); }
+
 // ---- the table primitives of the elimination routines (elim.hip) -------------------------
 static word *arena_raw(size_t words) {  // plain words from the staging arena (256-byte granules)
   word *p = g_arena.base + g_arena.used;

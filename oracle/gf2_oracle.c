@@ -632,3 +632,37 @@ void gf2o_trsm_lower_right(const gf2o_mat *L, gf2o_mat *B) {  /* x_j = b_j + sum
       if (p) o_flip(B, r, j);
     }
 }
+
+
+/* ---- echelon forms (m4ri/echelonform.c:29-139, m4ri/brilliantrussian.c:603-841) --------------------------------
+ * What mzd_echelonize_m4ri / mzd_echelonize_pluq / mzd_echelonize leave in A, stated without their schedules: columns
+ * left to right, the pivot of a column is the first row at or below the current rank with the bit set
+ * (_mzd_gauss_submatrix{,_full}, brilliantrussian.c:48-121; mzd_find_pivot, mzd.c:1661-1776; ple_russian.c:141-159), it is
+ * swapped up to the rank's row, the rows below are cleared in that column -- and, for the reduced form (full), the rows
+ * above as well.  The strips of 6k columns, the Gray-code tables and the PLUQ detour only change the order in which these
+ * additions happen: each row ends as itself plus the one combination of pivot rows that clears its pivot columns. */
+int32_t gf2o_echelonize(gf2o_mat *A, int full) {
+  int64_t rank = 0;
+  for (int64_t c = 0; c < A->ncols && rank < A->nrows; ++c) {
+    int64_t piv = -1;
+    for (int64_t i = rank; i < A->nrows; ++i)
+      if (o_bit(A, i, c)) { piv = i; break; }
+    if (piv < 0) continue;
+    o_row_swap(A, piv, rank);
+    for (int64_t r = full ? 0 : rank + 1; r < A->nrows; ++r)
+      if (r != rank && o_bit(A, r, c)) o_row_add_from(A, r, rank, c);
+    ++rank;
+  }
+  return (int32_t)rank;
+}
+
+/* mzd_apply_p_right / mzd_apply_p_right_trans (mzp.c:193-260): the column transpositions (i, P[i]) applied to every row,
+ * i descending for A * P, ascending for A * P^T. */
+void gf2o_apply_p_right(gf2o_mat *A, const int32_t *P, int64_t length, int trans) {
+  if (length > A->ncols) length = A->ncols;
+  for (int64_t r = 0; r < A->nrows; ++r)
+    for (int64_t t = 0; t < length; ++t) {
+      const int64_t i = trans ? t : length - 1 - t;
+      if (P[i] != i) o_col_swap_in_row(A, r, i, P[i]);
+    }
+}

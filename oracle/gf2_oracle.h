@@ -95,6 +95,13 @@ int32_t gf2o_ple_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff);
 int32_t gf2o_pluq(gf2o_mat *A, int32_t *P, int32_t *Q);
 int32_t gf2o_pluq_recursive(gf2o_mat *A, int32_t *P, int32_t *Q, int64_t cutoff);
 
+/* Row echelon form (full = 0) / reduced row echelon form (full = 1) in place, returns the rank: what
+ * mzd_echelonize_m4ri, mzd_echelonize_pluq and mzd_echelonize (m4ri/echelonform.c:29-139, brilliantrussian.c:603-841)
+ * leave in A -- see gf2_oracle.c for why the three agree. */
+int32_t gf2o_echelonize(gf2o_mat *A, int full);
+/* mzd_apply_p_right (trans = 0) / mzd_apply_p_right_trans (trans = 1), m4ri/mzp.c:193-260 */
+void gf2o_apply_p_right(gf2o_mat *A, const int32_t *P, int64_t length, int trans);
+
 /* table primitives of the elimination routines: m4ri/brilliantrussian.c:163-211 (mzd_make_table: the Gray-code
  * chain T[i] = T[i-1] ^ M[r + inc[i-1]], first word masked below column c, last by the column mask, L[ord[i]] = i,
  * steps whose row does not exist skipped) and :213-601 (mzd_process_rows, 2..6: nt tables, the k-bit strip cut as

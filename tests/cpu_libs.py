@@ -45,6 +45,8 @@ class Oracle:
             "gf2o_trsm_lower_right": (None, [MzdPtr, MzdPtr]),
             "gf2o_ple": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
             "gf2o_pluq": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
+            "gf2o_echelonize": (ctypes.c_int32, [MzdPtr, ctypes.c_int]),
+            "gf2o_apply_p_right": (None, [MzdPtr, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
             "gf2o_ple_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_pluq_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
@@ -90,6 +92,14 @@ class Oracle:
         tp = (MzdPtr * nt)(*[ctypes.pointer(t.struct) for t in Ts])
         lp = (ctypes.c_void_p * nt)(*[l.ctypes.data for l in Ls])
         self.L.gf2o_process_rows(M.ptr, startrow, stoprow, startcol, k, nt, tp, lp)
+
+    def echelonize(self, A, full):
+        return int(self.L.gf2o_echelonize(A.ptr, int(full)))
+
+    def apply_p_right(self, A, P, trans=False):
+        import numpy as np
+        p = np.ascontiguousarray(P, dtype=np.int32)
+        self.L.gf2o_apply_p_right(A.ptr, p.ctypes.data, len(p), int(trans))
 
     PLE_CUTOFF = 524288  # __M4RI_PLE_CUTOFF (m4ri/ple.h:40) of any build with an L3 of 4 MiB or more
 
@@ -166,6 +176,13 @@ class Reference:
         for name in ("_mzd_ple_russian", "_mzd_pluq_russian", "mzd_ple", "mzd_pluq"):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = _I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]
+        L.mzd_echelonize.restype, L.mzd_echelonize.argtypes = _I, [MzdPtr, _I]
+        L.mzd_echelonize_pluq.restype, L.mzd_echelonize_pluq.argtypes = _I, [MzdPtr, _I]
+        L.mzd_echelonize_m4ri.restype, L.mzd_echelonize_m4ri.argtypes = _I, [MzdPtr, _I, _I]
+        L._mzd_echelonize_m4ri.restype, L._mzd_echelonize_m4ri.argtypes = _I, [MzdPtr, _I, _I, _I, ctypes.c_double]
+        for name in ("mzd_apply_p_right", "mzd_apply_p_right_trans", "mzd_apply_p_left", "mzd_apply_p_left_trans"):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = None, [MzdPtr, ctypes.POINTER(Mzp)]
         self.has_mp = hasattr(L, "mzd_mul_mp")
         if self.has_mp:
             L.mzd_mul_mp.restype, L.mzd_mul_mp.argtypes = sig4
@@ -196,6 +213,16 @@ class Reference:
     def add(self, C, A, B):
         self.L._mzd_add(C.ptr, A.ptr, B.ptr)
         return C
+
+    def echelonize(self, A, full, which="mzd_echelonize_m4ri", k=0):
+        if which == "mzd_echelonize_m4ri":
+            return int(self.L.mzd_echelonize_m4ri(A.ptr, int(full), k))
+        return int(getattr(self.L, which)(A.ptr, int(full)))
+
+    def apply_p(self, A, P, which="mzd_apply_p_right"):
+        import numpy as np
+        p = np.ascontiguousarray(P, dtype=np.int32)
+        getattr(self.L, which)(A.ptr, ctypes.byref(mzp_of(p)))
 
     def ple(self, A, which="_mzd_ple_russian", k=0):
         """In place; returns (rank, P, Q)."""

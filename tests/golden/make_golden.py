@@ -302,8 +302,33 @@ def pluq_fixtures():
     json.dump(out, open(path, "w"), indent=1)
 
 
+ECHELON_CASES = [(12000, 12000, 81), (8000, 20000, 82), (20000, 8000, 83)]
+
+
+def echelon_fixtures():
+    """mzd_echelonize_pluq and mzd_echelonize_m4ri of the real reference (echelonform.c:29-139), full and not: the two must
+    agree; SHA-256 over the result's valid words -> echelon.json"""
+    import hashlib
+    import json
+    out = []
+    for m, n, seed in ECHELON_CASES:
+        for full in (0, 1):
+            hs = []
+            for which in ("mzd_echelonize_pluq", "mzd_echelonize_m4ri"):
+                A = ple_input("defects", m, n, seed)
+                t = time.time()
+                r = ref.echelonize(A, full, which)
+                hs.append((r, hashlib.sha256(A.masked().tobytes()).hexdigest()))
+                print(which, m, n, full, r, hs[-1][1][:16], f"{time.time() - t:.1f}s", flush=True)
+            assert hs[0] == hs[1]
+            out.append({"m": m, "n": n, "seed": seed, "full": full, "rank": hs[0][0], "sha256": hs[0][1]})
+    json.dump(out, open(os.path.join(HERE, "echelon.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if "--pluq" in sys.argv:
+    if "--echelon" in sys.argv:
+        echelon_fixtures()
+    elif "--pluq" in sys.argv:
         pluq_fixtures()
     elif "--solvers" in sys.argv:
         solver_fixtures()

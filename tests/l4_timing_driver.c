@@ -1,6 +1,6 @@
 /* tests/l4_timing_driver.c -- what LD_PRELOAD=libm4ri_amd.so does to M4RI's own L4 routines (our own client
  * code against M4RI's public API; linked against the interposable reference build like dropin_driver.c):
- * times mzd_trsm_upper_left, mzd_ple, mzd_pluq and mzd_solve_left at one size.  Run it with and without the preload;
+ * times mzd_trsm_upper_left, mzd_ple, mzd_pluq, mzd_solve_left and mzd_echelonize at one size.  Run it with and without the preload;
  * the internal mzd_addmul / _mzd_addmul calls of those routines then run on the GPU or on the CPU. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -46,12 +46,18 @@ int main(int argc, char **argv) {
   t = now();
   int st = mzd_solve_left(A3, Y, 0, 0);
   printf("  mzd_solve_left      %d x %d : %.3f s (status %d)\n", n, n, now() - t, st);
+  mzd_t *A5 = mzd_copy(NULL, A);
+  for (rci_t i = 0; i < n; ++i) mzd_row(A5, i)[(n / 5) / 64] = 0;
+  t = now();
+  r = mzd_echelonize(A5, 1);
+  printf("  mzd_echelonize full %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
   /* fingerprints so that the two runs can be compared */
-  word f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+  word f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
   for (rci_t i = 0; i < n; ++i)
     for (wi_t w = 0; w < X->width; ++w) { f1 = f1 * 1099511628211ull ^ mzd_row(X, i)[w]; f2 = f2 * 1099511628211ull ^ mzd_row(A2, i)[w];
-      f3 = f3 * 1099511628211ull ^ mzd_row(A4, i)[w]; f4 = f4 * 1099511628211ull ^ mzd_row(Y, i)[w]; }
-  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx\n", (unsigned long long)f1, (unsigned long long)f2,
-         (unsigned long long)f3, (unsigned long long)f4);
+      f3 = f3 * 1099511628211ull ^ mzd_row(A4, i)[w]; f4 = f4 * 1099511628211ull ^ mzd_row(Y, i)[w];
+      f5 = f5 * 1099511628211ull ^ mzd_row(A5, i)[w]; }
+  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx echelon %016llx\n", (unsigned long long)f1, (unsigned long long)f2,
+         (unsigned long long)f3, (unsigned long long)f4, (unsigned long long)f5);
   return 0;
 }

@@ -1,0 +1,109 @@
+"""Echelon forms on the GPU (include/m4ri_amd.h: mzd_echelonize, mzd_echelonize_m4ri, mzd_echelonize_pluq,
+_mzd_echelonize_m4ri; reference m4ri/echelonform.c:29-139, m4ri/brilliantrussian.c:603-841) and the column permutations
+mzd_apply_p_right{,_trans} (mzp.c:193-260) against the oracle, which tests/test_echelon_oracle.py pins to all three
+reference drivers: rank and matrix, bit for bit."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import m4ri_amd
+from m4ri_amd.mzd import Mzd
+from test_ple_oracle import SHAPES, _defects, _make
+
+pytestmark = pytest.mark.gpu
+WHICH = ("mzd_echelonize", "mzd_echelonize_m4ri", "mzd_echelonize_pluq", "_mzd_echelonize_m4ri")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert m4ri_amd.lib().m4ri_amd_device_count() >= 1, "no HIP device visible: the gpu tests have nothing to run on"
+    m4ri_amd.init(0)
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+@pytest.mark.parametrize("kind", ["random", "lowrank", "sparse", "zerocols"])
+@pytest.mark.parametrize("full", [0, 1])
+def test_echelon_forms_match_oracle(oracle, m, n, kind, full):
+    A = _make(kind, m, n, 4000 + 7 * m + n)
+    Ao = A.copy()
+    want = oracle.echelonize(Ao, full)
+    for which in WHICH:
+        Ag = A.copy()
+        assert m4ri_amd.mzd_echelonize(Ag, full, which) == want, which
+        assert np.array_equal(Ag.valid_words(), Ao.valid_words()), which
+
+
+@pytest.mark.parametrize("m,n,dup,zero", [(4200, 8256, 0, 0), (9000, 4200, 300, 100), (2500, 2500, 0, 0), (5000, 5000, 0, 0), (3000, 9000, 100, 0)])
+@pytest.mark.parametrize("full", [0, 1])
+def test_larger_echelon_forms_match_oracle(oracle, m, n, dup, zero, full):
+    A = _defects(m, n, 5000 + m + n, dup, zero)
+    Ao, Ag = A.copy(), A.copy()
+    want = oracle.echelonize(Ao, full)
+    assert m4ri_amd.mzd_echelonize(Ag, full) == want
+    assert np.array_equal(Ag.valid_words(), Ao.valid_words())
+
+
+def test_echelon_edge_shapes(oracle):
+    for (m, n) in [(0, 0), (0, 5), (5, 0), (1, 1), (1, 200), (200, 1), (64, 64), (65, 1), (3, 640)]:
+        for full in (0, 1):
+            A = Mzd.random(m, n, 3)
+            Ao = A.copy()
+            want = oracle.echelonize(Ao, full) if m and n else 0
+            assert m4ri_amd.mzd_echelonize(A, full) == want and A.equal(Ao), (m, n, full)
+    Z = Mzd(100, 300)
+    assert m4ri_amd.mzd_echelonize(Z, 1) == 0 and not Z.valid_words().any()
+
+
+def test_echelonize_on_a_window_keeps_the_parent(oracle):
+    P0 = Mzd.random(900, 1000, 9)
+    P0.valid_words()[:, 2] = 0
+    for full in (0, 1):
+        for (r0, c0, m, n) in [(10, 64, 500, 333), (0, 0, 900, 130), (100, 128, 64, 64), (3, 0, 300, 1000)]:
+            Po, Pg = Mzd(900, 1000, buf=P0.buf.copy()), Mzd(900, 1000, buf=P0.buf.copy())
+            wo, wg = Po.window(r0, c0, r0 + m, c0 + n), Pg.window(r0, c0, r0 + m, c0 + n)
+            assert m4ri_amd.mzd_echelonize(wg, full) == oracle.echelonize(wo, full)
+            assert np.array_equal(Po.buf, Pg.buf)
+
+
+def test_reduced_form_is_idempotent_and_spans_the_same_space():
+    """At a size the oracle does not reach: RREF(RREF(A)) == RREF(A), rank(A) rows, and A's rows lie in its span
+    (echelonizing [R; A] gives R again followed by zero rows)."""
+    m, n = 20000, 24000
+    A = m4ri_amd.mzd_mul(None, Mzd.random(m, 9000, 1), Mzd.random(9000, n, 2), 0)
+    R = A.copy()
+    r = m4ri_amd.mzd_echelonize(R, 1)
+    assert r == 9000
+    R2 = R.copy()
+    assert m4ri_amd.mzd_echelonize(R2, 1) == r and R2.equal(R)
+    S = Mzd(r + 3000, n)
+    S.valid_words()[:r] = R.valid_words()[:r]
+    S.valid_words()[r:] = A.valid_words()[5000:8000]
+    assert m4ri_amd.mzd_echelonize(S, 1) == r
+    assert np.array_equal(S.valid_words()[:r], R.valid_words()[:r]) and not S.valid_words()[r:].any()
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 64), (10, 65), (70, 130), (200, 333), (64, 1000), (3000, 2000)])
+def test_apply_p_right(oracle, m, n):
+    rng = np.random.default_rng(m * 7 + n)
+    Q = np.array([rng.integers(i, n) for i in range(n)], dtype=np.int32)
+    A = Mzd.random(m, n, 5)
+    for trans in (False, True):
+        Ao, Ag = A.copy(), A.copy()
+        oracle.apply_p_right(Ao, Q, trans)
+        m4ri_amd.mzd_apply_p_right(Ag, Q, trans)
+        assert np.array_equal(Ag.valid_words(), Ao.valid_words()), trans
+
+
+def test_echelon_forms_at_scale_vs_reference_sha256():
+    """Against SHA-256 values of the real reference's mzd_echelonize_m4ri / mzd_echelonize_pluq results
+    (tests/golden/echelon.json, make_golden.py --echelon)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "echelon.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/echelon.json not generated")
+    for e in json.load(open(path)):
+        A = _defects(e["m"], e["n"], e["seed"], e["m"] // 16, e["m"] // 64)
+        r = m4ri_amd.mzd_echelonize(A, e["full"])
+        assert (r, hashlib.sha256(A.masked().tobytes()).hexdigest()) == (e["rank"], e["sha256"]), e
