@@ -93,6 +93,10 @@ __device__ __forceinline__ constexpr uint32_t perm_sel(int j, int buf) {
   return 0x0c000000u | ((buf ? 0x01u : 0x0cu) << 16) | ((uint32_t)(4 + j) << 8) | 0x00u;
 }
 
+#ifndef K8Q_DEBUG_SKIP
+#define K8Q_DEBUG_SKIP 0
+#endif
+
 template <bool XOR_OUT>
 __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 65536];  // [buffer][256 bank rows][T0|T1|T2|T3][64 B]
@@ -167,7 +171,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     uint32_t off = (b_uni + ((uint32_t)stage * K8_STAGE + 4u) * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#if K8Q_DEBUG_SKIP == 2  // developer probe (tools/prof_leaf_traffic_operands.sh): no B loads, results are garbage
+      bhi_rows[j] = make_uint4(off, (uint32_t)stage, (uint32_t)j, 0u);
+#else
       bhi_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
+#endif
       off += b_rs;
       asm volatile("" : "+v"(off));  // one running offset VGPR instead of hoisted per-row offsets
     }
@@ -176,7 +184,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
     uint32_t off = (b_uni + (uint32_t)stage * K8_STAGE * b_rs) + b_slot;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#if K8Q_DEBUG_SKIP == 2
+      blo_rows[j] = make_uint4(off, (uint32_t)stage, (uint32_t)j, 1u);
+#else
       blo_rows[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0));
+#endif
       off += b_rs;
       asm volatile("" : "+v"(off));
     }
@@ -221,8 +233,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // the A dwords of the next 16 rows (a whole stage would cost the registers the pipeline needs)
   uint32_t areg[AR_MAX];
   auto load_a4 = [&](int slot, int g, int q) {  // rows 4g..4g+3 of stage q -> areg[4*slot ..]
+#if K8Q_DEBUG_SKIP == 1  // developer probe: no A loads
+    const uint32_t fake = a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u;
+    const uint4 v = make_uint4(fake, fake * 3u, fake * 5u, fake * 7u);
+#else
     const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   a_rsrc, (int)(a_lane + (uint32_t)q * a_qs + (uint32_t)g * 16u), 0, 0));
+#endif
     areg[slot * 4 + 0] = v.x; areg[slot * 4 + 1] = v.y; areg[slot * 4 + 2] = v.z; areg[slot * 4 + 3] = v.w;
   };
 

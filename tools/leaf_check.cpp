@@ -117,6 +117,7 @@ static int check(int m, int l, int n, int batch, int ksplit, int mode, int rg, i
   return bad != 0;
 }
 
+static bool g_share_b = false;  // --traffic ... 1: every product of the batch reads the SAME B (its HBM traffic vanishes)
 static void timeit(int m, int l, int n, int batch, int ksplit, int rg, int reps, int ug = 0, int pipe = 0) {
   const int wa = (l + 63) / 64, wn = (n + 63) / 64;
   const size_t asz = (size_t)m * wa * batch, bsz = (size_t)l * wn * batch, csz = (size_t)m * wn * batch;
@@ -131,7 +132,7 @@ static void timeit(int m, int l, int n, int batch, int ksplit, int rg, int reps,
   LeafArgs a{};
   a.A = dA; a.B = dB; a.C = dC;
   a.a_stride = wa; a.b_stride = wn; a.c_stride = wn;
-  a.a_bs = (int64_t)m * wa; a.b_bs = (int64_t)l * wn; a.c_bs = (int64_t)m * wn;
+  a.a_bs = (int64_t)m * wa; a.b_bs = g_share_b ? 0 : (int64_t)l * wn; a.c_bs = (int64_t)m * wn;
   a.m = m; a.l = l; a.n = n; a.batch = batch; a.ksplit = ksplit; a.mode = ksplit > 1 ? 1 : 0;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(launch(a, rg, ug, pipe)); CK(hipDeviceSynchronize());
@@ -153,7 +154,7 @@ int main(int argc, char **argv) {
   sm_state = 12345;
   int fails = 0;
   const int rgs[3] = {32, 24, 16};
-  if (!(argc > 1 && (!strcmp(argv[1], "--one") || !strcmp(argv[1], "--v4") || !strcmp(argv[1], "--shape"))))
+  if (!(argc > 1 && (!strcmp(argv[1], "--one") || !strcmp(argv[1], "--v4") || !strcmp(argv[1], "--shape") || !strcmp(argv[1], "--traffic"))))
   for (int rg : rgs) {
     fails += check(1024, 1024, 2048, 1, 1, 0, rg, 0, 4, 0);
     fails += check(1000, 777, 1234, 1, 1, 0, rg, 1, 4, 0);
@@ -165,6 +166,11 @@ int main(int argc, char **argv) {
     fails += check(193, 65, 65, 1, 2, 1, rg, 0, 4, 0);
   }
   if (argc > 1 && !strcmp(argv[1], "--check-only")) return fails != 0;
+  if (argc > 6 && !strcmp(argv[1], "--traffic")) {  // --traffic m l n batch shareB : generation 4 once, for rocprofv3 --pmc
+    g_share_b = atoi(argv[6]) != 0;
+    timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), 1, 32, 1, 1, 11);
+    return 0;
+  }
   if (argc > 6 && !strcmp(argv[1], "--shape")) {  // --shape m l n batch pipe : time one variant on one shape
     timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), 1, 32, 3, 1, atoi(argv[6]));
     return 0;
