@@ -138,6 +138,23 @@ rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const
 void mzd_apply_p_right(mzd_t *A, mzp_t const *P);
 void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P);
 
+/* ---- linear systems, kernels, inverses (the drivers over PLUQ; solve.hip) -------------------------------------
+ * mzd_solve_left (m4ri/solve.h:50, :123; solve.c:30-152): A X = B.  A (m x n) is left holding its PLUQ decomposition, B
+ * (max(m, n) rows) the solution in its first n rows with the undefined rows zero; returns 0, or -1 when
+ * inconsistency_check finds no solution.  mzd_pluq_solve_left (solve.h:76, :103): the same from a decomposition.
+ * mzd_kernel_left_pluq (solve.h:140; solve.c:154-191): A <- its PLUQ; returns a new n x (n - rank) matrix whose columns
+ * span {x : A x = 0}, or NULL when the rank is n.  mzd_inv_m4ri (m4ri/brilliantrussian.h:256; .c:971-997): B <- A^-1
+ * through the reduced echelon form of [A | I] (B == NULL: a new matrix).  mzd_apply_p_left{,_trans} (m4ri/mzp.h:120,
+ * :131; mzp.c:65-81): the row transpositions (i, P[i]) ascending / descending. */
+int mzd_solve_left(mzd_t *A, mzd_t *B, int const cutoff, int const inconsistency_check);
+int _mzd_solve_left(mzd_t *A, mzd_t *B, int const cutoff, int const inconsistency_check);
+int mzd_pluq_solve_left(mzd_t const *A, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int const cutoff, int const inconsistency_check);
+int _mzd_pluq_solve_left(mzd_t const *A, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int const cutoff, int const inconsistency_check);
+mzd_t *mzd_kernel_left_pluq(mzd_t *A, int const cutoff);
+mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k);
+void mzd_apply_p_left(mzd_t *A, mzp_t const *P);
+void mzd_apply_p_left_trans(mzd_t *A, mzp_t const *P);
+
 /* ---- the table primitives of M4RI's elimination routines -----------------------------
  * mzd_make_table (m4ri/brilliantrussian.h:56, .c:163-211): T[i], i = 1 .. 2^k - 1, = the Gray-code combinations of
  * rows r .. r+k-1 of M from word c/64 on (first word masked below column c, last word by M's column mask), and
@@ -244,6 +261,15 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
 /* PLUQ in place (m4ri/ple.c:50-60): the PLE, then the column step below on the first `rank` rows.  Blocking. */
 int m4ri_amd_pluq_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int32_t *P, int32_t *Q, int32_t *rank_out,
                       int64_t recursion_cutoff, void *stream);
+/* Device twins of the drivers over PLUQ (solve.hip); P, Q: HOST arrays; *retval: 0 / -1 as mzd_solve_left.  Blocking. */
+int m4ri_amd_apply_p_left_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *P, int64_t length, int trans, void *stream);
+int m4ri_amd_pluq_solve_left_dev(const word *A, int64_t a_stride, int64_t m, int64_t n, int32_t rank, const int32_t *P, const int32_t *Q, word *B,
+                                 int64_t b_stride, int64_t b_rows, int64_t b_cols, int cutoff, int inconsistency_check, int *retval, void *stream);
+int m4ri_amd_solve_left_dev(word *A, int64_t a_stride, int64_t m, int64_t n, word *B, int64_t b_stride, int64_t b_rows, int64_t b_cols, int cutoff,
+                            int inconsistency_check, int *retval, void *stream);
+int m4ri_amd_kernel_left_pluq_dev(word *A, int64_t a_stride, int64_t m, int64_t n, word *R, int64_t r_stride, int cutoff, int32_t *rank_out,
+                                  void *stream);
+int m4ri_amd_inv_dev(word *Binv, int64_t b_stride, const word *A, int64_t a_stride, int64_t n, void *stream);
 /* Device twins of mzd_echelonize* and mzd_apply_p_right{,_trans} (echelon.hip).  P: HOST array.  Blocking. */
 int m4ri_amd_echelonize_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int full, int32_t *rank_out, void *stream);
 int m4ri_amd_apply_p_right_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *P, int64_t length, int trans, void *stream);

@@ -123,6 +123,14 @@ SYMBOLS = {
     "mzd_apply_p_right_trans_tri": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
     "mzd_apply_p_right": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
     "mzd_apply_p_right_trans": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_apply_p_left": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_apply_p_left_trans": (None, [MzdPtr, ctypes.POINTER(Mzp)]),
+    "mzd_solve_left": (_I, [MzdPtr, MzdPtr, _I, _I]),
+    "_mzd_solve_left": (_I, [MzdPtr, MzdPtr, _I, _I]),
+    "mzd_pluq_solve_left": (_I, [MzdPtr, _I, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), MzdPtr, _I, _I]),
+    "_mzd_pluq_solve_left": (_I, [MzdPtr, _I, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), MzdPtr, _I, _I]),
+    "mzd_kernel_left_pluq": (MzdPtr, [MzdPtr, _I]),
+    "mzd_inv_m4ri": (MzdPtr, [MzdPtr, MzdPtr, _I]),
     "mzd_echelonize": (_I, [MzdPtr, _I]),
     "mzd_echelonize_m4ri": (_I, [MzdPtr, _I, _I]),
     "mzd_echelonize_pluq": (_I, [MzdPtr, _I]),
@@ -130,6 +138,11 @@ SYMBOLS = {
     "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
     "m4ri_amd_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
     "m4ri_amd_apply_p_right_trans_tri_dev": (_I, [_P, _I64, _I64, _I64, _P, _P]),
+    "m4ri_amd_apply_p_left_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),
+    "m4ri_amd_pluq_solve_left_dev": (_I, [_P, _I64, _I64, _I64, ctypes.c_int32, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P]),
+    "m4ri_amd_solve_left_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I, _I, _P, _P]),
+    "m4ri_amd_kernel_left_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P, _P]),
+    "m4ri_amd_inv_dev": (_I, [_P, _I64, _P, _I64, _I64, _P]),
     "m4ri_amd_echelonize_dev": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
     "m4ri_amd_apply_p_right_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
@@ -287,6 +300,43 @@ def mzd_apply_p_right(A: Mzd, P, trans: bool = False) -> None:
     mp = Mzp()
     mp.values, mp.length = p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(p)
     (lib().mzd_apply_p_right_trans if trans else lib().mzd_apply_p_right)(A.ptr, ctypes.byref(mp))
+
+
+def _mzp(values):
+    import numpy as np
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    mp = Mzp()
+    mp.values, mp.length = v.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(v)
+    return mp, v
+
+
+def mzd_apply_p_left(A: Mzd, P, trans: bool = False) -> None:
+    """The row transpositions (i, P[i]) on A, ascending (or descending: trans) -- reference m4ri/mzp.h:120, :131."""
+    mp, keep = _mzp(P)
+    (lib().mzd_apply_p_left_trans if trans else lib().mzd_apply_p_left)(A.ptr, ctypes.byref(mp))
+
+
+def mzd_solve_left(A: Mzd, B: Mzd, cutoff: int = 0, inconsistency_check: bool = False, which: str = "mzd_solve_left") -> int:
+    """A X = B in place (reference m4ri/solve.h:50): A <- its PLUQ, B <- X with the undefined rows zero; 0 or -1."""
+    return int(getattr(lib(), which)(A.ptr, B.ptr, cutoff, int(inconsistency_check)))
+
+
+def mzd_pluq_solve_left(A: Mzd, rank: int, P, Q, B: Mzd, cutoff: int = 0, inconsistency_check: bool = False, which: str = "mzd_pluq_solve_left") -> int:
+    mp, kp = _mzp(P)
+    mq, kq = _mzp(Q)
+    return int(getattr(lib(), which)(A.ptr, rank, ctypes.byref(mp), ctypes.byref(mq), B.ptr, cutoff, int(inconsistency_check)))
+
+
+def mzd_kernel_left_pluq(A: Mzd, cutoff: int = 0):
+    """A <- its PLUQ; returns the ncols x (ncols - rank) kernel basis or None (reference m4ri/solve.h:140)."""
+    r = lib().mzd_kernel_left_pluq(A.ptr, cutoff)
+    return from_struct_ptr(r, lib().m4ri_amd_result_free) if r else None
+
+
+def mzd_inv_m4ri(A: Mzd, B: Mzd = None) -> Mzd:
+    """B <- A^-1 (reference m4ri/brilliantrussian.h:256)."""
+    r = lib().mzd_inv_m4ri(B.ptr if B is not None else None, A.ptr, 0)
+    return B if B is not None else from_struct_ptr(r, lib().m4ri_amd_result_free)
 
 
 def mzd_apply_p_right_trans_tri(A: Mzd, Q) -> None:

@@ -196,6 +196,7 @@ int m4ri_amd_echelonize_dev(word *A, int64_t stride, int64_t nrows, int64_t ncol
     word *U = nullptr;
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&U), (size_t)rank * wr * 8));
     int rc = (int)hipMemcpy2DAsync(U, (size_t)wr * 8, A, (size_t)stride * 8, (size_t)wr * 8, (size_t)rank, hipMemcpyDeviceToDevice, st);
+    if (!rc) rc = m4ri_amd_mask_tail_dev(U, wr, rank, rank, st);  // the copy's last word also took the first columns of B along
     const int64_t w0 = rank / 64;
     if (!rc) rc = m4ri_amd_trsm_upper_left_dev(U, wr, A + w0, stride, rank, ncols - w0 * 64, 0, st);
     if (!rc) rc = (int)hipStreamSynchronize(st);

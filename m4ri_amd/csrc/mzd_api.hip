@@ -645,6 +645,118 @@ static void run_apply_p_right(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:1
 void mzd_apply_p_right(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 0); }
 void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 1); }
 
+// ---- the drivers over PLUQ: systems, kernels, inverses, row permutations (solve.hip) ---------------------------------
+static void run_apply_p_left(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:65-81
+  if (A->nrows == 0 || A->ncols == 0) return;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  HIPDIE(m4ri_amd_apply_p_left_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, P->length, trans, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+}
+void mzd_apply_p_left(mzd_t *A, mzp_t const *P) { run_apply_p_left(A, P, 0); }
+void mzd_apply_p_left_trans(mzd_t *A, mzp_t const *P) { run_apply_p_left(A, P, 1); }
+
+// A == nullptr-decomposition variant: rank/P/Q given (mzd_pluq_solve_left); otherwise A is decomposed in place
+static int run_solve_left(mzd_t *A, mzd_t const *Adec, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int cutoff, int check) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  int retval = 0;
+  if (cutoff < 0) cutoff = 0;
+  if (A) {
+    arena_reserve(inout_words(A) + inout_words(B));
+    InOut ia = inout_begin(A), ib = inout_begin(B);
+    HIPDIE(m4ri_amd_solve_left_dev(ia.d.p, ia.d.stride, A->nrows, A->ncols, ib.d.p, ib.d.stride, B->nrows, B->ncols, cutoff, check, &retval, nullptr));
+    inout_end(ia, A);
+    inout_end(ib, B);
+  } else {
+    arena_reserve((find_pin(Adec) ? 0 : dev_words(Adec->nrows, Adec->ncols)) + inout_words(B));
+    const DevMat dA = operand(Adec, true);
+    InOut ib        = inout_begin(B);
+    HIPDIE(m4ri_amd_pluq_solve_left_dev(dA.p, dA.stride, Adec->nrows, Adec->ncols, rank, P->values, Q->values, ib.d.p, ib.d.stride, B->nrows, B->ncols,
+                                        cutoff, check, &retval, nullptr));
+    inout_end(ib, B);
+  }
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return retval;
+}
+
+int mzd_solve_left(mzd_t *A, mzd_t *B, int const cutoff, int const inconsistency_check) {  // solve.c:30-40
+  if (A->ncols > B->nrows) die("mzd_solve_left: A ncols (%d) must be smaller than B nrows (%d).\n", A->ncols, B->nrows);
+  if (B->nrows != (A->ncols > A->nrows ? A->ncols : A->nrows))
+    die("mzd_solve_left: B nrows (%d) must be equal to max of A nrows (%d) and A ncols (%d).\n", B->nrows, A->nrows, A->ncols);
+  return run_solve_left(A, nullptr, 0, nullptr, nullptr, B, cutoff, inconsistency_check);
+}
+int _mzd_solve_left(mzd_t *A, mzd_t *B, int const cutoff, int const inconsistency_check) {  // solve.c:123-152
+  return run_solve_left(A, nullptr, 0, nullptr, nullptr, B, cutoff, inconsistency_check);
+}
+int mzd_pluq_solve_left(mzd_t const *A, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int const cutoff, int const inconsistency_check) {  // solve.c:42-55
+  if (A->ncols > B->nrows) die("mzd_pluq_solve_left: A ncols (%d) need to be lower than B nrows (%d).\n", A->ncols, B->nrows);
+  if (P->length != A->nrows) die("mzd_pluq_solve_left: A nrows (%d) need to match P size (%d).\n", A->nrows, P->length);
+  if (Q->length != A->ncols) die("mzd_pluq_solve_left: A ncols (%d) need to match Q size (%d).\n", A->ncols, P->length);
+  return run_solve_left(nullptr, A, rank, P, Q, B, cutoff, inconsistency_check);
+}
+int _mzd_pluq_solve_left(mzd_t const *A, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int const cutoff, int const inconsistency_check) {  // solve.c:57-121
+  return run_solve_left(nullptr, A, rank, P, Q, B, cutoff, inconsistency_check);
+}
+
+mzd_t *mzd_kernel_left_pluq(mzd_t *A, int const cutoff) {  // solve.c:154-191
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  if (A->ncols == 0) return nullptr;  // rank 0 == ncols
+  if (A->nrows == 0) {                // rank 0: every vector is in the kernel (solve.c:168-180 leaves the identity)
+    mzd_t *I = result_init(A->ncols, A->ncols);
+    for (rci_t i = 0; i < A->ncols; ++i) I->data[(int64_t)i * I->rowstride + i / 64] |= (word)1 << (i % 64);
+    return I;
+  }
+  arena_reserve(inout_words(A) + dev_words(A->ncols, A->ncols));
+  InOut ia = inout_begin(A);
+  DevMat dR;
+  dev_alloc(dR, A->ncols, A->ncols);  // the kernel has at most ncols columns; its real width is known after the PLUQ
+  HIPDIE(hipMemsetAsync(dR.p, 0, (size_t)A->ncols * dR.stride * 8, nullptr));
+  int32_t rank = 0;
+  HIPDIE(m4ri_amd_kernel_left_pluq_dev(ia.d.p, ia.d.stride, A->nrows, A->ncols, dR.p, dR.stride, cutoff < 0 ? 0 : cutoff, &rank, nullptr));
+  inout_end(ia, A);
+  mzd_t *R = nullptr;
+  if (rank < A->ncols) {
+    R = result_init(A->ncols, A->ncols - rank);
+    download(dR, R);
+  }
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return R;
+}
+
+mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k) {  // brilliantrussian.c:971-997
+  (void)k;
+  if (A->nrows != A->ncols) die("mzd_inv_m4ri: A must be square and is found to be (%d) x (%d).\n", A->nrows, A->ncols);
+  if (B == nullptr) B = result_init(A->nrows, A->ncols);
+  else if (B->nrows != A->nrows || B->ncols != A->ncols) die("mzd_inv_m4ri: B (%d x %d) has wrong dimensions.\n", B->nrows, B->ncols);
+  if (A->nrows == 0) return B;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve((find_pin(A) ? 0 : dev_words(A->nrows, A->ncols)) + inout_words(B));
+  const DevMat dA = operand(A, true);
+  InOut ib        = inout_begin(B);
+  HIPDIE(m4ri_amd_inv_dev(ib.d.p, ib.d.stride, dA.p, dA.stride, A->nrows, nullptr));
+  inout_end(ib, B);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return B;
+}
+
 // ---- the table primitives of the elimination routines (elim.hip) -------------------------
 static word *arena_raw(size_t words) {  // plain words from the staging arena (256-byte granules)
   word *p = g_arena.base + g_arena.used;

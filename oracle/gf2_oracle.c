@@ -666,3 +666,103 @@ void gf2o_apply_p_right(gf2o_mat *A, const int32_t *P, int64_t length, int trans
       if (P[i] != i) o_col_swap_in_row(A, r, i, P[i]);
     }
 }
+
+
+/* ---- the drivers over PLUQ (m4ri/mzp.c:65-81, m4ri/solve.c:30-191, m4ri/brilliantrussian.c:971-997) ------------------ */
+void gf2o_apply_p_left(gf2o_mat *A, const int32_t *P, int64_t length, int trans) {  /* mzp.c:65-81 */
+  if (A->ncols == 0) return;
+  if (length > A->nrows) length = A->nrows;
+  for (int64_t t = 0; t < length; ++t) {
+    const int64_t i = trans ? length - 1 - t : t;
+    o_row_swap(A, i, P[i]);
+  }
+}
+
+static int o_is_zero(const gf2o_mat *M) {
+  for (int64_t r = 0; r < M->nrows; ++r)
+    for (int64_t w = 0; w < M->width; ++w)
+      if (M->data[r * M->rowstride + w] & (w == M->width - 1 ? M->high_bitmask : ~(gf2o_word)0)) return 0;
+  return 1;
+}
+
+static void o_zero_rows(gf2o_mat *M, int64_t r0, int64_t r1) {
+  for (int64_t r = r0; r < r1; ++r)
+    for (int64_t w = 0; w < M->width; ++w)
+      M->data[r * M->rowstride + w] &= (w == M->width - 1) ? ~M->high_bitmask : 0;
+}
+
+int gf2o_pluq_solve_left(const gf2o_mat *A, int32_t rank, const int32_t *P, const int32_t *Q, gf2o_mat *B, int check) {  /* solve.c:57-121 */
+  int retval = 0;
+  gf2o_apply_p_left(B, P, A->nrows, 0);                                 /* :72 */
+  gf2o_mat *Y1 = gf2o_init_window(B, 0, 0, rank, B->ncols);             /* :76-77 */
+  gf2o_trsm_lower_left(A, Y1);                                          /* :78: only the bits (i, k), k < i < rank, of A are read */
+  if (check) {                                                          /* :81-98 */
+    gf2o_mat *H  = gf2o_init_window((gf2o_mat *)A, rank, 0, A->nrows, rank);
+    gf2o_mat *Y2 = gf2o_init_window(B, rank, 0, A->nrows, B->ncols);
+    if (A->nrows < B->nrows) o_zero_rows(B, A->nrows, B->nrows);
+    if (A->nrows > rank && rank > 0 && B->ncols > 0) gf2o_addmul(Y2, H, Y1, 0);
+    if (!o_is_zero(Y2)) retval = -1;
+    gf2o_free(H);
+    gf2o_free(Y2);
+  }
+  gf2o_trsm_upper_left(A, Y1);                                          /* :100 */
+  gf2o_free(Y1);
+  if (!check) o_zero_rows(B, rank, B->nrows);                           /* :104-114 */
+  gf2o_apply_p_left(B, Q, A->ncols, 1);                                 /* :116 */
+  return retval;
+}
+
+int gf2o_solve_left(gf2o_mat *A, gf2o_mat *B, int check) {                /* solve.c:123-152 */
+  if (check && B->nrows > A->nrows) {
+    gf2o_mat *Bpad = gf2o_init_window(B, A->nrows + 1 <= B->nrows ? A->nrows + 1 : B->nrows, 0, B->nrows, B->ncols);  /* :125: one row late */
+    const int z = o_is_zero(Bpad);
+    gf2o_free(Bpad);
+    if (!z) return -1;
+  }
+  int32_t *P = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A->nrows + 1)), *Q = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A->ncols + 1));
+  const int32_t rank = gf2o_pluq_recursive(A, P, Q, GF2O_PLE_CUTOFF);   /* :143 */
+  const int r = gf2o_pluq_solve_left(A, rank, P, Q, B, check);
+  free(P);
+  free(Q);
+  return r;
+}
+
+/* mzd_kernel_left_pluq (solve.c:154-191).  A <- its PLUQ; returns the rank; when it is below ncols, R (ncols x (ncols -
+ * rank), zeroed by the caller) <- the kernel basis. */
+int32_t gf2o_kernel_left_pluq(gf2o_mat *A, gf2o_mat *R) {
+  int32_t *P = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A->nrows + 1)), *Q = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A->ncols + 1));
+  const int32_t r = gf2o_pluq_recursive(A, P, Q, GF2O_PLE_CUTOFF);
+  if (r < A->ncols && R) {
+    gf2o_mat *RU = gf2o_init_window(R, 0, 0, r, R->ncols);
+    for (int64_t i = 0; i < r; ++i)                                     /* :170-175 */
+      for (int64_t j = 0; j < R->ncols; ++j)
+        if (o_bit(A, i, r + j)) o_flip(R, i, j);
+    gf2o_trsm_upper_left(A, RU);                                        /* :177 */
+    gf2o_free(RU);
+    for (int64_t i = 0; i < R->ncols; ++i) o_flip(R, r + i, i);         /* :179 */
+    gf2o_apply_p_left(R, Q, A->ncols, 1);                               /* :180 */
+  }
+  free(P);
+  free(Q);
+  return r;
+}
+
+/* mzd_inv_m4ri (brilliantrussian.c:971-997): the right block of the reduced row echelon form of [A | 0 | I] */
+void gf2o_inv(gf2o_mat *B, const gf2o_mat *A) {
+  const int64_t n = A->nrows, nr = 64 * A->width;
+  gf2o_mat *C = gf2o_init((int32_t)n, (int32_t)(2 * nr));
+  for (int64_t i = 0; i < n; ++i) {
+    for (int64_t w = 0; w < A->width; ++w)
+      C->data[i * C->rowstride + w] = A->data[i * A->rowstride + w] & (w == A->width - 1 ? A->high_bitmask : ~(gf2o_word)0);
+    o_flip(C, i, nr + i);
+  }
+  gf2o_echelonize(C, 1);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t w = 0; w < B->width; ++w) {
+      const gf2o_word v = C->data[i * C->rowstride + A->width + w];
+      gf2o_word *d = B->data + i * B->rowstride + w;
+      if (w == B->width - 1) *d = (*d & ~B->high_bitmask) | (v & B->high_bitmask);
+      else *d = v;
+    }
+  gf2o_free(C);
+}

@@ -102,6 +102,15 @@ int32_t gf2o_echelonize(gf2o_mat *A, int full);
 /* mzd_apply_p_right (trans = 0) / mzd_apply_p_right_trans (trans = 1), m4ri/mzp.c:193-260 */
 void gf2o_apply_p_right(gf2o_mat *A, const int32_t *P, int64_t length, int trans);
 
+/* The drivers over PLUQ: row transpositions (m4ri/mzp.c:65-81), linear systems (m4ri/solve.c:30-152: A <- its PLUQ,
+ * B <- a solution with the undefined rows zero; -1 = inconsistent), the kernel basis (solve.c:154-191) and the inverse
+ * (m4ri/brilliantrussian.c:971-997). */
+void gf2o_apply_p_left(gf2o_mat *A, const int32_t *P, int64_t length, int trans);
+int gf2o_pluq_solve_left(const gf2o_mat *A, int32_t rank, const int32_t *P, const int32_t *Q, gf2o_mat *B, int check);
+int gf2o_solve_left(gf2o_mat *A, gf2o_mat *B, int check);
+int32_t gf2o_kernel_left_pluq(gf2o_mat *A, gf2o_mat *R);
+void gf2o_inv(gf2o_mat *B, const gf2o_mat *A);
+
 /* table primitives of the elimination routines: m4ri/brilliantrussian.c:163-211 (mzd_make_table: the Gray-code
  * chain T[i] = T[i-1] ^ M[r + inc[i-1]], first word masked below column c, last by the column mask, L[ord[i]] = i,
  * steps whose row does not exist skipped) and :213-601 (mzd_process_rows, 2..6: nt tables, the k-bit strip cut as

@@ -47,6 +47,11 @@ class Oracle:
             "gf2o_pluq": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p]),
             "gf2o_echelonize": (ctypes.c_int32, [MzdPtr, ctypes.c_int]),
             "gf2o_apply_p_right": (None, [MzdPtr, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+            "gf2o_apply_p_left": (None, [MzdPtr, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+            "gf2o_pluq_solve_left": (ctypes.c_int, [MzdPtr, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, MzdPtr, ctypes.c_int]),
+            "gf2o_solve_left": (ctypes.c_int, [MzdPtr, MzdPtr, ctypes.c_int]),
+            "gf2o_kernel_left_pluq": (ctypes.c_int32, [MzdPtr, MzdPtr]),
+            "gf2o_inv": (None, [MzdPtr, MzdPtr]),
             "gf2o_ple_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_pluq_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
@@ -100,6 +105,35 @@ class Oracle:
         import numpy as np
         p = np.ascontiguousarray(P, dtype=np.int32)
         self.L.gf2o_apply_p_right(A.ptr, p.ctypes.data, len(p), int(trans))
+
+    def apply_p_left(self, A, P, trans=False):
+        import numpy as np
+        p = np.ascontiguousarray(P, dtype=np.int32)
+        self.L.gf2o_apply_p_left(A.ptr, p.ctypes.data, len(p), int(trans))
+
+    def solve_left(self, A, B, check=False):
+        """A <- its PLUQ, B <- a solution (undefined rows zero); returns 0 or -1 (inconsistent)."""
+        return int(self.L.gf2o_solve_left(A.ptr, B.ptr, int(check)))
+
+    def pluq_solve_left(self, A, rank, P, Q, B, check=False):
+        import numpy as np
+        p, q = np.ascontiguousarray(P, dtype=np.int32), np.ascontiguousarray(Q, dtype=np.int32)
+        return int(self.L.gf2o_pluq_solve_left(A.ptr, rank, p.ctypes.data, q.ctypes.data, B.ptr, int(check)))
+
+    def kernel_left_pluq(self, A):
+        """A <- its PLUQ; returns (rank, R) with R the ncols x (ncols - rank) kernel basis, or (rank, None)."""
+        from m4ri_amd.mzd import Mzd
+        r = self.ple(A.copy(), pluq=True, recursive=True)[0]
+        R = Mzd(A.ncols, A.ncols - r) if r < A.ncols else None
+        got = int(self.L.gf2o_kernel_left_pluq(A.ptr, R.ptr if R is not None else None))
+        assert got == r
+        return r, R
+
+    def inv(self, A):
+        from m4ri_amd.mzd import Mzd
+        B = Mzd(A.nrows, A.ncols)
+        self.L.gf2o_inv(B.ptr, A.ptr)
+        return B
 
     PLE_CUTOFF = 524288  # __M4RI_PLE_CUTOFF (m4ri/ple.h:40) of any build with an L3 of 4 MiB or more
 
@@ -183,6 +217,10 @@ class Reference:
         for name in ("mzd_apply_p_right", "mzd_apply_p_right_trans", "mzd_apply_p_left", "mzd_apply_p_left_trans"):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = None, [MzdPtr, ctypes.POINTER(Mzp)]
+        L.mzd_solve_left.restype, L.mzd_solve_left.argtypes = _I, [MzdPtr, MzdPtr, _I, _I]
+        L.mzd_pluq_solve_left.restype, L.mzd_pluq_solve_left.argtypes = _I, [MzdPtr, _I, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), MzdPtr, _I, _I]
+        L.mzd_kernel_left_pluq.restype, L.mzd_kernel_left_pluq.argtypes = MzdPtr, [MzdPtr, _I]
+        L.mzd_inv_m4ri.restype, L.mzd_inv_m4ri.argtypes = MzdPtr, [MzdPtr, MzdPtr, _I]
         self.has_mp = hasattr(L, "mzd_mul_mp")
         if self.has_mp:
             L.mzd_mul_mp.restype, L.mzd_mul_mp.argtypes = sig4
@@ -223,6 +261,21 @@ class Reference:
         import numpy as np
         p = np.ascontiguousarray(P, dtype=np.int32)
         getattr(self.L, which)(A.ptr, ctypes.byref(mzp_of(p)))
+
+    def solve_left(self, A, B, check=False):
+        return int(self.L.mzd_solve_left(A.ptr, B.ptr, 0, int(check)))
+
+    def pluq_solve_left(self, A, rank, P, Q, B, check=False):
+        import numpy as np
+        p, q = np.ascontiguousarray(P, dtype=np.int32), np.ascontiguousarray(Q, dtype=np.int32)
+        return int(self.L.mzd_pluq_solve_left(A.ptr, rank, ctypes.byref(mzp_of(p)), ctypes.byref(mzp_of(q)), B.ptr, 0, int(check)))
+
+    def kernel_left_pluq(self, A):
+        r = self.L.mzd_kernel_left_pluq(A.ptr, 0)
+        return from_struct_ptr(r, self.L.mzd_free) if r else None
+
+    def inv(self, A):
+        return from_struct_ptr(self.L.mzd_inv_m4ri(None, A.ptr, 0), self.L.mzd_free)
 
     def ple(self, A, which="_mzd_ple_russian", k=0):
         """In place; returns (rank, P, Q)."""

@@ -1,6 +1,6 @@
 /* tests/l4_timing_driver.c -- what LD_PRELOAD=libm4ri_amd.so does to M4RI's own L4 routines (our own client
  * code against M4RI's public API; linked against the interposable reference build like dropin_driver.c):
- * times mzd_trsm_upper_left, mzd_ple, mzd_pluq, mzd_solve_left and mzd_echelonize at one size.  Run it with and without the preload;
+ * times mzd_trsm_upper_left, mzd_ple, mzd_pluq, mzd_solve_left, mzd_echelonize and mzd_inv_m4ri at one size.  Run it with and without the preload;
  * the internal mzd_addmul / _mzd_addmul calls of those routines then run on the GPU or on the CPU. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -51,13 +51,16 @@ int main(int argc, char **argv) {
   t = now();
   r = mzd_echelonize(A5, 1);
   printf("  mzd_echelonize full %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
+  t = now();
+  mzd_t *Ai = mzd_inv_m4ri(NULL, A, 0);
+  printf("  mzd_inv_m4ri        %d x %d : %.3f s\n", n, n, now() - t);
   /* fingerprints so that the two runs can be compared */
-  word f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+  word f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0;
   for (rci_t i = 0; i < n; ++i)
     for (wi_t w = 0; w < X->width; ++w) { f1 = f1 * 1099511628211ull ^ mzd_row(X, i)[w]; f2 = f2 * 1099511628211ull ^ mzd_row(A2, i)[w];
       f3 = f3 * 1099511628211ull ^ mzd_row(A4, i)[w]; f4 = f4 * 1099511628211ull ^ mzd_row(Y, i)[w];
-      f5 = f5 * 1099511628211ull ^ mzd_row(A5, i)[w]; }
-  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx echelon %016llx\n", (unsigned long long)f1, (unsigned long long)f2,
-         (unsigned long long)f3, (unsigned long long)f4, (unsigned long long)f5);
+      f5 = f5 * 1099511628211ull ^ mzd_row(A5, i)[w]; f6 = f6 * 1099511628211ull ^ mzd_row(Ai, i)[w]; }
+  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx echelon %016llx inverse %016llx\n", (unsigned long long)f1, (unsigned long long)f2,
+         (unsigned long long)f3, (unsigned long long)f4, (unsigned long long)f5, (unsigned long long)f6);
   return 0;
 }
