@@ -20,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "gf2_common.h"
 #include "../../include/m4ri_amd.h"
@@ -195,40 +197,62 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
   return cutoff;  // 0 = engine default; >0 normalised inside m4ri_amd_mul_dev
 }
 
-// Large products from host memory, pipelined over blocks of C:  C_ij = A_i * B_j  on a gi x gj grid (2 x 2 when both m
-// and n allow it -- the blocks of a 65536^3 product then keep the full Strassen depth --, four row slabs of A and C
-// otherwise).  The copies are blocking calls of this thread (pageable memory), the products run on a non-blocking stream:
-//   upload A_0, B_0 | P_00 || upload B_1 | P_01 || upload A_1, download C_00 | P_10 || download C_01 | P_11 || ... | download
-// so of the 1.5 GiB over PCIe at 65536^3 only A_0, B_0 and the last block of C stay exposed.  Same bits as the one-shot
-// schedule (a block is an ordinary product).  Returns false when the product is too small to pay for it.
+// Large products from host memory, pipelined over blocks:  C_ij (+)= A_ik * B_kj  on a gi x gj x gk grid (2 x 2 x 1 when
+// both m and n allow it, 2 x 2 x 2 from 65536^3 on, four row slabs of A and C for narrow products).  The uploads are
+// blocking calls of this thread, the downloads of a second one (PCIe is full duplex), the products run on a non-blocking
+// stream:  upload A_00, B_00 | P || upload A_01, B_10 | P -> C_00 complete: download || upload B_01 | P || ...
+// so of the 1.5 GiB over PCIe at 65536^3 only the first pair of blocks (256 MiB) and the last block of C (128 MiB) stay
+// exposed.  Same bits as the one-shot schedule (every step is an ordinary product or addmul).  Returns false when the
+// product is too small to pay for it.
 size_t g_pipeline_min_bytes = (size_t)256 << 20;  // A + B + C bytes from which blocks are used; 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
 bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff) {
-  const int64_t m = A->nrows, n = B->ncols;
+  const int64_t m = A->nrows, l = A->ncols, n = B->ncols;
   const size_t bytes = ((size_t)m * A->width + (size_t)B->nrows * B->width + (size_t)m * C->width) * 8;
   if (g_pipeline_min_bytes == 0 || bytes < g_pipeline_min_bytes || m < 4 * 4096) return false;
-  // cuts: rows on whole 4096-row tiles, columns on whole words
-  std::vector<int64_t> rcut, ccut;
-  if (n >= 16384) {
-    rcut = {0, ((m / 2 + 4095) / 4096) * 4096, m};
-    ccut = {0, (n / 128) * 64, n};
+  // cuts: rows of A / C on whole 4096-row tiles, columns and the inner dimension on whole words
+  std::vector<int64_t> rcut, ccut, kcut;
+  static const char *grid_env = getenv("M4RI_AMD_PIPE_GRID");  // "gi,gj[,gk]": developer override of the block grid
+  int egi = 0, egj = 0, egk = 1;
+  const int nenv = grid_env ? sscanf(grid_env, "%d,%d,%d", &egi, &egj, &egk) : 0;
+  if (nenv >= 2 && egi >= 1 && egj >= 1 && egk >= 1 && m >= (int64_t)egi * 4096 && n >= (int64_t)egj * 64 && l >= (int64_t)egk * 64) {
+    if (nenv < 3) egk = 1;
+  } else if (n >= 16384) {
+    egi = 2; egj = 2;
+    // from 65536^3 on also two slices of the inner dimension: the blocks stay cubes (full Strassen depth) and the first
+    // product waits for half as many bytes (43.1 instead of 46.0 ms; at 32768^3 the plain 2 x 2 is 3 % faster)
+    egk = (l >= 65536 && m >= 65536 && n >= 65536) ? 2 : 1;
+  } else {
+    egi = (int)((m + ((m / 4 + 4095) / 4096) * 4096 - 1) / (((m / 4 + 4095) / 4096) * 4096)); egj = 1; egk = 1;
+  }
+  if (n >= 16384 || nenv >= 2) {
+    for (int i = 0; i < egi; ++i) rcut.push_back(((m * i / egi + 4095) / 4096) * 4096);
+    rcut.push_back(m);
   } else {
     const int64_t srows = ((m / 4 + 4095) / 4096) * 4096;
     for (int64_t r = 0; r < m; r += srows) rcut.push_back(r);
     rcut.push_back(m);
-    ccut = {0, n};
   }
-  const int gi = (int)rcut.size() - 1, gj = (int)ccut.size() - 1;
+  for (int j = 0; j < egj; ++j) ccut.push_back((n * j / egj / 64) * 64);
+  ccut.push_back(n);
+  for (int k = 0; k < egk; ++k) kcut.push_back((l * k / egk / 64) * 64);
+  kcut.push_back(l);
+  const int gi = (int)rcut.size() - 1, gj = (int)ccut.size() - 1, gk = (int)kcut.size() - 1;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   hipStream_t &cs = g_compute_stream[dev];
   if (!cs) HIPDIE(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  auto R = [&](int i) { return rcut[(size_t)i + 1] - rcut[(size_t)i]; };
+  auto Cc = [&](int j) { return ccut[(size_t)j + 1] - ccut[(size_t)j]; };
+  auto K = [&](int k) { return kcut[(size_t)k + 1] - kcut[(size_t)k]; };
   size_t need = 0;
-  for (int i = 0; i < gi; ++i) need += dev_words(rcut[(size_t)i + 1] - rcut[(size_t)i], A->ncols);
-  for (int j = 0; j < gj; ++j) need += dev_words(B->nrows, ccut[(size_t)j + 1] - ccut[(size_t)j]);
   for (int i = 0; i < gi; ++i)
-    for (int j = 0; j < gj; ++j) need += dev_words(rcut[(size_t)i + 1] - rcut[(size_t)i], ccut[(size_t)j + 1] - ccut[(size_t)j]);
+    for (int k = 0; k < gk; ++k) need += dev_words(R(i), K(k));
+  for (int k = 0; k < gk; ++k)
+    for (int j = 0; j < gj; ++j) need += dev_words(K(k), Cc(j));
+  for (int i = 0; i < gi; ++i)
+    for (int j = 0; j < gj; ++j) need += dev_words(R(i), Cc(j));
   arena_reserve(need);
   auto block_of = [&](const mzd_t *M, int64_t r0, int64_t r1, int64_t c0, int64_t c1) {  // mzd_init_window, mzd.c:159-177
     mzd_t S = *M;
@@ -241,57 +265,80 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     if ((M->flags & FLAG_WINDOW) || c1 != M->ncols) S.flags |= FLAG_WINDOW;
     return S;
   };
-  std::vector<DevMat> dA((size_t)gi), dB((size_t)gj), dC((size_t)gi * gj);
-  std::vector<hipEvent_t> upA((size_t)gi, nullptr), upB((size_t)gj, nullptr), upC((size_t)gi * gj, nullptr), done((size_t)gi * gj, nullptr);
+  const int nt = gi * gj;
+  std::vector<DevMat> dA((size_t)gi * gk), dB((size_t)gk * gj), dC((size_t)nt);
+  std::vector<hipEvent_t> upA((size_t)gi * gk, nullptr), upB((size_t)gk * gj, nullptr), upC((size_t)nt, nullptr), done((size_t)nt, nullptr);
   auto ev = [](hipEvent_t &e) { HIPDIE(hipEventCreateWithFlags(&e, hipEventDisableTiming)); };
-  auto upload_a = [&](int i) {  // host rows -> device (blocking), tail masks on the null stream, then the event the products wait for
-    if (upA[(size_t)i]) return;
-    const mzd_t S = block_of(A, rcut[(size_t)i], rcut[(size_t)i + 1], 0, A->ncols);
-    upload(dA[(size_t)i], &S);
-    ev(upA[(size_t)i]);
-    HIPDIE(hipEventRecord(upA[(size_t)i], nullptr));
+  auto upload_a = [&](int i, int k) {  // host rows -> device (blocking), tail masks on the null stream, then the event the products wait for
+    hipEvent_t &e = upA[(size_t)i * gk + k];
+    if (e) return;
+    const mzd_t S = block_of(A, rcut[(size_t)i], rcut[(size_t)i + 1], kcut[(size_t)k], kcut[(size_t)k + 1]);
+    upload(dA[(size_t)i * gk + k], &S);
+    ev(e);
+    HIPDIE(hipEventRecord(e, nullptr));
   };
-  auto upload_b = [&](int j) {
-    if (upB[(size_t)j]) return;
-    const mzd_t S = block_of(B, 0, B->nrows, ccut[(size_t)j], ccut[(size_t)j + 1]);
-    upload(dB[(size_t)j], &S);
-    ev(upB[(size_t)j]);
-    HIPDIE(hipEventRecord(upB[(size_t)j], nullptr));
+  auto upload_b = [&](int k, int j) {
+    hipEvent_t &e = upB[(size_t)k * gj + j];
+    if (e) return;
+    const mzd_t S = block_of(B, kcut[(size_t)k], kcut[(size_t)k + 1], ccut[(size_t)j], ccut[(size_t)j + 1]);
+    upload(dB[(size_t)k * gj + j], &S);
+    ev(e);
+    HIPDIE(hipEventRecord(e, nullptr));
   };
   auto c_block = [&](int i, int j) { return block_of(C, rcut[(size_t)i], rcut[(size_t)i + 1], ccut[(size_t)j], ccut[(size_t)j + 1]); };
   auto prepare_c = [&](int t) {
+    if (upC[(size_t)t]) return;
     const mzd_t S = c_block(t / gj, t % gj);
     if (add) upload(dC[(size_t)t], &S);
     else dev_alloc(dC[(size_t)t], S.nrows, S.ncols);
     ev(upC[(size_t)t]);
     HIPDIE(hipEventRecord(upC[(size_t)t], nullptr));
   };
-  auto download_c = [&](int t) {
-    HIPDIE(hipEventSynchronize(done[(size_t)t]));
-    mzd_t S = c_block(t / gj, t % gj);
-    download(dC[(size_t)t], &S);
-  };
-  const int nt = gi * gj;
-  upload_a(0);
-  upload_b(0);
-  prepare_c(0);
-  for (int t = 0; t < nt; ++t) {
-    const int i = t / gj, j = t % gj;
-    HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i], 0));
-    HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)j], 0));
-    HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
-    HIPDIE(m4ri_amd_mul_dev(dC[(size_t)t].p, dC[(size_t)t].stride, dA[(size_t)i].p, dA[(size_t)i].stride, dB[(size_t)j].p, dB[(size_t)j].stride,
-                            rcut[(size_t)i + 1] - rcut[(size_t)i], A->ncols, ccut[(size_t)j + 1] - ccut[(size_t)j], add, cutoff, cs));
-    ev(done[(size_t)t]);
-    HIPDIE(hipEventRecord(done[(size_t)t], cs));
-    if (t + 1 < nt) {  // what the next product needs: overlaps product t
-      upload_a((t + 1) / gj);
-      upload_b((t + 1) % gj);
-      prepare_c(t + 1);
+  // The downloads run on a second host thread: a blocking copy holds its thread, and the blocks of C can travel down
+  // while the next operands travel up (PCIe is full duplex: 53 GiB/s each way on this box, tools/pcie_probe_2d.py).
+  std::mutex dl_mu;
+  std::condition_variable dl_cv;
+  int issued = 0;  // blocks of C whose `done` event exists
+  std::thread downloader([&]() {
+    HIPDIE(hipSetDevice(dev));
+    for (int t = 0; t < nt; ++t) {
+      {
+        std::unique_lock<std::mutex> lk(dl_mu);
+        dl_cv.wait(lk, [&] { return issued > t; });
+      }
+      HIPDIE(hipEventSynchronize(done[(size_t)t]));
+      mzd_t S = c_block(t / gj, t % gj);
+      download(dC[(size_t)t], &S);
     }
-    if (t >= 1) download_c(t - 1);  // product t - 1 is finished or about to be; overlaps product t
+  });
+  // products in the order (block of C, inner slice); the uploads of step s + 1 are issued right after product s
+  const int steps = nt * gk;
+  auto need_for = [&](int s) {
+    const int t = s / gk, k = s % gk;
+    upload_a(t / gj, k);
+    upload_b(k, t % gj);
+    prepare_c(t);
+  };
+  need_for(0);
+  for (int s = 0; s < steps; ++s) {
+    const int t = s / gk, k = s % gk, i = t / gj, j = t % gj;
+    HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i * gk + k], 0));
+    HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)k * gj + j], 0));
+    HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
+    const DevMat &a = dA[(size_t)i * gk + k], &b = dB[(size_t)k * gj + j];
+    HIPDIE(m4ri_amd_mul_dev(dC[(size_t)t].p, dC[(size_t)t].stride, a.p, a.stride, b.p, b.stride, R(i), K(k), Cc(j), (add || k > 0) ? 1 : 0, cutoff, cs));
+    if (k == gk - 1) {
+      ev(done[(size_t)t]);
+      HIPDIE(hipEventRecord(done[(size_t)t], cs));
+      {
+        std::lock_guard<std::mutex> lk(dl_mu);
+        issued = t + 1;
+      }
+      dl_cv.notify_one();
+    }
+    if (s + 1 < steps) need_for(s + 1);  // overlaps product s
   }
-  download_c(nt - 1);
+  downloader.join();
   HIPDIE(hipDeviceSynchronize());
   for (auto *v : {&upA, &upB, &upC, &done})
     for (hipEvent_t e : *v)
