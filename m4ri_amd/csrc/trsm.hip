@@ -8,12 +8,14 @@
 //   _mzd_trsm_lower_left_russian / _mzd_trsm_upper_left_russian  m4ri/triangular_russian.c:206-330, :50-170
 // The reference recurses on halves with mzd_addmul for the update (triangular.c:437-441, :501-505), solves
 // blocks of <= 2048 rows by a Four-Russians sweep (tables of the rows just solved, one pass over the rows
-// below per 8k pivot rows) and blocks of <= 64 rows by direct substitution.  Here the recursion goes all the
-// way down to 64 rows with the engine's own product for every update (a rank-64 .. rank-n/2 addmul on
-// device-resident views), and the 64-row base is one small kernel: a thread owns one 64-bit word column of B,
-// keeps its 64 words in registers and substitutes; the rows of the triangle are wave-uniform (scalar loads).
+// below per 8k pivot rows) and blocks of <= 64 rows by direct substitution.  Here the recursion on halves runs on
+// the engine's own product (addmul on device-resident views) down to blocks of 512 rows; those are solved by
+// multiplying with the block's inverse, all diagonal blocks inverted up front in one launch (see below).  Systems
+// of <= 64 rows (the PLE's pivot rows) take one small kernel: a thread owns one 64-bit word column of B, keeps its
+// 64 words in registers and substitutes; the rows of the triangle are wave-uniform (scalar loads).
 // The diagonal is never read (taken as 1) and neither is the other triangle, exactly like the reference.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "gf2_common.h"
 #include "../../include/m4ri_amd.h"
 
@@ -71,6 +73,93 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__r
     }
 }
 
+// ---- blocks of 512 rows through their inverses -------------------------------------------------------------------
+// A product call costs ~65 us whatever its size (pack, leaf prologue, split reduction), so a recursion that bottoms out
+// at 64 rows spends its time launching: 1023 products and 1024 base kernels for a 65536-row triangle.  The diagonal
+// blocks of 512 rows are inverted up front instead -- all of them in ONE launch, a workgroup per block, a thread per
+// column of the inverse (substitution on a unit vector, the block's rows broadcast), transposed through LDS -- and a
+// block's solve becomes X = T_bb^-1 * B_b, one product; the recursion stops at 512 rows (127 + 128 products).
+constexpr int TB = 512;  // rows of a diagonal block
+
+template <bool UPPER>
+__global__ __launch_bounds__(TB) void trsm_invert_blocks_kernel(const word *__restrict__ T, int64_t t_stride, int64_t mb, word *__restrict__ Tinv) {
+  __shared__ word cols[TB][TB / 64 + 1];  // cols[j] = column j of the inverse (bit i = entry (i, j)); +1: bank spread
+  const int64_t r0 = (int64_t)blockIdx.x * TB;
+  const int sz     = (int)((mb - r0) < TB ? (mb - r0) : TB);
+  const int j      = threadIdx.x;
+  const word *blk  = T + r0 * t_stride + r0 / 64;  // the block's rows, from its own first column on
+  word x[TB / 64];
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) x[w] = 0;
+  // T x = e_j by substitution.  Entries of x not computed yet are 0, so a row's diagonal, its other triangle and whatever
+  // lies beyond the block's columns never contribute.
+  for (int t = 0; t < sz; ++t) {
+    const int i     = UPPER ? sz - 1 - t : t;
+    const word *row = blk + (int64_t)i * t_stride;
+    word p = 0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (w * 64 < sz) p ^= row[w] & x[w];
+    const word bit = (word)((__popcll(p) & 1) ^ (i == j ? 1 : 0));
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (w == i / 64) x[w] |= bit << (i % 64);
+  }
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) cols[j][w] = (j < sz) ? x[w] : 0;
+  __syncthreads();
+  // row i of the inverse: bit j = cols[j] bit i
+  const int i = threadIdx.x;
+  word out[TB / 64];
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) out[w] = 0;
+  if (i < sz)
+    for (int jj = 0; jj < sz; ++jj) out[jj / 64] |= ((cols[jj][i / 64] >> (i % 64)) & 1) << (jj % 64);
+  word *dst = Tinv + ((int64_t)blockIdx.x * TB + i) * (TB / 64);
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) dst[w] = out[w];
+}
+
+struct TrsmScratch {
+  word *inv = nullptr, *tmp = nullptr;
+  size_t inv_words = 0, tmp_words = 0;
+  hipEvent_t last = nullptr;  // end of the previous solve that used the scratch (it may have run on another stream)
+};
+TrsmScratch g_trsm_scratch[16];
+std::mutex g_trsm_mu;
+
+struct TrsmRun {
+  bool upper;
+  const word *T;  // the whole triangle
+  int64_t ts;
+  word *B;
+  int64_t bs, nb;
+  int cutoff;
+  hipStream_t st;
+  const word *inv;  // the inverted diagonal blocks, block k at inv + k * TB * (TB / 64)
+  word *tmp;        // TB x words_of(nb) words
+};
+
+// rows [r0, r0 + mb) of the system, r0 a multiple of TB
+int solve_blocks(const TrsmRun &R, int64_t r0, int64_t mb) {
+  const int64_t wn = words_of(R.nb);
+  word *Bb = R.B + r0 * R.bs;
+  if (mb <= TB) {  // X = T_bb^-1 * B_b
+    HIPTRY(hipMemcpy2DAsync(R.tmp, (size_t)wn * 8, Bb, (size_t)R.bs * 8, (size_t)wn * 8, (size_t)mb, hipMemcpyDeviceToDevice, R.st));
+    return m4ri_amd_mul_dev(Bb, R.bs, R.inv + (r0 / TB) * TB * (TB / 64), TB / 64, R.tmp, wn, mb, mb, R.nb, 0, R.cutoff, R.st);
+  }
+  const int64_t mb1 = (((mb - 1) / TB + 1) >> 1) * TB;  // halves on a block boundary
+  const word *Tr = R.T + r0 * R.ts + r0 / 64;           // this sub-triangle
+  if (!R.upper) {
+    if (int rc = solve_blocks(R, r0, mb1)) return rc;
+    HIPTRY(m4ri_amd_mul_dev(Bb + mb1 * R.bs, R.bs, Tr + mb1 * R.ts, R.ts, Bb, R.bs, mb - mb1, mb1, R.nb, 1, R.cutoff, R.st));
+    return solve_blocks(R, r0 + mb1, mb - mb1);
+  }
+  if (int rc = solve_blocks(R, r0 + mb1, mb - mb1)) return rc;
+  HIPTRY(m4ri_amd_mul_dev(Bb, R.bs, Tr + mb1 / 64, R.ts, Bb + mb1 * R.bs, R.bs, mb1, mb - mb1, R.nb, 1, R.cutoff, R.st));
+  return solve_blocks(R, r0, mb1);
+}
+
 int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb, int64_t nb, int cutoff, hipStream_t st) {
   if (mb <= 1 || nb <= 0) return 0;
   if (mb <= 64) {
@@ -81,20 +170,38 @@ int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb
     else       hipLaunchKernelGGL((trsm_base_kernel<false>), dim3(g), dim3(TRSM_THREADS), 0, st, T, ts, B, bs, (int)mb, wn, mask);
     return (int)hipGetLastError();
   }
-  // halves on a word boundary of the triangle's columns (triangular.c:428, :492)
-  const int64_t mb1 = (((mb - 1) / 64 + 1) >> 1) * 64;
-  word *B0 = B, *B1 = B + mb1 * bs;
-  const word *T00 = T, *T11 = T + mb1 * ts + mb1 / 64;
-  if (!upper) {
-    const word *L10 = T + mb1 * ts;  // (mb - mb1) x mb1
-    if (int rc = solve(false, T00, ts, B0, bs, mb1, nb, cutoff, st)) return rc;
-    HIPTRY(m4ri_amd_mul_dev(B1, bs, L10, ts, B0, bs, mb - mb1, mb1, nb, 1, cutoff, st));
-    return solve(false, T11, ts, B1, bs, mb - mb1, nb, cutoff, st);
+  // The operands handed to the multiply engine must not carry bits beyond their own columns: the sub-diagonal blocks
+  // T[r.., c..c+l) end on a 512-column boundary or on the triangle's last column mb -- the caller keeps T's bits beyond
+  // column mb out of the way (a clean mb x mb matrix, or a masked copy: see echelon.hip / solve.hip).
+  std::lock_guard<std::mutex> lk(g_trsm_mu);
+  int dev = 0;
+  HIPTRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  TrsmScratch &s = g_trsm_scratch[dev];
+  const int64_t nblk = (mb + TB - 1) / TB, wn = words_of(nb);
+  const size_t need_inv = (size_t)nblk * TB * (TB / 64), need_tmp = (size_t)TB * (size_t)wn;
+  // grow-only scratch; a buffer still in use by an earlier call on another stream must not be freed under it
+  if (need_inv > s.inv_words) {
+    if (s.inv) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.inv)); }
+    s.inv = nullptr; s.inv_words = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.inv), need_inv * 8));
+    s.inv_words = need_inv;
   }
-  const word *U01 = T + mb1 / 64;    // mb1 x (mb - mb1)
-  if (int rc = solve(true, T11, ts, B1, bs, mb - mb1, nb, cutoff, st)) return rc;
-  HIPTRY(m4ri_amd_mul_dev(B0, bs, U01, ts, B1, bs, mb1, mb - mb1, nb, 1, cutoff, st));
-  return solve(true, T00, ts, B0, bs, mb1, nb, cutoff, st);
+  if (need_tmp > s.tmp_words) {
+    if (s.tmp) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.tmp)); }
+    s.tmp = nullptr; s.tmp_words = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.tmp), need_tmp * 8));
+    s.tmp_words = need_tmp;
+  }
+  if (!s.last) HIPTRY(hipEventCreateWithFlags(&s.last, hipEventDisableTiming));
+  else HIPTRY(hipStreamWaitEvent(st, s.last, 0));
+  if (upper) hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, mb, s.inv);
+  else       hipLaunchKernelGGL((trsm_invert_blocks_kernel<false>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, mb, s.inv);
+  HIPTRY(hipGetLastError());
+  const TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  const int rc = solve_blocks(R, 0, mb);
+  HIPTRY(hipEventRecord(s.last, st));
+  return rc;
 }
 
 // ---- right-hand solves: B <- B * T^-1 (X * T = B) -----------------------------------------------------------------
