@@ -232,6 +232,29 @@ __global__ __launch_bounds__(256) void trsm_right_base_kernel(const word *__rest
   B[r * b_stride] = x;
 }
 
+// columns [c0, c0 + nb) of the system X T = B, c0 a multiple of TB: the same scheme as solve_blocks -- X_b = B_b * T_bb^-1
+int solve_right_blocks(const TrsmRun &R, int64_t mrows, int64_t c0, int64_t nb) {
+  word *Bb = R.B + c0 / 64;
+  if (nb <= TB) {
+    const int64_t wb = words_of(nb);
+    HIPTRY(hipMemcpy2DAsync(R.tmp, (size_t)wb * 8, Bb, (size_t)R.bs * 8, (size_t)wb * 8, (size_t)mrows, hipMemcpyDeviceToDevice, R.st));
+    if (nb % 64) HIPTRY(m4ri_amd_mask_tail_dev(R.tmp, wb, mrows, nb, R.st));  // the copy's last word may carry the columns behind the system
+    // the product writes whole words of its nb columns: bits of B beyond column c0 + nb in that word are rewritten as zero,
+    // which is what they are (B's own tail) whenever nb is not a multiple of 64 -- that only happens in the last block
+    return m4ri_amd_mul_dev(Bb, R.bs, R.tmp, wb, R.inv + (c0 / TB) * TB * (TB / 64), TB / 64, mrows, nb, nb, 0, R.cutoff, R.st);
+  }
+  const int64_t nb1 = (((nb - 1) / TB + 1) >> 1) * TB;
+  const word *Tr = R.T + c0 * R.ts + c0 / 64;
+  if (R.upper) {
+    if (int rc = solve_right_blocks(R, mrows, c0, nb1)) return rc;
+    HIPTRY(m4ri_amd_mul_dev(Bb + nb1 / 64, R.bs, Bb, R.bs, Tr + nb1 / 64, R.ts, mrows, nb1, nb - nb1, 1, R.cutoff, R.st));
+    return solve_right_blocks(R, mrows, c0 + nb1, nb - nb1);
+  }
+  if (int rc = solve_right_blocks(R, mrows, c0 + nb1, nb - nb1)) return rc;
+  HIPTRY(m4ri_amd_mul_dev(Bb, R.bs, Bb + nb1 / 64, R.bs, Tr + nb1 * R.ts, R.ts, mrows, nb - nb1, nb1, 1, R.cutoff, R.st));
+  return solve_right_blocks(R, mrows, c0, nb1);
+}
+
 int solve_right(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb, int64_t nb, int cutoff, hipStream_t st) {
   if (mb <= 0 || nb <= 1) return 0;
   if (nb <= 64) {
@@ -240,19 +263,34 @@ int solve_right(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int6
     else       hipLaunchKernelGGL((trsm_right_base_kernel<false>), dim3(g), dim3(256), 0, st, T, ts, B, bs, mb, (int)nb);
     return (int)hipGetLastError();
   }
-  const int64_t nb1 = (((nb - 1) / 64 + 1) >> 1) * 64;  // triangular.c:72, :319
-  word *B0 = B, *B1 = B + nb1 / 64;
-  const word *T00 = T, *T11 = T + nb1 * ts + nb1 / 64;
-  if (upper) {
-    const word *U01 = T + nb1 / 64;  // nb1 x (nb - nb1)
-    if (int rc = solve_right(true, T00, ts, B0, bs, mb, nb1, cutoff, st)) return rc;
-    HIPTRY(m4ri_amd_mul_dev(B1, bs, B0, bs, U01, ts, mb, nb1, nb - nb1, 1, cutoff, st));
-    return solve_right(true, T11, ts, B1, bs, mb, nb - nb1, cutoff, st);
+  std::lock_guard<std::mutex> lk(g_trsm_mu);
+  int dev = 0;
+  HIPTRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  TrsmScratch &s = g_trsm_scratch[dev];
+  const int64_t nblk = (nb + TB - 1) / TB;
+  const size_t need_inv = (size_t)nblk * TB * (TB / 64), need_tmp = (size_t)mb * (TB / 64);
+  if (need_inv > s.inv_words) {
+    if (s.inv) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.inv)); }
+    s.inv = nullptr; s.inv_words = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.inv), need_inv * 8));
+    s.inv_words = need_inv;
   }
-  const word *L10 = T + nb1 * ts;    // (nb - nb1) x nb1
-  if (int rc = solve_right(false, T11, ts, B1, bs, mb, nb - nb1, cutoff, st)) return rc;
-  HIPTRY(m4ri_amd_mul_dev(B0, bs, B1, bs, L10, ts, mb, nb - nb1, nb1, 1, cutoff, st));
-  return solve_right(false, T00, ts, B0, bs, mb, nb1, cutoff, st);
+  if (need_tmp > s.tmp_words) {
+    if (s.tmp) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.tmp)); }
+    s.tmp = nullptr; s.tmp_words = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.tmp), need_tmp * 8));
+    s.tmp_words = need_tmp;
+  }
+  if (!s.last) HIPTRY(hipEventCreateWithFlags(&s.last, hipEventDisableTiming));
+  else HIPTRY(hipStreamWaitEvent(st, s.last, 0));
+  if (upper) hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, nb, s.inv);
+  else       hipLaunchKernelGGL((trsm_invert_blocks_kernel<false>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, nb, s.inv);
+  HIPTRY(hipGetLastError());
+  const TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  const int rc = solve_right_blocks(R, mb, 0, nb);
+  HIPTRY(hipEventRecord(s.last, st));
+  return rc;
 }
 
 }  // namespace
