@@ -41,7 +41,10 @@ namespace {
     if (e_ != hipSuccess) return (int)e_;             \
   } while (0)
 
-constexpr int SLICE_THREADS = 1024;
+#ifndef PLE_SLICE_THREADS
+#define PLE_SLICE_THREADS 1024
+#endif
+constexpr int SLICE_THREADS = PLE_SLICE_THREADS;
 constexpr int ROW_THREADS   = 256;
 
 struct PleBlock {
@@ -157,6 +160,87 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   if (tid == 0) out->rank = rank;
 }
 
+// ---- 1'. the same search in ONE WAVE, for blocks whose pivots all sit within 64 rows of the rank position --------------
+// The general kernel above spends ~1 us per column on workgroup barriers and LDS hand-offs (60 us per block whatever the
+// matrix).  With a window of 64 rows the hand-offs are lane reads: the pivot lane is the lowest set bit of a ballot, its
+// word comes by v_readlane, the window moves by a lane shift, pivot l's column and tail live in lane l.  Same rule, same
+// outputs.  When a column has no pivot inside the window while rows lie beyond it, the kernel gives up without having
+// touched V (rank = -1) and the host runs the general kernel on the block instead.
+__device__ __forceinline__ word wave_read(word x, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+  return ((word)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
+  __shared__ word s_head[128];  // the original words of the first 128 rows, kept in step with the swaps
+  const int tid   = threadIdx.x;
+  const int nhead = (int)(n < 128 ? n : 128);
+  s_head[tid]      = tid < nhead ? V[tid] : 0;
+  s_head[tid + 64] = tid + 64 < nhead ? V[tid + 64] : 0;
+  __syncthreads();
+  word v  = s_head[tid];
+  int cnt = 0, rank = 0;
+  word ph = 0;            // lane l: pivot l from the column after its pivot column on
+  int pc = 0, psw = 0;    // lane l: pivot l's column, and the row (relative to r0) that was swapped up for it
+  for (int c = 0; c < ncb && rank < n; ++c) {
+    const bool valid = (int64_t)rank + tid < n;
+    unsigned long long b = __ballot(valid && cnt == rank && ((v >> c) & 1));
+    if (!b) {
+      if (__ballot(valid && cnt < rank)) {  // the rows that entered the window since catch up with the pivots found meanwhile
+        for (int l = 0; l < rank; ++l) {
+          const word hl = wave_read(ph, l);
+          const int cl  = __builtin_amdgcn_readlane(pc, l);
+          if (valid && l >= cnt && ((v >> cl) & 1)) v ^= hl;
+        }
+        if (valid && cnt < rank) cnt = rank;
+        b = __ballot(valid && cnt == rank && ((v >> c) & 1));
+      }
+      if (!b) {
+        if ((int64_t)rank + 64 < n) {  // candidates beyond the window: not this kernel's case
+          if (tid == 0) out->rank = -1;
+          return;
+        }
+        continue;  // no pivot in this column
+      }
+    }
+    const int pl  = (int)__builtin_ctzll(b);  // lane of the pivot row; its position is rank + pl
+    const word vp = wave_read(v, pl);
+    const word high = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
+    if (tid == 0) {
+      const word vr = s_head[rank];
+      s_head[rank + pl] = vr;  // the displaced row keeps its original word
+      s_head[rank]      = vp;  // the pivot row's word is final
+    }
+    if (tid == rank) { ph = high; pc = c; psw = rank + pl; }
+    __syncthreads();
+    if (cnt == rank) {
+      if (tid != pl && ((v >> c) & 1)) v ^= high;
+      cnt = rank + 1;
+    }
+    // the row the pivot displaced (lane 0's) sits where the pivot was; then the window moves one lane to the left and the
+    // next row enters at the top, with no pivot applied yet
+    const word v0 = wave_read(v, 0);
+    const int c0  = __builtin_amdgcn_readlane(cnt, 0);
+    if (tid == pl && pl > 0) { v = v0; cnt = c0; }
+    const int64_t enter = (int64_t)rank + 1 + 63;
+    word vn = __shfl_down(v, 1);
+    int cn  = __shfl_down(cnt, 1);
+    if (tid == 63) { vn = enter < nhead ? s_head[enter] : 0; cn = 0; }
+    v = vn; cnt = cn;
+    ++rank;
+  }
+  __syncthreads();
+  if (tid < nhead) V[tid] = s_head[tid];
+  if (tid + 64 < nhead) V[tid + 64] = s_head[tid + 64];
+  if (tid < rank) {
+    out->pivcol[tid]  = pc;
+    out->swaprow[tid] = (int32_t)(r0 + psw);
+    out->vhigh[tid]   = ph;
+  }
+  if (tid == 0) out->rank = rank;
+}
+
 // ---- 2a. the block's row swaps on every other word; one thread per word column ---------------------------------
 __global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wb, int64_t r0,
                                                                    const PleBlock *__restrict__ blk) {
@@ -175,13 +259,38 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__rest
 // ---- 2b. the slice eliminated row by row (parallel), written back, multipliers gathered --------------------------------
 // rows below the pivots: replay the block's pivots on the row's word (the multiplier of pivot l is the bit at
 // its column when its turn comes, and stays there); pivot rows already hold their final word.
-// Mc[i - rank]: a row's multipliers in the low `rank` bits; Lc[t]: the same for pivot row t (bits j < t).
+// Lc[t]: pivot row t's multipliers (bits j < t) -- the unit lower triangle L of the block.  The rows below would be
+// updated with M * U, U = L^-1 U* the pivot rows after their own solve; written as (M L^-1) * U* the update can read
+// the pivot rows as they are, and their solve leaves the critical path (it runs on a side stream, ple_blocks).  So
+// Mc[i - rank] = the row's multipliers times L^-1: every workgroup rebuilds L from the pivot rows' slice words and
+// inverts it in its first wave (a lane per column, substitution, rows assembled by ballots).
 __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
                                                                 const word *__restrict__ V, const PleBlock *__restrict__ blk,
                                                                 word *__restrict__ Mc, word *__restrict__ Lc) {
+  __shared__ word s_L[64], s_Linv[64];
   const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;  // V index
+  const int rank  = blk->rank;
+  if (threadIdx.x < 64) {
+    const int t = threadIdx.x;
+    word lc = 0;
+    if (t < rank) {
+      const word pv = V[t];
+      for (int j = 0; j < t; ++j) lc |= ((pv >> blk->pivcol[j]) & 1) << j;
+    }
+    s_L[t] = lc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x;
+    word x = 0;  // column j of L^-1
+    for (int t = 0; t < rank; ++t) x |= (word)((__popcll(s_L[t] & x) & 1) ^ (t == j ? 1 : 0)) << t;
+    for (int t = 0; t < rank; ++t) {
+      const word row = __ballot((x >> t) & 1);
+      if (j == t) s_Linv[t] = row;
+    }
+  }
+  __syncthreads();
   if (i >= nrows - r0) return;
-  const int rank = blk->rank;
   word v = V[i];
   if (i >= rank)
     for (int l = 0; l < rank; ++l)
@@ -190,8 +299,14 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
   word m = 0;
   const int lim = i < rank ? (int)i : rank;
   for (int t = 0; t < lim; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
-  if (i >= rank) Mc[i - rank] = m;
-  else Lc[i] = m;
+  if (i >= rank) {
+    word mt = 0;
+    for (int t = 0; t < rank; ++t)
+      if ((m >> t) & 1) mt ^= s_Linv[t];
+    Mc[i - rank] = mt;
+  } else {
+    Lc[i] = m;
+  }
 }
 
 // ---- 3. rows below, words to the right: C ^= M * U, inner dimension <= 64 -----------------------------------------------
@@ -397,6 +512,9 @@ struct Scratch {
   PleBlock *blk = nullptr;
   PleBlock *hblk = nullptr;  // pinned host mirror
   int *lastrow = nullptr, *hlastrow = nullptr;
+  int64_t lc_blocks = 0;          // Lc holds 64 words per 64-column block of the matrix (a block's triangle is read later, on the side stream)
+  hipStream_t side = nullptr;     // the pivot rows' own solves run here, off the critical path
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
   int64_t rows = 0, cols = 0;
 };
 std::mutex g_ple_mu;
@@ -406,7 +524,9 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
   if (!s.blk) {
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.blk), sizeof(PleBlock)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hblk), sizeof(PleBlock), hipHostMallocDefault));
-    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Lc), 64 * 8));
+    HIPTRY(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+    HIPTRY(hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&s.ev_side, hipEventDisableTiming));
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.lastrow), sizeof(int)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hlastrow), sizeof(int), hipHostMallocDefault));
   }
@@ -416,6 +536,12 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.V), (size_t)nrows * 8));
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Mc), (size_t)nrows * 8));
     s.rows = nrows;
+  }
+  if (words_of(ncols) > s.lc_blocks) {
+    if (s.Lc) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.Lc)); }
+    s.Lc = nullptr; s.lc_blocks = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Lc), (size_t)words_of(ncols) * 64 * 8));
+    s.lc_blocks = words_of(ncols);
   }
   if (ncols > s.cols) {
     if (s.Q) { HIPTRY(hipFree(s.Q)); HIPTRY(hipFree(s.pivmask)); }
@@ -436,6 +562,7 @@ struct PleRun {
   Scratch *s;
   int64_t r0;      // rows finished so far = pivots found so far
   int64_t cutoff;  // __M4RI_PLE_CUTOFF of the reference build being matched (words); 0: no recursion
+  bool side_used = false;
 };
 
 // Columns [c0, c1) (c0 on a word boundary) in blocks of 64: the t-th pivot found goes to Q[c0 + t].
@@ -450,23 +577,29 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
     const int64_t nleft = nrows - r0;
     hipLaunchKernelGGL(ple_extract_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
                        s.V);
-    hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
+    static const bool wave_first = !(getenv("M4RI_AMD_PLE_WAVE") && atoi(getenv("M4RI_AMD_PLE_WAVE")) == 0);
+    if (wave_first) hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, s.V, s.blk);
+    else hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
     HIPTRY(hipGetLastError());
     HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
     HIPTRY(hipStreamSynchronize(st));
+    if (s.hblk->rank < 0) {  // a pivot further than 64 rows down: the general search, from the untouched slice
+      hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
+      HIPTRY(hipGetLastError());
+      HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
+      HIPTRY(hipStreamSynchronize(st));
+    }
     const int rank = s.hblk->rank;
     if (rank == 0) continue;  // nothing moved: the slice words are unchanged
     const int64_t below = nrows - r0 - rank;
     hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
                        r0, s.blk);
+    word *Lc = s.Lc + wb * 64;
     hipLaunchKernelGGL(ple_finish_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
-                       s.V, s.blk, s.Mc, s.Lc);
+                       s.V, s.blk, s.Mc, Lc);
     HIPTRY(hipGetLastError());
     if (wb + 1 < width) {
-      // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular
-      // solve with the <= 64 x 64 triangle of their multipliers
-      HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, st));
-      if (below > 0) {  // rows below, words to the right: C ^= M * U, inner dimension = the block's rank
+      if (below > 0) {  // rows below, words to the right: C ^= (M L^-1) * U*, inner dimension = the block's rank, U* the pivot rows as they are
         const bool vec      = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
         const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
         const int64_t wn     = width - wfirst;
@@ -476,6 +609,13 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
         else HIPTRY(launch_rank_update<false>(st, variant, A + (r0 + rank) * stride + wfirst, stride, s.Mc, A + r0 * stride + wfirst, stride, below, wn, rank, skip));
         HIPTRY(hipGetLastError());
       }
+      // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular solve
+      // with the <= 64 x 64 triangle of their multipliers -- after the update has read them, on the side stream: nothing
+      // later in the factorisation looks at these rows again
+      HIPTRY(hipEventRecord(s.ev_main, st));
+      HIPTRY(hipStreamWaitEvent(s.side, s.ev_main, 0));
+      HIPTRY(m4ri_amd_trsm_lower_left_dev(Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, s.side));
+      R.side_used = true;
     }
     for (int t = 0; t < rank; ++t) {
       R.P[r0 + t]                = s.hblk->swaprow[t];
@@ -565,7 +705,12 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
   const int64_t width = words_of(ncols);
   PleRun run{A, stride, nrows, ncols, width, P, Q, st, &s, 0, recursion_cutoff};
   int64_t found = 0;
-  if (int rc = recursion_cutoff ? ple_rec(run, nrows, 0, ncols, &found) : ple_blocks(run, 0, ncols, &found)) return rc;
+  const int rc_f = recursion_cutoff ? ple_rec(run, nrows, 0, ncols, &found) : ple_blocks(run, 0, ncols, &found);
+  if (run.side_used) {  // the pivot rows' solves join here, also on an error path: the side stream works on the caller's matrix
+    HIPTRY(hipEventRecord(s.ev_side, s.side));
+    HIPTRY(hipStreamWaitEvent(st, s.ev_side, 0));
+  }
+  if (rc_f) return rc_f;
   const int rank = (int)run.r0;
   *rank_out      = rank;
   if (rank > 0) {
