@@ -23,6 +23,18 @@ CASES = {
     # brilliantrussian.c:1003-1004, :1008-1009
     "m4rm_inner_mismatch": ("m4ri_amd.mzd_mul_m4rm(None, Mzd.init(4, 5), Mzd.init(6, 7), 0)", "mzd_mul_m4rm: A ncols (5) need to match B nrows (6)"),
     "m4rm_wrong_c": ("m4ri_amd.mzd_mul_m4rm(Mzd.init(5, 7), Mzd.init(4, 5), Mzd.init(5, 7), 0)", "mzd_mul_m4rm: C (5 x 7) has wrong dimensions"),
+    # triangular.c:396-404, :41-50
+    "trsm_lower_left_mismatch": ("m4ri_amd.mzd_trsm_lower_left(Mzd.init(5, 5), Mzd.init(6, 7))", "mzd_trsm_lower_left: L ncols (5) need to match B nrows (6)"),
+    "trsm_upper_right_not_square": ("m4ri_amd.lib().mzd_trsm_upper_right(Mzd.init(7, 6).ptr, Mzd.init(5, 7).ptr, 0)", "mzd_trsm_upper_right: U must be square"),
+    # ple.c:33-48
+    "ple_p_length": ("import ctypes, numpy as np\nA = Mzd.init(4, 5)\nmp, mq = m4ri_amd.Mzp(), m4ri_amd.Mzp()\n"
+                     "p, q = np.zeros(3, dtype=np.int32), np.zeros(5, dtype=np.int32)\n"
+                     "mp.values, mp.length = p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 3\nmq.values, mq.length = q.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 5\n"
+                     "m4ri_amd.lib().mzd_pluq(A.ptr, ctypes.byref(mp), ctypes.byref(mq), 0)", "mzd_pluq: Permutation P length (3) must match A nrows (4)"),
+    # solve.c:30-38
+    "solve_left_b_rows": ("m4ri_amd.mzd_solve_left(Mzd.init(4, 6), Mzd.init(5, 3))", "mzd_solve_left: A ncols (6) must be smaller than B nrows (5)"),
+    "solve_left_b_rows_max": ("m4ri_amd.mzd_solve_left(Mzd.init(6, 4), Mzd.init(5, 3))", "mzd_solve_left: B nrows (5) must be equal to max of A nrows (6) and A ncols (4)"),
+    "inv_not_square": ("m4ri_amd.mzd_inv_m4ri(Mzd.init(4, 5))", "mzd_inv_m4ri: A must be square"),
 }
 
 
