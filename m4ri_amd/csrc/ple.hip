@@ -317,7 +317,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
 // lanes per row, 16 bytes each, sixteen ds_read_b128 lookups per chunk (the reference's _mzd_process_rows_ple_N
 // does the same with seven 8-bit tables per 56 columns, ple_russian_template.h).
 #ifndef RU_UNR
-#define RU_UNR 4
+#define RU_UNR 8  // rows in flight per lane: 2 / 4 / 8 / 12 / 16 -> 115.6 / 107.0 / 99.1 / 110.0 / 147.8 ms over the 1023 launches of a 65536^2 PLE
+#endif
+#ifndef RU_NT
+#define RU_NT 0  // bit 0: nontemporal loads of the streamed rows, bit 1: nontemporal stores (measured: tools/prof_rank_update_variants.sh)
 #endif
 constexpr int RU_ROWS_DEFAULT = 2048, RU_DEFAULT_TW = 32;
 typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
@@ -367,7 +370,11 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
       if (r < r_hi) {
         m[u]          = M[r];
         const word *cp = C + r * c_stride + w0 + 2 * lane;
+#if RU_NT & 1
+        if (VEC && two) { const word2 c = __builtin_nontemporal_load(reinterpret_cast<const word2 *>(cp)); x0[u] = c.x; x1[u] = c.y; }
+#else
         if (VEC && two) { const word2 c = *reinterpret_cast<const word2 *>(cp); x0[u] = c.x; x1[u] = c.y; }
+#endif
         else { x0[u] = cp[0]; x1[u] = two ? cp[1] : 0; }
       }
     }
@@ -385,7 +392,11 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
       const int64_t r = rb + (int64_t)u * RSTEP;
       if (r < r_hi) {
         word *cp = C + r * c_stride + w0 + 2 * lane;
+#if RU_NT & 2
+        if (VEC && two) { word2 c; c.x = x0[u]; c.y = x1[u]; __builtin_nontemporal_store(c, reinterpret_cast<word2 *>(cp)); }
+#else
         if (VEC && two) { word2 c; c.x = x0[u]; c.y = x1[u]; *reinterpret_cast<word2 *>(cp) = c; }
+#endif
         else { cp[0] = x0[u]; if (two) cp[1] = x1[u]; }
       }
     }
