@@ -160,12 +160,15 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   if (tid == 0) out->rank = rank;
 }
 
-// ---- 1'. the same search in ONE WAVE, for blocks whose pivots all sit within 64 rows of the rank position --------------
+// ---- 1'. the same search in ONE WAVE, for blocks whose pivots all sit within the first 128 rows ---------------------
 // The general kernel above spends ~1 us per column on workgroup barriers and LDS hand-offs (60 us per block whatever the
-// matrix).  With a window of 64 rows the hand-offs are lane reads: the pivot lane is the lowest set bit of a ballot, its
-// word comes by v_readlane, the window moves by a lane shift, pivot l's column and tail live in lane l.  Same rule, same
-// outputs.  When a column has no pivot inside the window while rows lie beyond it, the kernel gives up without having
-// touched V (rank = -1) and the host runs the general kernel on the block instead.
+// matrix).  Here lane t keeps the rows at positions t and 64 + t in registers -- the word reduced by the pivots so far, and
+// the original word that goes back to V -- every candidate is reduced at every step (two XORs per lane), the pivot is the
+// lowest set bit of a ballot over the low rows or else the high ones, its word comes by v_readlane, the row it displaces
+// is handed over by v_readlane too, and pivot l's column and tail live in lane l: no LDS, no barrier, no lane shift.
+// Same rule, same outputs.  With r pivots found there are 128 - r >= 64 candidates left, so a column that has a pivot
+// further down misses here with probability 2^-64 for generic input; sparse and structured inputs do miss: then the kernel
+// gives up before writing anything (rank = -1) and the host runs the general kernel on the block.
 __device__ __forceinline__ word wave_read(word x, int lane) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
@@ -173,66 +176,42 @@ __device__ __forceinline__ word wave_read(word x, int lane) {
 }
 
 __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
-  __shared__ word s_head[128];  // the original words of the first 128 rows, kept in step with the swaps
-  const int tid   = threadIdx.x;
-  const int nhead = (int)(n < 128 ? n : 128);
-  s_head[tid]      = tid < nhead ? V[tid] : 0;
-  s_head[tid + 64] = tid + 64 < nhead ? V[tid + 64] : 0;
-  __syncthreads();
-  word v  = s_head[tid];
-  int cnt = 0, rank = 0;
-  word ph = 0;            // lane l: pivot l from the column after its pivot column on
-  int pc = 0, psw = 0;    // lane l: pivot l's column, and the row (relative to r0) that was swapped up for it
-  for (int c = 0; c < ncb && rank < n; ++c) {
-    const bool valid = (int64_t)rank + tid < n;
-    unsigned long long b = __ballot(valid && cnt == rank && ((v >> c) & 1));
-    if (!b) {
-      if (__ballot(valid && cnt < rank)) {  // the rows that entered the window since catch up with the pivots found meanwhile
-        for (int l = 0; l < rank; ++l) {
-          const word hl = wave_read(ph, l);
-          const int cl  = __builtin_amdgcn_readlane(pc, l);
-          if (valid && l >= cnt && ((v >> cl) & 1)) v ^= hl;
-        }
-        if (valid && cnt < rank) cnt = rank;
-        b = __ballot(valid && cnt == rank && ((v >> c) & 1));
-      }
-      if (!b) {
-        if ((int64_t)rank + 64 < n) {  // candidates beyond the window: not this kernel's case
+  const int tid = threadIdx.x;
+  const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
+  word o_lo = has_lo ? V[tid] : 0, o_hi = has_hi ? V[tid + 64] : 0;  // original words, in step with the swaps
+  word v_lo = o_lo, v_hi = o_hi;                                     // reduced by the pivots found so far
+  word ph = 0;          // lane l: pivot l from the column after its pivot column on
+  int pc = 0, psw = 0;  // lane l: pivot l's column, and the position the pivot row was found at
+  int rank = 0;
+  for (int c = 0; c < ncb && rank < n && rank < 64; ++c) {
+    const unsigned long long b_lo = __ballot(has_lo && tid >= rank && ((v_lo >> c) & 1));
+    unsigned long long b_hi = 0;
+    if (!b_lo) {
+      b_hi = __ballot(has_hi && ((v_hi >> c) & 1));
+      if (!b_hi) {
+        if (n > 128) {  // candidates beyond the 128 rows held here: not this kernel's case
           if (tid == 0) out->rank = -1;
           return;
         }
         continue;  // no pivot in this column
       }
     }
-    const int pl  = (int)__builtin_ctzll(b);  // lane of the pivot row; its position is rank + pl
-    const word vp = wave_read(v, pl);
-    const word high = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
-    if (tid == 0) {
-      const word vr = s_head[rank];
-      s_head[rank + pl] = vr;  // the displaced row keeps its original word
-      s_head[rank]      = vp;  // the pivot row's word is final
+    const bool from_hi = b_lo == 0;
+    const int pl       = (int)__builtin_ctzll(from_hi ? b_hi : b_lo);
+    const word vp      = from_hi ? wave_read(v_hi, pl) : wave_read(v_lo, pl);  // the pivot row's word: final
+    const word red_r   = wave_read(v_lo, rank), org_r = wave_read(o_lo, rank);  // the row at the rank position: it is displaced
+    const word high    = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
+    if (tid == pl) {  // the displaced row takes the pivot row's place (pl == rank in the low half: overwritten just below)
+      if (from_hi) { v_hi = red_r; o_hi = org_r; }
+      else { v_lo = red_r; o_lo = org_r; }
     }
-    if (tid == rank) { ph = high; pc = c; psw = rank + pl; }
-    __syncthreads();
-    if (cnt == rank) {
-      if (tid != pl && ((v >> c) & 1)) v ^= high;
-      cnt = rank + 1;
-    }
-    // the row the pivot displaced (lane 0's) sits where the pivot was; then the window moves one lane to the left and the
-    // next row enters at the top, with no pivot applied yet
-    const word v0 = wave_read(v, 0);
-    const int c0  = __builtin_amdgcn_readlane(cnt, 0);
-    if (tid == pl && pl > 0) { v = v0; cnt = c0; }
-    const int64_t enter = (int64_t)rank + 1 + 63;
-    word vn = __shfl_down(v, 1);
-    int cn  = __shfl_down(cnt, 1);
-    if (tid == 63) { vn = enter < nhead ? s_head[enter] : 0; cn = 0; }
-    v = vn; cnt = cn;
+    if (tid == rank) { o_lo = vp; ph = high; pc = c; psw = pl + (from_hi ? 64 : 0); }
+    if (tid > rank && ((v_lo >> c) & 1)) v_lo ^= high;
+    if ((v_hi >> c) & 1) v_hi ^= high;
     ++rank;
   }
-  __syncthreads();
-  if (tid < nhead) V[tid] = s_head[tid];
-  if (tid + 64 < nhead) V[tid + 64] = s_head[tid + 64];
+  if (has_lo) V[tid] = o_lo;
+  if (has_hi) V[tid + 64] = o_hi;
   if (tid < rank) {
     out->pivcol[tid]  = pc;
     out->swaprow[tid] = (int32_t)(r0 + psw);
