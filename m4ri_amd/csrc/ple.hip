@@ -52,6 +52,8 @@ struct PleBlock {
   int32_t pivcol[64];   // column of pivot t inside the block
   int32_t swaprow[64];  // absolute row that was swapped into position r0 + t
   word vhigh[64];       // pivot t's slice word from the column after its pivot column on
+  word Lc[64];          // pivot row t's multipliers (bits j < t): the block's unit lower triangle L
+  word Linv[64];        // row t of L^-1 (block_triangle below)
 };
 
 // ---- 0. the block's word of every remaining row -> dense vector -------------------------------------------------
@@ -59,6 +61,35 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_extract_kernel(const word *__
                                                                  word *__restrict__ V) {
   const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
   if (i < nrows - r0) V[i] = A[(r0 + i) * stride + wb];
+}
+
+// The block's 64 x 64 unit triangle L and its inverse, by one wave at the end of a pivot search: lane t brings pivot row
+// t's final slice word and pivot t's column.  Lc[t] = the row's multipliers (its bits at the columns of the pivots before
+// it); L^-1 by substitution, a lane per column, rows assembled by ballots.  The rows below are updated with (M L^-1) U*
+// instead of M U (ple_finish_kernel), so the pivot rows' own solve U = L^-1 U* leaves the critical path.
+__device__ __forceinline__ word wave_read64(word x, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+  return ((word)hi << 32) | lo;
+}
+__device__ __forceinline__ void block_triangle(int tid, word my_word, int my_col, int rank, PleBlock *__restrict__ out) {
+  word lc = 0;
+  for (int j = 0; j < rank; ++j) {
+    const int cj = __builtin_amdgcn_readlane(my_col, j);
+    if (j < tid && tid < rank) lc |= ((my_word >> cj) & 1) << j;
+  }
+  word x = 0;  // column tid of L^-1
+  for (int t = 0; t < rank; ++t) {
+    const word lt = wave_read64(lc, t);
+    x |= (word)((__popcll(lt & x) & 1) ^ (t == tid ? 1 : 0)) << t;
+  }
+  word mine = 0;
+  for (int t = 0; t < rank; ++t) {
+    const word row = __ballot((x >> t) & 1);
+    if (tid == t) mine = row;
+  }
+  out->Lc[tid]   = lc;
+  out->Linv[tid] = tid < rank ? mine : 0;
 }
 
 // ---- 1. the block's pivots (ONE workgroup) ---------------------------------------------------------------------------
@@ -157,6 +188,8 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
     }
     ++rank;
   }
+  __syncthreads();
+  if (tid < 64) block_triangle(tid, tid < rank ? s_head[tid] : 0, tid < rank ? s_col[tid] : 0, rank, out);
   if (tid == 0) out->rank = rank;
 }
 
@@ -169,12 +202,6 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
 // Same rule, same outputs.  With r pivots found there are 128 - r >= 64 candidates left, so a column that has a pivot
 // further down misses here with probability 2^-64 for generic input; sparse and structured inputs do miss: then the kernel
 // gives up before writing anything (rank = -1) and the host runs the general kernel on the block.
-__device__ __forceinline__ word wave_read(word x, int lane) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
-  return ((word)hi << 32) | lo;
-}
-
 __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
   const int tid = threadIdx.x;
   const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
@@ -198,8 +225,8 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     }
     const bool from_hi = b_lo == 0;
     const int pl       = (int)__builtin_ctzll(from_hi ? b_hi : b_lo);
-    const word vp      = from_hi ? wave_read(v_hi, pl) : wave_read(v_lo, pl);  // the pivot row's word: final
-    const word red_r   = wave_read(v_lo, rank), org_r = wave_read(o_lo, rank);  // the row at the rank position: it is displaced
+    const word vp      = from_hi ? wave_read64(v_hi, pl) : wave_read64(v_lo, pl);  // the pivot row's word: final
+    const word red_r   = wave_read64(v_lo, rank), org_r = wave_read64(o_lo, rank);  // the row at the rank position: it is displaced
     const word high    = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
     if (tid == pl) {  // the displaced row takes the pivot row's place (pl == rank in the low half: overwritten just below)
       if (from_hi) { v_hi = red_r; o_hi = org_r; }
@@ -212,6 +239,7 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
   }
   if (has_lo) V[tid] = o_lo;
   if (has_hi) V[tid + 64] = o_hi;
+  block_triangle(tid, o_lo, pc, rank, out);
   if (tid < rank) {
     out->pivcol[tid]  = pc;
     out->swaprow[tid] = (int32_t)(r0 + psw);
@@ -238,35 +266,19 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__rest
 // ---- 2b. the slice eliminated row by row (parallel), written back, multipliers gathered --------------------------------
 // rows below the pivots: replay the block's pivots on the row's word (the multiplier of pivot l is the bit at
 // its column when its turn comes, and stays there); pivot rows already hold their final word.
-// Lc[t]: pivot row t's multipliers (bits j < t) -- the unit lower triangle L of the block.  The rows below would be
-// updated with M * U, U = L^-1 U* the pivot rows after their own solve; written as (M L^-1) * U* the update can read
-// the pivot rows as they are, and their solve leaves the critical path (it runs on a side stream, ple_blocks).  So
-// Mc[i - rank] = the row's multipliers times L^-1: every workgroup rebuilds L from the pivot rows' slice words and
-// inverts it in its first wave (a lane per column, substitution, rows assembled by ballots).
+// The rows below would be updated with M * U, U = L^-1 U* the pivot rows after their own solve; written as
+// (M L^-1) * U* the update can read the pivot rows as they are, and their solve leaves the critical path (it runs on a
+// side stream, ple_blocks).  So Mc[i - rank] = the row's multipliers times L^-1, with L^-1 from the pivot search
+// (block_triangle); the block's triangle L itself is copied to Lc for that solve.
 __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
                                                                 const word *__restrict__ V, const PleBlock *__restrict__ blk,
                                                                 word *__restrict__ Mc, word *__restrict__ Lc) {
-  __shared__ word s_L[64], s_Linv[64];
+  __shared__ word s_Linv[64];
   const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;  // V index
   const int rank  = blk->rank;
   if (threadIdx.x < 64) {
-    const int t = threadIdx.x;
-    word lc = 0;
-    if (t < rank) {
-      const word pv = V[t];
-      for (int j = 0; j < t; ++j) lc |= ((pv >> blk->pivcol[j]) & 1) << j;
-    }
-    s_L[t] = lc;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int j = threadIdx.x;
-    word x = 0;  // column j of L^-1
-    for (int t = 0; t < rank; ++t) x |= (word)((__popcll(s_L[t] & x) & 1) ^ (t == j ? 1 : 0)) << t;
-    for (int t = 0; t < rank; ++t) {
-      const word row = __ballot((x >> t) & 1);
-      if (j == t) s_Linv[t] = row;
-    }
+    s_Linv[threadIdx.x] = blk->Linv[threadIdx.x];
+    if (blockIdx.x == 0) Lc[threadIdx.x] = blk->Lc[threadIdx.x];  // where the side stream's solve of the pivot rows reads it
   }
   __syncthreads();
   if (i >= nrows - r0) return;
@@ -283,8 +295,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
     for (int t = 0; t < rank; ++t)
       if ((m >> t) & 1) mt ^= s_Linv[t];
     Mc[i - rank] = mt;
-  } else {
-    Lc[i] = m;
   }
 }
 
