@@ -54,6 +54,8 @@ struct PleBlock {
   word vhigh[64];       // pivot t's slice word from the column after its pivot column on
   word Lc[64];          // pivot row t's multipliers (bits j < t): the block's unit lower triangle L
   word Linv[64];        // row t of L^-1 (block_triangle below)
+  int32_t nsrc;         // > 0: the block's row swaps as ONE permutation of the first nsrc rows (the one-wave search knows it) ...
+  int32_t src[128];     // ... position t takes the row that stood at position src[t]
 };
 
 // ---- 0. the block's word of every remaining row -> dense vector -------------------------------------------------
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   }
   __syncthreads();
   if (tid < 64) block_triangle(tid, tid < rank ? s_head[tid] : 0, tid < rank ? s_col[tid] : 0, rank, out);
-  if (tid == 0) out->rank = rank;
+  if (tid == 0) { out->rank = rank; out->nsrc = 0; }
 }
 
 // ---- 1'. the same search in ONE WAVE, for blocks whose pivots all sit within the first 128 rows ---------------------
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
   const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
   word o_lo = has_lo ? V[tid] : 0, o_hi = has_hi ? V[tid + 64] : 0;  // original words, in step with the swaps
   word v_lo = o_lo, v_hi = o_hi;                                     // reduced by the pivots found so far
+  int i_lo = tid, i_hi = tid + 64;                                   // where the row in this slot stood at the start
   word ph = 0;          // lane l: pivot l from the column after its pivot column on
   int pc = 0, psw = 0;  // lane l: pivot l's column, and the position the pivot row was found at
   int rank = 0;
@@ -227,12 +230,14 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     const int pl       = (int)__builtin_ctzll(from_hi ? b_hi : b_lo);
     const word vp      = from_hi ? wave_read64(v_hi, pl) : wave_read64(v_lo, pl);  // the pivot row's word: final
     const word red_r   = wave_read64(v_lo, rank), org_r = wave_read64(o_lo, rank);  // the row at the rank position: it is displaced
+    const int idx_r    = __builtin_amdgcn_readlane(i_lo, rank);
+    const int idx_p    = from_hi ? __builtin_amdgcn_readlane(i_hi, pl) : __builtin_amdgcn_readlane(i_lo, pl);
     const word high    = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
     if (tid == pl) {  // the displaced row takes the pivot row's place (pl == rank in the low half: overwritten just below)
-      if (from_hi) { v_hi = red_r; o_hi = org_r; }
-      else { v_lo = red_r; o_lo = org_r; }
+      if (from_hi) { v_hi = red_r; o_hi = org_r; i_hi = idx_r; }
+      else { v_lo = red_r; o_lo = org_r; i_lo = idx_r; }
     }
-    if (tid == rank) { o_lo = vp; ph = high; pc = c; psw = pl + (from_hi ? 64 : 0); }
+    if (tid == rank) { o_lo = vp; i_lo = idx_p; ph = high; pc = c; psw = pl + (from_hi ? 64 : 0); }
     if (tid > rank && ((v_lo >> c) & 1)) v_lo ^= high;
     if ((v_hi >> c) & 1) v_hi ^= high;
     ++rank;
@@ -240,6 +245,9 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
   if (has_lo) V[tid] = o_lo;
   if (has_hi) V[tid + 64] = o_hi;
   block_triangle(tid, o_lo, pc, rank, out);
+  out->src[tid]      = i_lo;
+  out->src[tid + 64] = i_hi;
+  if (tid == 0) out->nsrc = (int32_t)(n < 128 ? n : 128);
   if (tid < rank) {
     out->pivcol[tid]  = pc;
     out->swaprow[tid] = (int32_t)(r0 + psw);
@@ -260,6 +268,28 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_swap_rows_kernel(word *__rest
     const word x = A[a * stride + w], y = A[b * stride + w];
     A[a * stride + w] = y;
     A[b * stride + w] = x;
+  }
+}
+
+// The same swaps as one permutation of the first <= 128 rows (what the one-wave search hands over): a workgroup per tile of
+// PERM_TW word columns, the moved rows through LDS -- all loads, then all stores, instead of up to 64 dependent exchanges.
+constexpr int PERM_TW = 32;
+__global__ __launch_bounds__(ROW_THREADS) void ple_permute_rows_kernel(word *__restrict__ A, int64_t stride, int64_t width, int64_t wb, int64_t r0,
+                                                                      const PleBlock *__restrict__ blk) {
+  __shared__ word tile[128][PERM_TW];
+  __shared__ int s_src[128];
+  const int n = blk->nsrc;
+  if (threadIdx.x < 128) s_src[threadIdx.x] = threadIdx.x < n ? blk->src[threadIdx.x] : (int)threadIdx.x;
+  __syncthreads();
+  const int64_t w0 = (int64_t)blockIdx.x * PERM_TW;
+  for (int e = threadIdx.x; e < n * PERM_TW; e += ROW_THREADS) {
+    const int t = e / PERM_TW, w = e % PERM_TW;
+    if (s_src[t] != t && w0 + w < width && w0 + w != wb) tile[t][w] = A[(r0 + s_src[t]) * stride + w0 + w];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * PERM_TW; e += ROW_THREADS) {
+    const int t = e / PERM_TW, w = e % PERM_TW;
+    if (s_src[t] != t && w0 + w < width && w0 + w != wb) A[(r0 + t) * stride + w0 + w] = tile[t][w];
   }
 }
 
@@ -592,8 +622,11 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
     const int rank = s.hblk->rank;
     if (rank == 0) continue;  // nothing moved: the slice words are unchanged
     const int64_t below = nrows - r0 - rank;
-    hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
-                       r0, s.blk);
+    if (s.hblk->nsrc > 0)
+      hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0, s.blk);
+    else
+      hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
+                         r0, s.blk);
     word *Lc = s.Lc + wb * 64;
     hipLaunchKernelGGL(ple_finish_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
                        s.V, s.blk, s.Mc, Lc);
