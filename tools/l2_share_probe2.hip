@@ -8,6 +8,8 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
+// BUFLOAD: the loads go through a raw buffer descriptor, as in the leaf
+template <bool BUFLOAD>
 __global__ __launch_bounds__(512) void probe(const unsigned char *buf, int chunks, int chunk_stride, int readers, int gap_ticks, int step_ticks,
                                              uint32_t *out) {
   __shared__ unsigned char big[128 * 1024];
@@ -19,7 +21,13 @@ __global__ __launch_bounds__(512) void probe(const unsigned char *buf, int chunk
     const uint64_t s0 = __builtin_amdgcn_s_memrealtime();
     for (int g = 0; g < 8; ++g) {
       const uint64_t g0 = __builtin_amdgcn_s_memrealtime();
-      const uint4 v = *reinterpret_cast<const uint4 *>(buf + (size_t)q * chunk_stride + rgrp * 128 + g * 16);
+      uint4 v;
+      if (BUFLOAD) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(buf), (short)0, chunks * chunk_stride, 0x00020000);
+        v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((size_t)q * chunk_stride + rgrp * 128 + g * 16), 0, 0));
+      } else {
+        v = *reinterpret_cast<const uint4 *>(buf + (size_t)q * chunk_stride + rgrp * 128 + g * 16);
+      }
       acc ^= v.x ^ v.y ^ v.z ^ v.w;
       while (__builtin_amdgcn_s_memrealtime() - g0 < (uint64_t)gap_ticks) __builtin_amdgcn_s_sleep(1);
     }
@@ -31,12 +39,15 @@ __global__ __launch_bounds__(512) void probe(const unsigned char *buf, int chunk
 int main(int argc, char **argv) {
   const int readers = argc > 1 ? atoi(argv[1]) : 16, gap_ns = argc > 2 ? atoi(argv[2]) : 800, step_ns = argc > 3 ? atoi(argv[3]) : 6400;
   const int chunk_stride = argc > 4 ? atoi(argv[4]) : 32768;
+  const int bufload = argc > 5 ? atoi(argv[5]) : 0;
   const int chunks = 2048;
   unsigned char *buf; uint32_t *out;
   CK(hipMalloc(&buf, (size_t)chunks * chunk_stride)); CK(hipMalloc(&out, 256 * 512 * 4));
   CK(hipMemset(buf, 1, (size_t)chunks * chunk_stride)); CK(hipDeviceSynchronize());
-  hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, 0, buf, chunks, chunk_stride, readers, gap_ns / 10, step_ns / 10, out);
+  if (bufload) hipLaunchKernelGGL(probe<true>, dim3(256), dim3(512), 0, 0, buf, chunks, chunk_stride, readers, gap_ns / 10, step_ns / 10, out);
+  else hipLaunchKernelGGL(probe<false>, dim3(256), dim3(512), 0, 0, buf, chunks, chunk_stride, readers, gap_ns / 10, step_ns / 10, out);
   CK(hipDeviceSynchronize());
-  printf("readers %d gap %d ns step %d ns chunk stride %d: %d lines of 128 B read\n", readers, gap_ns, step_ns, chunk_stride, chunks * 128);
+  printf("readers %d gap %d ns step %d ns chunk stride %d %s: %d lines of 128 B read\n", readers, gap_ns, step_ns, chunk_stride,
+         bufload ? "buffer loads" : "global loads", chunks * 128);
   return 0;
 }
