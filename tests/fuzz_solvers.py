@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fuzz of the decomposition / echelon routines against the oracle on random shapes and structures (developer tool, GPU
-box): PLE and PLUQ in both flavours (identity or the reference's recursion leftovers behind the rank), both echelon
+"""Fuzz of the decomposition / echelon routines against the oracle on random shapes and structures (a script, not a
+pytest module; it lives under tests/ because it runs the checker; GPU box): PLE and PLUQ in both flavours (identity or the reference's recursion leftovers behind the rank), both echelon
 forms, the column permutations, left and right triangular solves.  usage: fuzz_solvers.py [seconds] [seed]"""
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 
 import m4ri_amd  # noqa: E402
