@@ -325,7 +325,7 @@ int m4ri_amd_set_max_fuse(int levels);
 
 /* The M4RI-named products pipeline a large product from host memory over four row slabs of A and C (upload of
    slab k+1 and download of slab k-1 under product k; same bits).  min_bytes: size of A + B + C from which that
-   happens (default 256 MiB; 0 = never).  Returns the previous value; negative arguments only query. */
+   happens (default 64 MiB; 0 = never).  Returns the previous value; negative arguments only query. */
 int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes);
 
 /* Release the engine's workspace (device memory pool) and the host entry points' staging arena;

@@ -11,6 +11,8 @@ from m4ri_amd.mzd import Mzd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 m4ri_amd.init(0)
+if len(sys.argv) > 2:  # second argument: the pipeline's size threshold in MiB (0 = off)
+    m4ri_amd.set_host_pipeline(int(sys.argv[2]) << 20)
 A, B = Mzd.random(n, n, 3), Mzd.random(n, n, 4)
 C = Mzd.init(n, n)
 m4ri_amd.mzd_mul(C, A, B, 0)
