@@ -207,44 +207,60 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
 __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
   const int tid = threadIdx.x;
   const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
-  word o_lo = has_lo ? V[tid] : 0, o_hi = has_hi ? V[tid + 64] : 0;  // original words, in step with the swaps
-  word v_lo = o_lo, v_hi = o_hi;                                     // reduced by the pivots found so far
-  int i_lo = tid, i_hi = tid + 64;                                   // where the row in this slot stood at the start
-  word ph = 0;          // lane l: pivot l from the column after its pivot column on
-  int pc = 0, psw = 0;  // lane l: pivot l's column, and the position the pivot row was found at
+  const word org_lo = has_lo ? V[tid] : 0, org_hi = has_hi ? V[tid + 64] : 0;  // the slice words as they stand
+  word v_lo = org_lo, v_hi = org_hi;  // the rows in this lane's two slots, reduced by the pivots found so far
+  int i_lo = tid, i_hi = tid + 64;    // where the row in each slot stood at the start
+  word pv = 0, ph = 0;                // lane l: pivot row l's final word, and the part of it behind its pivot column
+  int pc = 0, psw = 0;                // lane l: pivot l's column, and the position the pivot row was found at
   int rank = 0;
-  for (int c = 0; c < ncb && rank < n && rank < 64; ++c) {
-    const unsigned long long b_lo = __ballot(has_lo && tid >= rank && ((v_lo >> c) & 1));
-    unsigned long long b_hi = 0;
-    if (!b_lo) {
-      b_hi = __ballot(has_hi && ((v_hi >> c) & 1));
-      if (!b_hi) {
-        if (n > 128) {  // candidates beyond the 128 rows held here: not this kernel's case
-          if (tid == 0) out->rank = -1;
-          return;
-        }
-        continue;  // no pivot in this column
+  const int cols = ncb < 64 ? ncb : 64;
+  for (int c = 0; c < cols && rank < n; ++c) {
+    const unsigned long long b_lo = __ballot(tid >= rank && ((v_lo >> c) & 1));  // slots without a row hold 0
+    if (__builtin_expect(b_lo != 0, 1)) {
+      const int pl     = (int)__builtin_ctzll(b_lo);
+      const word vp    = wave_read64(v_lo, pl);    // the pivot row's word: final
+      const word red_r = wave_read64(v_lo, rank);  // the row at the rank position: the pivot row displaces it
+      const int idx_r  = __builtin_amdgcn_readlane(i_lo, rank), idx_p = __builtin_amdgcn_readlane(i_lo, pl);
+      const word high  = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
+      if (tid == pl) { v_lo = red_r; i_lo = idx_r; }
+      if (tid == rank) { pv = vp; ph = high; pc = c; psw = pl; i_lo = idx_p; }
+      if (tid > rank && ((v_lo >> c) & 1)) v_lo ^= high;
+      if ((v_hi >> c) & 1) v_hi ^= high;
+      ++rank;
+      continue;
+    }
+    const unsigned long long b_hi = __ballot((v_hi >> c) & 1);
+    if (!b_hi) {
+      if (n > 128) {  // candidates beyond the 128 rows held here: not this kernel's case
+        if (tid == 0) out->rank = -1;
+        return;
       }
+      continue;  // no pivot in this column
     }
-    const bool from_hi = b_lo == 0;
-    const int pl       = (int)__builtin_ctzll(from_hi ? b_hi : b_lo);
-    const word vp      = from_hi ? wave_read64(v_hi, pl) : wave_read64(v_lo, pl);  // the pivot row's word: final
-    const word red_r   = wave_read64(v_lo, rank), org_r = wave_read64(o_lo, rank);  // the row at the rank position: it is displaced
-    const int idx_r    = __builtin_amdgcn_readlane(i_lo, rank);
-    const int idx_p    = from_hi ? __builtin_amdgcn_readlane(i_hi, pl) : __builtin_amdgcn_readlane(i_lo, pl);
-    const word high    = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
-    if (tid == pl) {  // the displaced row takes the pivot row's place (pl == rank in the low half: overwritten just below)
-      if (from_hi) { v_hi = red_r; o_hi = org_r; i_hi = idx_r; }
-      else { v_lo = red_r; o_lo = org_r; i_lo = idx_r; }
+    {  // the pivot sits in a high slot (rare)
+      const int pl     = (int)__builtin_ctzll(b_hi);
+      const word vp    = wave_read64(v_hi, pl);
+      const word red_r = wave_read64(v_lo, rank);
+      const int idx_r  = __builtin_amdgcn_readlane(i_lo, rank), idx_p = __builtin_amdgcn_readlane(i_hi, pl);
+      const word high  = c < 63 ? (vp & (~(word)0 << (c + 1))) : 0;
+      if (tid == pl) { v_hi = red_r; i_hi = idx_r; }
+      if (tid == rank) { pv = vp; ph = high; pc = c; psw = pl + 64; i_lo = idx_p; }
+      if (tid > rank && ((v_lo >> c) & 1)) v_lo ^= high;
+      if ((v_hi >> c) & 1) v_hi ^= high;
+      ++rank;
     }
-    if (tid == rank) { o_lo = vp; i_lo = idx_p; ph = high; pc = c; psw = pl + (from_hi ? 64 : 0); }
-    if (tid > rank && ((v_lo >> c) & 1)) v_lo ^= high;
-    if ((v_hi >> c) & 1) v_hi ^= high;
-    ++rank;
   }
-  if (has_lo) V[tid] = o_lo;
-  if (has_hi) V[tid + 64] = o_hi;
-  block_triangle(tid, o_lo, pc, rank, out);
+  // the slice words go back in their new order: pivot rows final, every other row with its ORIGINAL word (the parallel
+  // pass afterwards replays the pivots on those) -- gathered from where the rows stood at the start
+  {
+    const word a = __shfl(org_lo, i_lo & 63), b2 = __shfl(org_hi, i_lo & 63);
+    const word lo_out = tid < rank ? pv : (i_lo < 64 ? a : b2);
+    const word c2 = __shfl(org_lo, i_hi & 63), d = __shfl(org_hi, i_hi & 63);
+    const word hi_out = i_hi < 64 ? c2 : d;
+    if (has_lo) V[tid] = lo_out;
+    if (has_hi) V[tid + 64] = hi_out;
+  }
+  block_triangle(tid, pv, pc, rank, out);
   out->src[tid]      = i_lo;
   out->src[tid + 64] = i_hi;
   if (tid == 0) out->nsrc = (int32_t)(n < 128 ? n : 128);
@@ -303,29 +319,30 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_permute_rows_kernel(word *__r
 __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
                                                                 const word *__restrict__ V, const PleBlock *__restrict__ blk,
                                                                 word *__restrict__ Mc, word *__restrict__ Lc) {
-  __shared__ word s_Linv[64];
+  __shared__ word s_Linv[64], s_high[64];
+  __shared__ int s_col[64];  // the block's record through LDS once: the loops below would otherwise wait for one scalar load per step
   const int64_t i = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;  // V index
   const int rank  = blk->rank;
   if (threadIdx.x < 64) {
     s_Linv[threadIdx.x] = blk->Linv[threadIdx.x];
+    s_high[threadIdx.x] = blk->vhigh[threadIdx.x];
+    s_col[threadIdx.x]  = blk->pivcol[threadIdx.x];
     if (blockIdx.x == 0) Lc[threadIdx.x] = blk->Lc[threadIdx.x];  // where the side stream's solve of the pivot rows reads it
   }
   __syncthreads();
   if (i >= nrows - r0) return;
   word v = V[i];
-  if (i >= rank)
-    for (int l = 0; l < rank; ++l)
-      if ((v >> blk->pivcol[l]) & 1) v ^= blk->vhigh[l];
-  A[(r0 + i) * stride + wb] = v;
-  word m = 0;
-  const int lim = i < rank ? (int)i : rank;
-  for (int t = 0; t < lim; ++t) m |= ((v >> blk->pivcol[t]) & 1) << t;
-  if (i >= rank) {
-    word mt = 0;
-    for (int t = 0; t < rank; ++t)
-      if ((m >> t) & 1) mt ^= s_Linv[t];
-    Mc[i - rank] = mt;
+  if (i < rank) { A[(r0 + i) * stride + wb] = v; return; }  // pivot rows already hold their final word
+  // replay the pivots; the multiplier of pivot l is the bit at its column when its turn comes (it stays there), and the
+  // row's multipliers times L^-1 are the XOR of the rows of L^-1 they select
+  word mt = 0;
+  for (int l = 0; l < rank; ++l) {
+    const bool on = (v >> s_col[l]) & 1;
+    v ^= on ? s_high[l] : 0;
+    mt ^= on ? s_Linv[l] : 0;
   }
+  A[(r0 + i) * stride + wb] = v;
+  Mc[i - rank] = mt;
 }
 
 // ---- 3. rows below, words to the right: C ^= M * U, inner dimension <= 64 -----------------------------------------------
