@@ -294,6 +294,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_permute_rows_kernel(word *__r
                                                                       const PleBlock *__restrict__ blk) {
   __shared__ word tile[128][PERM_TW];
   __shared__ int s_src[128];
+  if (blk->rank <= 0) return;  // nothing moved, or the search gave up (then nsrc is not this block's)
   const int n = blk->nsrc;
   if (threadIdx.x < 128) s_src[threadIdx.x] = threadIdx.x < n ? blk->src[threadIdx.x] : (int)threadIdx.x;
   __syncthreads();
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
     if (blockIdx.x == 0) Lc[threadIdx.x] = blk->Lc[threadIdx.x];  // where the side stream's solve of the pivot rows reads it
   }
   __syncthreads();
-  if (i >= nrows - r0) return;
+  if (rank <= 0 || i >= nrows - r0) return;  // no pivot (the slice words are unchanged) or a search that gave up (rank -1)
   word v = V[i];
   if (i < rank) { A[(r0 + i) * stride + wb] = v; return; }  // pivot rows already hold their final word
   // replay the pivots; the multiplier of pivot l is the bit at its column when its turn comes (it stays there), and the
@@ -366,8 +367,15 @@ typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
 template <bool VEC, int TW, int THREADS>
 __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restrict__ C, int64_t c_stride, const word *__restrict__ M,
                                                                   const word *__restrict__ U, int64_t u_stride, int64_t rows, int64_t wn,
-                                                                  int rank, int skip_below, int RU_ROWS) {
+                                                                  int rank, int skip_below, int RU_ROWS, const PleBlock *__restrict__ blk) {
   __shared__ __attribute__((aligned(16))) word tab[16][16][TW];  // [table][entry][word]
+  if (blk) {  // launched before the host knew the block's rank: C and rows arrive for rank 0, the record has the real one
+    rank = blk->rank;
+    if (rank <= 0) return;
+    C += (int64_t)rank * c_stride;
+    rows -= rank;
+    if (rows <= 0) return;
+  }
   const int tid      = threadIdx.x;
   const int64_t w0   = (int64_t)blockIdx.x * TW;
   const int64_t r_lo = (int64_t)blockIdx.y * RU_ROWS;
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
 
 template <bool VEC>
 hipError_t launch_rank_update(hipStream_t st, int variant, word *C, int64_t cs, const word *M, const word *U, int64_t us, int64_t rows, int64_t wn,
-                              int rank, int skip) {
+                              int rank, int skip, const PleBlock *blk = nullptr) {
   // rows per workgroup: about 2048 workgroups per launch (8 per CU), between 256 and 2048 rows in whole 128-row trips --
   // the trailing matrix shrinks from 1 GiB to nothing over a decomposition, and a fixed 2048 rows left the late
   // launches with a handful of workgroups (65536^2: 135 -> 110 ms over all 1023 launches); M4RI_AMD_RU_ROWS overrides
@@ -453,7 +461,7 @@ hipError_t launch_rank_update(hipStream_t st, int variant, word *C, int64_t cs, 
   const unsigned gy = (unsigned)((rows + RU_ROWS - 1) / RU_ROWS);
 #define RU_LAUNCH(TW, TH)                                                                                                              \
   hipLaunchKernelGGL((ple_rank_update_kernel<VEC, TW, TH>), dim3((unsigned)((wn + TW - 1) / TW), gy), dim3(TH), 0, st, C, cs, M, U, us, rows, wn, \
-                     rank, skip, RU_ROWS)
+                     rank, skip, RU_ROWS, blk)
   if (variant == 64) RU_LAUNCH(64, 1024);
   else if (variant == 32) RU_LAUNCH(32, 512);
   else RU_LAUNCH(16, 256);
@@ -561,7 +569,7 @@ struct Scratch {
   int *lastrow = nullptr, *hlastrow = nullptr;
   int64_t lc_blocks = 0;          // Lc holds 64 words per 64-column block of the matrix (a block's triangle is read later, on the side stream)
   hipStream_t side = nullptr;     // the pivot rows' own solves run here, off the critical path
-  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_copy = nullptr;
   int64_t rows = 0, cols = 0;
 };
 std::mutex g_ple_mu;
@@ -574,6 +582,7 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
     HIPTRY(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
     HIPTRY(hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming));
     HIPTRY(hipEventCreateWithFlags(&s.ev_side, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming));
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.lastrow), sizeof(int)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hlastrow), sizeof(int), hipHostMallocDefault));
   }
@@ -618,51 +627,68 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
   word *A = R.A;
   const int64_t stride = R.stride, nrows = R.nrows, ncols = R.ncols, width = R.width, first = R.r0;
   hipStream_t st = R.st;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
+  static const bool wave_first = !(getenv("M4RI_AMD_PLE_WAVE") && atoi(getenv("M4RI_AMD_PLE_WAVE")) == 0);
+  static const int variant     = getenv("M4RI_AMD_RU_TW") ? atoi(getenv("M4RI_AMD_RU_TW")) : RU_DEFAULT_TW;
   for (int64_t wb = c0 / 64; wb * 64 < c1 && R.r0 < nrows; ++wb) {
     const int64_t r0 = R.r0;
     const int ncb = (int)((c1 - wb * 64) < 64 ? (c1 - wb * 64) : 64);
     const int64_t nleft = nrows - r0;
-    hipLaunchKernelGGL(ple_extract_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
-                       s.V);
-    static const bool wave_first = !(getenv("M4RI_AMD_PLE_WAVE") && atoi(getenv("M4RI_AMD_PLE_WAVE")) == 0);
-    if (wave_first) hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, s.V, s.blk);
-    else hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
-    HIPTRY(hipGetLastError());
-    HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
-    HIPTRY(hipStreamSynchronize(st));
-    if (s.hblk->rank < 0) {  // a pivot further than 64 rows down: the general search, from the untouched slice
+    word *Lc = s.Lc + wb * 64;
+    const unsigned row_grid = (unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS);
+    // rows below, words to the right: C ^= (M L^-1) * U*, inner dimension = the block's rank, U* the pivot rows as they are;
+    // dev_rank: the kernel takes the rank from the block's record (it is launched before the host has read it)
+    auto update = [&](int rank, bool dev_rank) -> int {
+      if (wb + 1 >= width || nleft - rank <= 0) return 0;
+      const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
+      const int64_t wn     = width - wfirst;
+      const int skip       = (int)(wb + 1 - wfirst);
+      word *C              = A + (r0 + rank) * stride + wfirst;
+      const word *U        = A + r0 * stride + wfirst;
+      if (vec) HIPTRY(launch_rank_update<true>(st, variant, C, stride, s.Mc, U, stride, nleft - rank, wn, rank, skip, dev_rank ? s.blk : nullptr));
+      else HIPTRY(launch_rank_update<false>(st, variant, C, stride, s.Mc, U, stride, nleft - rank, wn, rank, skip, dev_rank ? s.blk : nullptr));
+      return 0;
+    };
+    hipLaunchKernelGGL(ple_extract_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V);
+    int rank = 0;
+    bool done = false;
+    if (wave_first) {
+      // The one-wave search, its record on the way to the host, and -- without waiting for it -- everything that follows
+      // from the record on the device: row moves, the slice pass, the trailing update.  The host only waits for the copy;
+      // by the time it has the rank and queues the next block, the device is still busy with this one.
+      hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, s.V, s.blk);
+      HIPTRY(hipGetLastError());
+      HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
+      HIPTRY(hipEventRecord(s.ev_copy, st));
+      hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0, s.blk);
+      hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V, s.blk, s.Mc, Lc);
+      HIPTRY(hipGetLastError());
+      if (int rc = update(0, true)) return rc;
+      HIPTRY(hipEventRecord(s.ev_main, st));
+      HIPTRY(hipEventSynchronize(s.ev_copy));
+      rank = s.hblk->rank;
+      done = rank >= 0;  // -1: a pivot further than 128 rows down -- the kernels above did nothing; the general search takes over
+    }
+    if (!done) {
       hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
       HIPTRY(hipGetLastError());
       HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
       HIPTRY(hipStreamSynchronize(st));
-    }
-    const int rank = s.hblk->rank;
-    if (rank == 0) continue;  // nothing moved: the slice words are unchanged
-    const int64_t below = nrows - r0 - rank;
-    if (s.hblk->nsrc > 0)
-      hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0, s.blk);
-    else
-      hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb,
-                         r0, s.blk);
-    word *Lc = s.Lc + wb * 64;
-    hipLaunchKernelGGL(ple_finish_kernel, dim3((unsigned)((nleft + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb,
-                       s.V, s.blk, s.Mc, Lc);
-    HIPTRY(hipGetLastError());
-    if (wb + 1 < width) {
-      if (below > 0) {  // rows below, words to the right: C ^= (M L^-1) * U*, inner dimension = the block's rank, U* the pivot rows as they are
-        const bool vec      = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
-        const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
-        const int64_t wn     = width - wfirst;
-        const int skip       = (int)(wb + 1 - wfirst);
-        static const int variant = getenv("M4RI_AMD_RU_TW") ? atoi(getenv("M4RI_AMD_RU_TW")) : RU_DEFAULT_TW;
-        if (vec) HIPTRY(launch_rank_update<true>(st, variant, A + (r0 + rank) * stride + wfirst, stride, s.Mc, A + r0 * stride + wfirst, stride, below, wn, rank, skip));
-        else HIPTRY(launch_rank_update<false>(st, variant, A + (r0 + rank) * stride + wfirst, stride, s.Mc, A + r0 * stride + wfirst, stride, below, wn, rank, skip));
+      rank = s.hblk->rank;
+      if (rank > 0) {
+        hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0,
+                           s.blk);
+        hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V, s.blk, s.Mc, Lc);
         HIPTRY(hipGetLastError());
+        if (int rc = update(rank, false)) return rc;
+        HIPTRY(hipEventRecord(s.ev_main, st));
       }
+    }
+    if (rank == 0) continue;  // nothing moved: the slice words are unchanged
+    if (wb + 1 < width) {
       // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular solve
-      // with the <= 64 x 64 triangle of their multipliers -- after the update has read them, on the side stream: nothing
-      // later in the factorisation looks at these rows again
-      HIPTRY(hipEventRecord(s.ev_main, st));
+      // with the <= 64 x 64 triangle of their multipliers -- after the update has read them (ev_main), on the side stream:
+      // nothing later in the factorisation looks at these rows again
       HIPTRY(hipStreamWaitEvent(s.side, s.ev_main, 0));
       HIPTRY(m4ri_amd_trsm_lower_left_dev(Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, s.side));
       R.side_used = true;
