@@ -204,10 +204,12 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
 // Same rule, same outputs.  With r pivots found there are 128 - r >= 64 candidates left, so a column that has a pivot
 // further down misses here with probability 2^-64 for generic input; sparse and structured inputs do miss: then the kernel
 // gives up before writing anything (rank = -1) and the host runs the general kernel on the block.
-__global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, PleBlock *__restrict__ out) {
+// V: the block's word of the rows from r0 on, element i at V[i * vs] -- the matrix's own word column (vs = the row stride):
+// this path needs no dense copy of the slice.
+__global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, int64_t vs, PleBlock *__restrict__ out) {
   const int tid = threadIdx.x;
   const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
-  const word org_lo = has_lo ? V[tid] : 0, org_hi = has_hi ? V[tid + 64] : 0;  // the slice words as they stand
+  const word org_lo = has_lo ? V[tid * vs] : 0, org_hi = has_hi ? V[(tid + 64) * vs] : 0;  // the slice words as they stand
   word v_lo = org_lo, v_hi = org_hi;  // the rows in this lane's two slots, reduced by the pivots found so far
   int i_lo = tid, i_hi = tid + 64;    // where the row in each slot stood at the start
   word pv = 0, ph = 0;                // lane l: pivot row l's final word, and the part of it behind its pivot column
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     const word lo_out = tid < rank ? pv : (i_lo < 64 ? a : b2);
     const word c2 = __shfl(org_lo, i_hi & 63), d = __shfl(org_hi, i_hi & 63);
     const word hi_out = i_hi < 64 ? c2 : d;
-    if (has_lo) V[tid] = lo_out;
-    if (has_hi) V[tid + 64] = hi_out;
+    if (has_lo) V[tid * vs] = lo_out;
+    if (has_hi) V[(tid + 64) * vs] = hi_out;
   }
   block_triangle(tid, pv, pc, rank, out);
   out->src[tid]      = i_lo;
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_permute_rows_kernel(word *__r
 // (M L^-1) * U* the update can read the pivot rows as they are, and their solve leaves the critical path (it runs on a
 // side stream, ple_blocks).  So Mc[i - rank] = the row's multipliers times L^-1, with L^-1 from the pivot search
 // (block_triangle); the block's triangle L itself is copied to Lc for that solve.
-__global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restrict__ A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
-                                                                const word *__restrict__ V, const PleBlock *__restrict__ blk,
+__global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *A, int64_t stride, int64_t nrows, int64_t r0, int64_t wb,
+                                                                const word *V, int64_t vs, const PleBlock *__restrict__ blk,
                                                                 word *__restrict__ Mc, word *__restrict__ Lc) {
   __shared__ word s_Linv[64], s_high[64];
   __shared__ int s_col[64];  // the block's record through LDS once: the loops below would otherwise wait for one scalar load per step
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *__restric
   }
   __syncthreads();
   if (rank <= 0 || i >= nrows - r0) return;  // no pivot (the slice words are unchanged) or a search that gave up (rank -1)
-  word v = V[i];
+  word v = V[i * vs];  // the dense slice (vs = 1) or the matrix's word column itself (vs = stride: the same word this thread writes)
   if (i < rank) { A[(r0 + i) * stride + wb] = v; return; }  // pivot rows already hold their final word
   // replay the pivots; the multiplier of pivot l is the bit at its column when its turn comes (it stays there), and the
   // row's multipliers times L^-1 are the XOR of the rows of L^-1 they select
@@ -649,19 +651,19 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       else HIPTRY(launch_rank_update<false>(st, variant, C, stride, s.Mc, U, stride, nleft - rank, wn, rank, skip, dev_rank ? s.blk : nullptr));
       return 0;
     };
-    hipLaunchKernelGGL(ple_extract_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V);
     int rank = 0;
     bool done = false;
+    word *col = A + r0 * stride + wb;  // the block's word of the rows from r0 on, in place
     if (wave_first) {
       // The one-wave search, its record on the way to the host, and -- without waiting for it -- everything that follows
       // from the record on the device: row moves, the slice pass, the trailing update.  The host only waits for the copy;
       // by the time it has the rank and queues the next block, the device is still busy with this one.
-      hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, s.V, s.blk);
+      hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, col, stride, s.blk);
       HIPTRY(hipGetLastError());
       HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
       HIPTRY(hipEventRecord(s.ev_copy, st));
       hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0, s.blk);
-      hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V, s.blk, s.Mc, Lc);
+      hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, col, stride, s.blk, s.Mc, Lc);
       HIPTRY(hipGetLastError());
       if (int rc = update(0, true)) return rc;
       HIPTRY(hipEventRecord(s.ev_main, st));
@@ -669,7 +671,8 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       rank = s.hblk->rank;
       done = rank >= 0;  // -1: a pivot further than 128 rows down -- the kernels above did nothing; the general search takes over
     }
-    if (!done) {
+    if (!done) {  // the general search works on a dense copy of the slice
+      hipLaunchKernelGGL(ple_extract_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V);
       hipLaunchKernelGGL(ple_pivots_kernel, dim3(1), dim3(SLICE_THREADS), 0, st, nleft, r0, ncb, s.V, s.blk);
       HIPTRY(hipGetLastError());
       HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
@@ -678,7 +681,7 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       if (rank > 0) {
         hipLaunchKernelGGL(ple_swap_rows_kernel, dim3((unsigned)((width + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0,
                            s.blk);
-        hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V, s.blk, s.Mc, Lc);
+        hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V, (int64_t)1, s.blk, s.Mc, Lc);
         HIPTRY(hipGetLastError());
         if (int rc = update(rank, false)) return rc;
         HIPTRY(hipEventRecord(s.ev_main, st));
