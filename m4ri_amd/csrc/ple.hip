@@ -206,7 +206,10 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
 // gives up before writing anything (rank = -1) and the host runs the general kernel on the block.
 // V: the block's word of the rows from r0 on, element i at V[i * vs] -- the matrix's own word column (vs = the row stride):
 // this path needs no dense copy of the slice.
-__global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, int64_t vs, PleBlock *__restrict__ out) {
+// hout: the host's pinned mirror of the record -- what the host wants from it (rank, pivot columns, swapped rows) is written
+// straight there, so no copy has to be queued behind the kernel.
+__global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t r0, int ncb, word *__restrict__ V, int64_t vs, PleBlock *__restrict__ out,
+                                                             PleBlock *__restrict__ hout) {
   const int tid = threadIdx.x;
   const bool has_lo = tid < n, has_hi = (int64_t)tid + 64 < n;
   const word org_lo = has_lo ? V[tid * vs] : 0, org_hi = has_hi ? V[(tid + 64) * vs] : 0;  // the slice words as they stand
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     const unsigned long long b_hi = __ballot((v_hi >> c) & 1);
     if (!b_hi) {
       if (n > 128) {  // candidates beyond the 128 rows held here: not this kernel's case
-        if (tid == 0) out->rank = -1;
+        if (tid == 0) { out->rank = -1; hout->rank = -1; }
         return;
       }
       continue;  // no pivot in this column
@@ -270,8 +273,10 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     out->pivcol[tid]  = pc;
     out->swaprow[tid] = (int32_t)(r0 + psw);
     out->vhigh[tid]   = ph;
+    hout->pivcol[tid]  = pc;
+    hout->swaprow[tid] = (int32_t)(r0 + psw);
   }
-  if (tid == 0) out->rank = rank;
+  if (tid == 0) { out->rank = rank; hout->rank = rank; }
 }
 
 // ---- 2a. the block's row swaps on every other word; one thread per word column ---------------------------------
@@ -658,9 +663,8 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       // The one-wave search, its record on the way to the host, and -- without waiting for it -- everything that follows
       // from the record on the device: row moves, the slice pass, the trailing update.  The host only waits for the copy;
       // by the time it has the rank and queues the next block, the device is still busy with this one.
-      hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, col, stride, s.blk);
+      hipLaunchKernelGGL(ple_pivots_wave_kernel, dim3(1), dim3(64), 0, st, nleft, r0, ncb, col, stride, s.blk, s.hblk);
       HIPTRY(hipGetLastError());
-      HIPTRY(hipMemcpyAsync(s.hblk, s.blk, sizeof(PleBlock), hipMemcpyDeviceToHost, st));
       HIPTRY(hipEventRecord(s.ev_copy, st));
       hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0, s.blk);
       hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, col, stride, s.blk, s.Mc, Lc);
