@@ -56,6 +56,10 @@ struct PleBlock {
   word Linv[64];        // row t of L^-1 (block_triangle below)
   int32_t nsrc;         // > 0: the block's row swaps as ONE permutation of the first nsrc rows (the one-wave search knows it) ...
   int32_t src[128];     // ... position t takes the row that stood at position src[t]
+  word deferred;        // columns the one-wave search passed over because none of ITS 128 rows had a pivot there while rows lie
+                        // beyond: to be confirmed against those rows (ple_verify_kernel) before anything is committed
+  word stage[128];      // with deferred != 0: the rearranged slice words of the first 128 rows, not yet written to the matrix
+  int32_t missed;       // ple_verify_kernel: a row beyond the window does have a bit in a deferred column
 };
 
 // ---- 0. the block's word of every remaining row -> dense vector -------------------------------------------------
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(SLICE_THREADS) void ple_pivots_kernel(int64_t n, in
   }
   __syncthreads();
   if (tid < 64) block_triangle(tid, tid < rank ? s_head[tid] : 0, tid < rank ? s_col[tid] : 0, rank, out);
-  if (tid == 0) { out->rank = rank; out->nsrc = 0; }
+  if (tid == 0) { out->rank = rank; out->nsrc = 0; out->deferred = 0; }
 }
 
 // ---- 1'. the same search in ONE WAVE, for blocks whose pivots all sit within the first 128 rows ---------------------
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
   word pv = 0, ph = 0;                // lane l: pivot row l's final word, and the part of it behind its pivot column
   int pc = 0, psw = 0;                // lane l: pivot l's column, and the position the pivot row was found at
   int rank = 0;
+  word deferred = 0;
   const int cols = ncb < 64 ? ncb : 64;
   for (int c = 0; c < cols && rank < n; ++c) {
     const unsigned long long b_lo = __ballot(tid >= rank && ((v_lo >> c) & 1));  // slots without a row hold 0
@@ -236,11 +241,11 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     }
     const unsigned long long b_hi = __ballot((v_hi >> c) & 1);
     if (!b_hi) {
-      if (n > 128) {  // candidates beyond the 128 rows held here: not this kernel's case
-        if (tid == 0) { out->rank = -1; hout->rank = -1; }
-        return;
-      }
-      continue;  // no pivot in this column
+      // no pivot among the rows held here.  If rows lie beyond, the column is passed over on the assumption that they have none
+      // either (a column without a pivot is the usual reason), and the assumption is checked before anything is committed.
+      // Later pivots do not disturb the check: they only change bits behind their own, later, columns.
+      if (n > 128) deferred |= (word)1 << c;
+      continue;
     }
     {  // the pivot sits in a high slot (rare)
       const int pl     = (int)__builtin_ctzll(b_hi);
@@ -262,8 +267,13 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     const word lo_out = tid < rank ? pv : (i_lo < 64 ? a : b2);
     const word c2 = __shfl(org_lo, i_hi & 63), d = __shfl(org_hi, i_hi & 63);
     const word hi_out = i_hi < 64 ? c2 : d;
-    if (has_lo) V[tid * vs] = lo_out;
-    if (has_hi) V[(tid + 64) * vs] = hi_out;
+    if (deferred) {  // not yet: the host has the deferred columns verified first (ple_blocks)
+      out->stage[tid]      = lo_out;
+      out->stage[tid + 64] = hi_out;
+    } else {
+      if (has_lo) V[tid * vs] = lo_out;
+      if (has_hi) V[(tid + 64) * vs] = hi_out;
+    }
   }
   block_triangle(tid, pv, pc, rank, out);
   out->src[tid]      = i_lo;
@@ -276,7 +286,30 @@ __global__ __launch_bounds__(64) void ple_pivots_wave_kernel(int64_t n, int64_t 
     hout->pivcol[tid]  = pc;
     hout->swaprow[tid] = (int32_t)(r0 + psw);
   }
-  if (tid == 0) { out->rank = rank; hout->rank = rank; }
+  if (tid == 0) { out->rank = rank; hout->rank = rank; out->deferred = deferred; hout->deferred = deferred; }
+}
+
+// Are the columns the one-wave search passed over really without a pivot?  Every row beyond its window replays the block's
+// pivots on its slice word and looks at the deferred columns.
+__global__ __launch_bounds__(ROW_THREADS) void ple_verify_kernel(const word *__restrict__ V, int64_t vs, int64_t n, PleBlock *__restrict__ blk) {
+  __shared__ word s_high[64];
+  __shared__ int s_col[64];
+  const int rank = blk->rank;
+  if (threadIdx.x < 64) {
+    s_high[threadIdx.x] = blk->vhigh[threadIdx.x];
+    s_col[threadIdx.x]  = blk->pivcol[threadIdx.x];
+  }
+  __syncthreads();
+  const int64_t i = 128 + (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
+  word v = i < n ? V[i * vs] : 0;
+  for (int l = 0; l < rank; ++l) v ^= ((v >> s_col[l]) & 1) ? s_high[l] : 0;
+  if (__syncthreads_or((v & blk->deferred) != 0) && threadIdx.x == 0) blk->missed = 1;
+}
+
+// the verified block's first 128 slice words go where the search would have put them
+__global__ __launch_bounds__(128) void ple_commit_stage_kernel(word *__restrict__ V, int64_t vs, PleBlock *__restrict__ blk) {
+  if ((int)threadIdx.x < blk->nsrc) V[(int64_t)threadIdx.x * vs] = blk->stage[threadIdx.x];
+  if (threadIdx.x == 0) blk->deferred = 0;  // from here on the block is an ordinary one for the kernels that follow
 }
 
 // ---- 2a. the block's row swaps on every other word; one thread per word column ---------------------------------
@@ -301,7 +334,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_permute_rows_kernel(word *__r
                                                                       const PleBlock *__restrict__ blk) {
   __shared__ word tile[128][PERM_TW];
   __shared__ int s_src[128];
-  if (blk->rank <= 0) return;  // nothing moved, or the search gave up (then nsrc is not this block's)
+  if (blk->rank <= 0 || blk->deferred) return;  // nothing moved / not confirmed yet (ple_verify_kernel; the host launches this again)
   const int n = blk->nsrc;
   if (threadIdx.x < 128) s_src[threadIdx.x] = threadIdx.x < n ? blk->src[threadIdx.x] : (int)threadIdx.x;
   __syncthreads();
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ple_finish_kernel(word *A, int64_
     if (blockIdx.x == 0) Lc[threadIdx.x] = blk->Lc[threadIdx.x];  // where the side stream's solve of the pivot rows reads it
   }
   __syncthreads();
-  if (rank <= 0 || i >= nrows - r0) return;  // no pivot (the slice words are unchanged) or a search that gave up (rank -1)
+  if (rank <= 0 || blk->deferred || i >= nrows - r0) return;  // no pivot (the slice words are unchanged) or a block not confirmed yet
   word v = V[i * vs];  // the dense slice (vs = 1) or the matrix's word column itself (vs = stride: the same word this thread writes)
   if (i < rank) { A[(r0 + i) * stride + wb] = v; return; }  // pivot rows already hold their final word
   // replay the pivots; the multiplier of pivot l is the bit at its column when its turn comes (it stays there), and the
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(THREADS) void ple_rank_update_kernel(word *__restri
   __shared__ __attribute__((aligned(16))) word tab[16][16][TW];  // [table][entry][word]
   if (blk) {  // launched before the host knew the block's rank: C and rows arrive for rank 0, the record has the real one
     rank = blk->rank;
-    if (rank <= 0) return;
+    if (rank <= 0 || blk->deferred) return;
     C += (int64_t)rank * c_stride;
     rows -= rank;
     if (rows <= 0) return;
@@ -673,7 +706,30 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       HIPTRY(hipEventRecord(s.ev_main, st));
       HIPTRY(hipEventSynchronize(s.ev_copy));
       rank = s.hblk->rank;
-      done = rank >= 0;  // -1: a pivot further than 128 rows down -- the kernels above did nothing; the general search takes over
+      done = true;
+      if (s.hblk->deferred != 0) {
+        // The search passed over columns in which none of its 128 rows had a pivot (the kernels queued above did nothing):
+        // have the rows beyond looked at.  Nothing there -- the usual case, a column without a pivot -- and the block is
+        // committed as found; otherwise the slice is untouched and the general search takes over.
+        HIPTRY(hipMemsetAsync(&s.blk->missed, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(ple_verify_kernel, dim3((unsigned)((nleft - 128 + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, st, col, stride, nleft, s.blk);
+        HIPTRY(hipGetLastError());
+        HIPTRY(hipMemcpyAsync(&s.hblk->missed, &s.blk->missed, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPTRY(hipStreamSynchronize(st));
+        if (s.hblk->missed == 0) {
+          hipLaunchKernelGGL(ple_commit_stage_kernel, dim3(1), dim3(128), 0, st, col, stride, s.blk);
+          if (rank > 0) {
+            hipLaunchKernelGGL(ple_permute_rows_kernel, dim3((unsigned)((width + PERM_TW - 1) / PERM_TW)), dim3(ROW_THREADS), 0, st, A, stride, width, wb, r0,
+                               s.blk);
+            hipLaunchKernelGGL(ple_finish_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, col, stride, s.blk, s.Mc, Lc);
+            HIPTRY(hipGetLastError());
+            if (int rc = update(rank, false)) return rc;
+            HIPTRY(hipEventRecord(s.ev_main, st));
+          }
+        } else {
+          done = false;
+        }
+      }
     }
     if (!done) {  // the general search works on a dense copy of the slice
       hipLaunchKernelGGL(ple_extract_kernel, dim3(row_grid), dim3(ROW_THREADS), 0, st, A, stride, nrows, r0, wb, s.V);
