@@ -79,7 +79,10 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__r
 // blocks of 512 rows are inverted up front instead -- all of them in ONE launch, a workgroup per block, a thread per
 // column of the inverse (substitution on a unit vector, the block's rows broadcast), transposed through LDS -- and a
 // block's solve becomes X = T_bb^-1 * B_b, one product; the recursion stops at 512 rows (127 + 128 products).
-constexpr int TB = 512;  // rows of a diagonal block
+#ifndef TRSM_TB
+#define TRSM_TB 512
+#endif
+constexpr int TB = TRSM_TB;  // rows of a diagonal block (256 / 512 / 1024: 44.0 / 38.8 / 37.7 ms at 65536^2, 6.2 / 5.2 / 5.8 ms at 16384^2)
 
 template <bool UPPER>
 __global__ __launch_bounds__(TB) void trsm_invert_blocks_kernel(const word *__restrict__ T, int64_t t_stride, int64_t mb, word *__restrict__ Tinv) {
