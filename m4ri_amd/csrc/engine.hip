@@ -162,9 +162,18 @@ const LeafKind LEAF_KINDS[5] = {{4, 32, 4096, 6.7}, {3, 32, 2048, 5.3},
 constexpr int LEAF_KIND_FALLBACK = 2;  // generation 1, 1024 rows: needs no packed A
 
 LeafKind pick_leaf(int64_t m) {
+  static const int forced_gen = getenv("M4RI_AMD_LEAF_GEN") ? atoi(getenv("M4RI_AMD_LEAF_GEN")) : 0;  // developer override
+  // Generation 4 from 192 rows on, however few of its 4096 tile rows that fills: its waves that own only padding skip their
+  // gathers, so a short tile costs the LDS array its real rows, and its 512-column tiles put four times as many
+  // workgroups on the chip as the 2048-column tiles of generation 1 (single products: 1024 x 1024 x 65536 70.8 vs 140.7 us,
+  // 1100^3 54 vs 124 us, 6000^3 85 vs 152 us; 8800^3 and up: a tie; below ~180 rows generation 1 wins --
+  // tools/small_shape_leaf_gens.py).  The throughput model below, calibrated on full batches, is left to pick among the
+  // short generation-1 tiles.
+  if (!forced_gen && m >= 192) return LEAF_KINDS[0];
   LeafKind best = LEAF_KINDS[LEAF_KIND_FALLBACK];
   double best_cost = 1e300;
   for (const LeafKind &k : LEAF_KINDS) {
+    if (forced_gen && k.gen != forced_gen) continue;
     const double padded = (double)(((m + k.rows - 1) / k.rows) * k.rows);
     const double cost   = padded / k.rate;
     if (cost < best_cost) { best_cost = cost; best = k; }

@@ -319,10 +319,10 @@ def test_device_views_and_ragged_strassen(oracle):
 
 
 @pytest.mark.parametrize("m,l,n,cutoff,a_shift,leaf_gen", [
-    (8192, 8192, 8192, 2048, 0, 3),    # two fused levels, 2048-row leaves: pass writes generation 3's packed A
-    (16384, 4096, 4096, 1024, 0, 4),   # 4096-row leaves: generation 4's rotated packed A, short inner dimension
-    (8192, 5120, 8192, 1024, 0, 3),    # 20-word leaf rows do not tile the fused pass: down2 + separate pack
-    (8192, 8192, 8192, 2048, 1, 3),    # A view starting one word into its rows (8-byte aligned, odd stride)
+    (8192, 8192, 8192, 2048, 0, 4),    # two fused levels, 2048-row leaves (half-filled tiles): pass writes the rotated packed A
+    (16384, 4096, 4096, 1024, 0, 4),   # 4096-row leaves, short inner dimension
+    (8192, 5120, 8192, 1024, 0, 4),    # 20-word leaf rows do not tile the fused pass: down2 + separate pack
+    (8192, 8192, 8192, 2048, 1, 4),    # A view starting one word into its rows (8-byte aligned, odd stride)
 ])
 def test_fused_down_pack_paths(oracle, m, l, n, cutoff, a_shift, leaf_gen):
     """The last A-side pass of the breadth-first schedule writes the leaf's packed operand directly
@@ -340,10 +340,10 @@ def test_fused_down_pack_paths(oracle, m, l, n, cutoff, a_shift, leaf_gen):
 
 
 @pytest.mark.parametrize("m,l,n,cutoff,leaf_gen,add", [
-    (16384, 16384, 16384, 2048, 3, False),  # 343 leaves of 2048^3: three-level pass writes generation 3's packed A
-    (32768, 8192, 8192, 1024, 4, False),    # 4096-row leaves: generation 4's rotated packed A
-    (8192, 10240, 8192, 1024, 1, False),    # 20-word leaf rows of 1024-row leaves: plain three-level passes, generation 1 (no packed A)
-    (4096, 4096, 4096, 512, 1, True),       # accumulate through the three-level up pass
+    (16384, 16384, 16384, 2048, 4, False),  # 343 leaves of 2048^3: three-level pass writes the packed A of half-filled tiles
+    (32768, 8192, 8192, 1024, 4, False),    # 4096-row leaves
+    (8192, 10240, 8192, 1024, 4, False),    # 20-word leaf rows of 1024-row leaves: plain three-level passes + separate pack
+    (4096, 4096, 4096, 512, 4, True),       # accumulate through the three-level up pass
 ])
 def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
     """One fused pass per operand for the three deepest levels (aux_kernels.hip winograd_down3 / up3);
