@@ -16,6 +16,6 @@ bench: build      ## the headline number (one JSON line)
 leaf-check:       ## developer harness for the leaf kernels (every generation in the build)
 	mkdir -p build
 	hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp m4ri_amd/csrc/m4rm_leaf.hip \
-	  m4ri_amd/csrc/m4rm8_leaf.hip m4ri_amd/csrc/m4rm8q_leaf.hip -o build/leaf_check
+	  m4ri_amd/csrc/a4_pack.hip m4ri_amd/csrc/m4rm8q_leaf.hip -o build/leaf_check
 
 .PHONY: build test test-gpu bench leaf-check

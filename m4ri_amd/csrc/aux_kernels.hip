@@ -446,7 +446,7 @@ extern "C" hipError_t gf2_launch_fill_splitmix(hipStream_t s, word *M, int64_t s
 
 // ---- two levels down on the A side, written straight into the leaf's packed form ------------------
 // The M4RM leaf (generations 3 and 4) reads A chunk-major: A4[q][r] = the q-th 32-bit chunk of row r
-// (m4rm8_leaf.hip).  Producing that layout here saves the separate pack pass -- one read and one
+// (a4_pack.hip).  Producing that layout here saves the separate pack pass -- one read and one
 // write of all 7^L leaf operands, the largest single item of the schedule's HBM traffic.  A
 // workgroup owns a 32-row x 32-chunk tile of the grandchild grid; every one of its 49 outputs goes
 // through a (double-buffered) LDS transpose so that both the reads of the grandparent (128 B per

@@ -27,7 +27,6 @@
 
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
-hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *gchild,
@@ -152,14 +151,12 @@ hipEvent_t take_event(Engine *e) {
 }
 
 // ---- leaf launch ------------------------------------------------------------------------------
-// Three leaf kernels (m4rm8q = generation 4, m4rm8 = generation 3, m4rm_leaf = generation 1; the k = 7
-// generation 2 was retired in round 2: generation 1 serves its 1024-row tiles 13 % slower and needs no packed A);
-// they differ in tile shape (4096x512, 2048x1024, 1024x2048 and shorter) and in measured throughput on full tiles
-// (8192^3 batches: 6.7 / 5.3 / 4.1 / 3.4 / 2.8 e15).  Pick the one that wastes the least time on padded rows.
+// Two leaf kernels: m4rm8q = generation 4 (4096 x 512 tiles, packed A) and m4rm_leaf = generation 1 (1024-row tiles and
+// shorter, plain A).  Generations 2 (k = 7) and 3 (128-byte entries, 2048 x 1024 tiles) were retired in round 2: generation 4
+// is at least as fast on every shape from 192 rows on, short tiles included (pick_leaf).
 struct LeafKind { int gen; int rg; int rows; double rate; };
-const LeafKind LEAF_KINDS[5] = {{4, 32, 4096, 6.7}, {3, 32, 2048, 5.3},
-                                {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
-constexpr int LEAF_KIND_FALLBACK = 2;  // generation 1, 1024 rows: needs no packed A
+const LeafKind LEAF_KINDS[4] = {{4, 32, 4096, 6.7}, {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
+constexpr int LEAF_KIND_FALLBACK = 1;  // generation 1, 1024 rows: needs no packed A
 
 LeafKind pick_leaf(int64_t m) {
   static const int forced_gen = getenv("M4RI_AMD_LEAF_GEN") ? atoi(getenv("M4RI_AMD_LEAF_GEN")) : 0;  // developer override
@@ -188,7 +185,7 @@ size_t packed_a_words(int64_t m, int64_t l, int64_t batch) {
 
 // can a leaf launch of this shape use the packed-A kernel `kind` with the scratch the engine holds?
 bool packed_a_fits(const Engine *e, const LeafKind &kind, int64_t m, int64_t l, int64_t batch) {
-  if (kind.gen < 3 || batch <= 0) return false;
+  if (kind.gen < 4 || batch <= 0) return false;
   const size_t need = (size_t)gf2_m4rm8_a4_words(m, l, batch);
   return e->apk != nullptr && need <= e->apk_words && (uint64_t)need * 8 / (uint64_t)batch < (1ull << 32);
 }
@@ -205,7 +202,7 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
     return (int)hipErrorInvalidValue;
   LeafKind kind      = pick_leaf(m);
   const int64_t wn   = words_of(n);
-  const int64_t tw   = kind.gen == 4 ? 8 : kind.gen == 3 ? 16 : LEAF_TW;  // tile width in words
+  const int64_t tw   = kind.gen == 4 ? 8 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
   const int64_t sbits  = kind.gen == 4 ? 32 : 16;  // inner bits per stage (barrier to barrier)
   const int64_t stages = (l + sbits - 1) / sbits;
@@ -273,15 +270,15 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   a.batch = (int32_t)batch; a.ksplit = ksplit;
   a.mode  = (ksplit > 1 && slabs) ? 2 : (add || ksplit > 1) ? 1 : 0;
   a.Cpart = e->part;
-  // generations 3 and 4 consume A in a packed, chunk-major form (one streaming pass into the call's
-  // scratch first); they need that scratch and 32-bit offsets inside one packed operand
+  // generation 4 consumes A in a packed, chunk-major form (one streaming pass into the call's
+  // scratch first); it needs that scratch and 32-bit offsets inside one packed operand
   if (a_prepacked) {
-    if (kind.gen < 3 || !packed_a_fits(e, kind, m, l, batch)) return (int)hipErrorInvalidValue;  // caller checked
-  } else if (kind.gen >= 3) {
+    if (kind.gen < 4 || !packed_a_fits(e, kind, m, l, batch)) return (int)hipErrorInvalidValue;  // caller checked
+  } else if (kind.gen == 4) {
     if (!packed_a_fits(e, kind, m, l, batch)) kind = LEAF_KINDS[LEAF_KIND_FALLBACK];
     else {
       const size_t need = (size_t)gf2_m4rm8_a4_words(m, l, batch);
-      HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, kind.gen - 3));  // 0 / 1: the generation's index twists
+      HIPTRY(gf2_launch_a4_pack_rot(st, a, e->apk, 1));  // the index bytes pre-rotated for the leaf's constant selectors
       e->stats.aux_bytes += 8.0 * (double)batch * (double)m * words_of(l) + 8.0 * (double)need;
     }
   }
@@ -307,7 +304,6 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
       HIPTRY(gf2_launch_reduce_partials(st, add ? 1 : 0, C, cs, cbs, m, wn, kind.rows, tw, (m + kind.rows - 1) / kind.rows, (wn + tw - 1) / tw,
                                         0, tiles, ksplit, e->part));
   }
-  else if (kind.gen == 3) HIPTRY(gf2_launch_m4rm8(st, a, e->apk, 32, 4, 0));
   else HIPTRY(gf2_launch_m4rm_leaf(st, a, kind.rg));
   if (e->profiling && e0 && e1) {
     HIPTRY(hipEventRecord(e1, st));
@@ -400,7 +396,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // the row-major A operands of the leaves are never materialised and the pack pass disappears.
   const LeafKind leaf_kind = pick_leaf(m >> L);
   bool prepack = false;
-  if (fuse >= 2 && leaf_kind.gen >= 3) {
+  if (fuse >= 2 && leaf_kind.gen == 4) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
     const int d0      = L - fuse;
     const word *pa    = d0 == 0 ? A.p : aligned16;  // deeper levels live in the 256-byte aligned workspace
@@ -451,7 +447,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
-    const int rot = leaf_kind.gen >= 3 ? leaf_kind.gen - 3 : 0;  // the leaf generation's index twists (pack mode)
+    const int rot = leaf_kind.gen == 4 ? 1 : 0;  // the leaf's pre-rotated index bytes (pack mode)
     if (step == 3) {
       if (prepack) HIPTRY(gf2_launch_winograd_down3_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down3(st, 0, pa, pas, pabs, Al[d + 3], cnt, cm, cl / 64));

@@ -2,7 +2,7 @@
 // interleaved per LDS bank row, double-buffered, software-pipelined gathers, table building on the
 // four older waves.
 //
-// One more turn of generation 3's screw (m4rm8_leaf.hip).  The leaf is bound by LDS-array cycles,
+// One more turn of the screw of generation 3 (retired; its description is in DESIGN.md 3.1).  The leaf is bound by LDS-array cycles,
 // and for a tile of fixed area the gathers cost the same while the table writes shrink with the
 // entry size, because more rows share every entry:
 //
@@ -17,7 +17,7 @@
 //     ds_read_b128's four 16-lane service groups holds four row groups -- {0,3,5,6}, {1,2,4,7},
 //     {8,11,13,14}, {9,10,12,15} -- whose `rot` values are 0,1,2,3 in every case, so the four row
 //     groups always sit in four different quarters of the bank row: conflict-free for ANY indices.
-//   * The packed A (a4_pack_kernel of m4rm8_leaf.hip, or the fused Winograd pass of aux_kernels.hip)
+//   * The packed A (a4_pack_kernel of a4_pack.hip, or the fused Winograd pass of aux_kernels.hip)
 //     holds a row's four index bytes already rotated by `rot`, so byte i of the dword IS gather i's
 //     index and the four v_perm selectors are compile-time constants.
 //   * Software pipeline: row g+1's four gathers are issued before row g's XORs, so a wave keeps
@@ -401,7 +401,7 @@ extern "C" int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit) {
 }
 
 // Host launcher.  A must already be packed chunk-major WITH the byte rotation (gf2_launch_a4_pack_rot
-// of m4rm8_leaf.hip, rot = 1, or gf2_launch_winograd_down2_pack) into `a4_ws`.  Tiles are 4096 rows
+// of a4_pack.hip, rot = 1, or gf2_launch_winograd_down2_pack) into `a4_ws`.  Tiles are 4096 rows
 // x 512 columns.
 extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws) {
   a.wn        = (int32_t)words_of(a.n);

@@ -1,7 +1,7 @@
 // m4rm_leaf.hip -- M4RM leaf, generation 1 (two-phase, k = 8): C (^)= A*B over GF(2) by the Method of
 // Four Russians, hand-written for gfx950 (MI355X / CDNA4).  No MFMA: this is a lookup + XOR path.
 // The engine uses it for tiles shorter than 1024 rows and as the fallback that needs no packed A;
-// full tiles run generations 3 and 4 (m4rm8_leaf.hip, m4rm8q_leaf.hip).
+// everything from 192 rows on runs generation 4 (m4rm8q_leaf.hip).
 //
 // Replaces (result-identical, not structure-identical) the reference's leaf
 //   _mzd_mul_m4rm           /root/reference m4ri/brilliantrussian.c:1032-1190

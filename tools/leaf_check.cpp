@@ -2,7 +2,7 @@
 // not a test the driver runs): checks gf2_launch_m4rm_leaf against a definitional CPU multiply on
 // ragged/batched/strided shapes, then times the bench-sized launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I m4ri_amd/csrc tools/leaf_check.cpp \
-//         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/m4rm8_leaf.hip m4ri_amd/csrc/m4rm8q_leaf.hip -o build/leaf_check
+//         m4ri_amd/csrc/m4rm_leaf.hip m4ri_amd/csrc/a4_pack.hip m4ri_amd/csrc/m4rm8q_leaf.hip -o build/leaf_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -12,16 +12,14 @@
 
 extern "C" hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 extern "C" hipError_t gf2_launch_m4rm_leaf_variant(hipStream_t stream, LeafArgs a, int rg, int ug, int pipe);
-extern "C" hipError_t gf2_launch_m4rm8(hipStream_t stream, LeafArgs a, word *a4_ws, int rg, int ug, int pipe);
 extern "C" int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
-extern "C" hipError_t gf2_launch_a4_pack(hipStream_t stream, LeafArgs a, word *a4_ws);
 extern "C" hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 extern "C" hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
 static word *g_a7 = nullptr; static int64_t g_a7_words = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 // pipe: variant bits of the two-phase kernel (1 = software-pipelined use phase, 2 = B rows staged
-// through LDS); 10 = generation 3, 11 = generation 4.  (The generation-2, generation-5 and half-builder
+// through LDS); 11 = generation 4.  (The generation-2, generation-3, generation-5 and half-builder
 // experiments were removed with their kernels in round 2; their measurements are in DESIGN.md 3.1.)
 static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
   if (pipe == 11) {  // generation 4: 8-bit tables, 64-byte entries, 4096 x 512 tiles
@@ -29,12 +27,6 @@ static hipError_t launch(LeafArgs a, int rg, int ug, int pipe) {
     if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
     CK(gf2_launch_a4_pack_rot(0, a, g_a7, 1));
     return gf2_launch_m4rm8q(0, a, g_a7);
-  }
-  if (pipe == 10) {  // generation 3: 8-bit tables, 128-byte entries, 2048 x 1024 tiles
-    const int64_t need = gf2_m4rm8_a4_words(a.m, a.l, a.batch);
-    if (need > g_a7_words) { if (g_a7) (void)hipFree(g_a7); CK(hipMalloc(&g_a7, need * 8)); g_a7_words = need; }
-    CK(gf2_launch_a4_pack(0, a, g_a7));
-    return gf2_launch_m4rm8(0, a, g_a7, rg, ug, 0);
   }
   return gf2_launch_m4rm_leaf_variant(0, a, rg, ug, pipe);
 }
@@ -193,7 +185,7 @@ int main(int argc, char **argv) {
     return fails != 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--variants")) {
-    const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 4, 10}, {32, 1, 11}};
+    const int v[][3] = {{32, 4, 0}, {24, 4, 0}, {16, 4, 0}, {32, 1, 11}};
     for (auto &x : v) {
       fails += check(1000, 777, 1234, 2, 1, 1, x[0], 3, x[1], x[2]);
       fails += check(2100, 300, 4100, 2, 3, 1, x[0], 2, x[1], x[2]);
