@@ -68,10 +68,13 @@ namespace {
 constexpr int MAX_LEVELS      = 6;
 constexpr int64_t PART_SLABS  = 768;  // slabs (256 KiB each) a split generation-4 launch may use: 192 MiB of the workspace
 #ifndef LEAF_SPLIT_COST_BITS
-#define LEAF_SPLIT_COST_BITS 128
+#define LEAF_SPLIT_COST_BITS 256
 #endif
 #ifndef LEAF_MIN_SPLIT_BITS
-#define LEAF_MIN_SPLIT_BITS 512  // fewest inner bits one split of a leaf launch may get
+#define LEAF_MIN_SPLIT_BITS 512  // fewest inner bits one split of a leaf launch may get (generation 1: atomics)
+#endif
+#ifndef LEAF_MIN_SPLIT_BITS_G4
+#define LEAF_MIN_SPLIT_BITS_G4 128  // the same for generation 4 (slabs + reduce pass)
 #endif
 int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
 constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
@@ -219,12 +222,19 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
     // per-workgroup overheads in inner bits, calibrated on generation 4 (tools/small_sizes_timing.py):
     // prologue + epilogue ~ 192 bits of stage time, the atomic epilogue of a split ~ 512 more
     // (generation 4 writes slabs instead and pays one reduce pass: LEAF_SPLIT_COST_BITS)
-    const double fixed = 192.0 / (double)sbits, atomic = (kind.gen == 4 ? (double)LEAF_SPLIT_COST_BITS : 512.0) / (double)sbits;
+    // Generation 4's slabs cost a fixed part (the reduce pass is one more launch) and a part that grows with the number
+    // of slabs written and read back -- measured on single products (tools/leaf_split_sweep.sh): 512^3 42 -> 29 us,
+    // 1024^3 50 -> 35 us, 4096^3 71 -> 60 us with splits down to 128 bits, while 512 x 512 x 65536, whose 128 tiles
+    // already cover half the chip, must NOT split (42 vs 53 us).
+    const double fixed = 192.0 / (double)sbits;
+    auto split_cost = [&](int64_t ntiles, int64_t ks) {
+      return kind.gen == 4 ? ((double)LEAF_SPLIT_COST_BITS + 2.0 * (double)(ntiles * ks)) / (double)sbits : 512.0 / (double)sbits;
+    };
     auto cost = [&](int64_t ks) {
       const int64_t rounds = (tiles * ks + e->cus - 1) / e->cus;
-      return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? atomic : 0.0));
+      return (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + (ks > 1 ? split_cost(tiles, ks) : 0.0));
     };
-    int64_t cap = stages * sbits / LEAF_MIN_SPLIT_BITS;  // inner bits per split: see the constant
+    int64_t cap = stages * sbits / (kind.gen == 4 ? LEAF_MIN_SPLIT_BITS_G4 : LEAF_MIN_SPLIT_BITS);  // inner bits per split: see the constants
     if (cap < 1) cap = 1;
     if (cap > 32) cap = 32;
     ksplit           = 1;
@@ -237,7 +247,7 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
       const int64_t rem = tiles % e->cus, full_rounds = tiles / e->cus;
       for (int64_t ks = 2; ks <= cap; ++ks) {
         const int64_t rounds = (rem * ks + e->cus - 1) / e->cus;
-        const double c = (double)full_rounds * ((double)stages + fixed) + (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + atomic);
+        const double c = (double)full_rounds * ((double)stages + fixed) + (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + split_cost(rem, ks));
         if (c < best_cost * 0.99) { best_cost = c; tail_tiles = rem; tail_ksplit = (int)ks; }
       }
       if (tail_tiles) ksplit = 1;
