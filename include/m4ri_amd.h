@@ -155,6 +155,18 @@ mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k);
 void mzd_apply_p_left(mzd_t *A, mzp_t const *P);
 void mzd_apply_p_left_trans(mzd_t *A, mzp_t const *P);
 
+/* ---- transposes and triangular inverses (transpose.hip, trsm.hip) ------------------------------------------------
+ * mzd_transpose (m4ri/mzd.h:611; mzd.c:1118-1139): DST <- A^T (DST == NULL: a new matrix; wrong dimensions die with the
+ * reference's message).  DST may be A itself here (the reference forbids it).
+ * mzd_trtri_upper (m4ri/triangular.h:163; triangular.c:518-547) and mzd_trtri_upper_russian (m4ri/triangular_russian.h:66;
+ * .c:384-470): A <- A^-1 in place for a unit upper triangular A.  As in the reference the diagonal and the lower
+ * triangle are not written; unlike the reference they are not read either: a zero on the diagonal (a singular input,
+ * outside the reference's contract) makes the reference's result depend on its blocking, while this library returns
+ * the inverse of the unit-diagonal matrix. */
+mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A);
+mzd_t *mzd_trtri_upper(mzd_t *A);
+mzd_t *mzd_trtri_upper_russian(mzd_t *A, int k);
+
 /* ---- the table primitives of M4RI's elimination routines -----------------------------
  * mzd_make_table (m4ri/brilliantrussian.h:56, .c:163-211): T[i], i = 1 .. 2^k - 1, = the Gray-code combinations of
  * rows r .. r+k-1 of M from word c/64 on (first word masked below column c, last word by M's column mask), and
@@ -270,6 +282,12 @@ int m4ri_amd_solve_left_dev(word *A, int64_t a_stride, int64_t m, int64_t n, wor
 int m4ri_amd_kernel_left_pluq_dev(word *A, int64_t a_stride, int64_t m, int64_t n, word *R, int64_t r_stride, int cutoff, int32_t *rank_out,
                                   void *stream);
 int m4ri_amd_inv_dev(word *Binv, int64_t b_stride, const word *A, int64_t a_stride, int64_t n, void *stream);
+/* Device twins of mzd_transpose and mzd_trtri_upper.  m4ri_amd_transpose_dev: D (ncols x nrows) <- A^T, D must not
+ * overlap A; one HBM-bound launch (A read once, D written once, whole 128-byte lines on both sides); asynchronous.
+ * m4ri_amd_trtri_upper_dev: U (n x n) <- U^-1, only the bits strictly above the diagonal are read and written;
+ * asynchronous on `stream`, scratch grow-only per device. */
+int m4ri_amd_transpose_dev(word *D, int64_t d_stride, const word *A, int64_t a_stride, int64_t nrows, int64_t ncols, void *stream);
+int m4ri_amd_trtri_upper_dev(word *U, int64_t stride, int64_t n, void *stream);
 /* Device twins of mzd_echelonize* and mzd_apply_p_right{,_trans} (echelon.hip).  P: HOST array.  Blocking. */
 int m4ri_amd_echelonize_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int full, int32_t *rank_out, void *stream);
 int m4ri_amd_apply_p_right_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, const int32_t *P, int64_t length, int trans, void *stream);

@@ -143,6 +143,11 @@ SYMBOLS = {
     "m4ri_amd_solve_left_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I, _I, _P, _P]),
     "m4ri_amd_kernel_left_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P, _P]),
     "m4ri_amd_inv_dev": (_I, [_P, _I64, _P, _I64, _I64, _P]),
+    "mzd_transpose": (MzdPtr, [MzdPtr, MzdPtr]),
+    "mzd_trtri_upper": (MzdPtr, [MzdPtr]),
+    "mzd_trtri_upper_russian": (MzdPtr, [MzdPtr, _I]),
+    "m4ri_amd_transpose_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _P]),
+    "m4ri_amd_trtri_upper_dev": (_I, [_P, _I64, _I64, _P]),
     "m4ri_amd_echelonize_dev": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
     "m4ri_amd_apply_p_right_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),
     "m4ri_amd_mzd_init": (MzdPtr, [_I, _I]),
@@ -337,6 +342,21 @@ def mzd_inv_m4ri(A: Mzd, B: Mzd = None) -> Mzd:
     """B <- A^-1 (reference m4ri/brilliantrussian.h:256)."""
     r = lib().mzd_inv_m4ri(B.ptr if B is not None else None, A.ptr, 0)
     return B if B is not None else from_struct_ptr(r, lib().m4ri_amd_result_free)
+
+
+def mzd_transpose(A: Mzd, DST: Mzd = None) -> Mzd:
+    """DST <- A^T (reference m4ri/mzd.h:611)."""
+    r = lib().mzd_transpose(DST.ptr if DST is not None else None, A.ptr)
+    return DST if DST is not None else from_struct_ptr(r, lib().m4ri_amd_result_free)
+
+
+def mzd_trtri_upper(A: Mzd, which: str = "mzd_trtri_upper") -> Mzd:
+    """A <- A^-1 in place, A unit upper triangular (reference m4ri/triangular.h:163, triangular_russian.h:66)."""
+    if which == "mzd_trtri_upper":
+        lib().mzd_trtri_upper(A.ptr)
+    else:
+        lib().mzd_trtri_upper_russian(A.ptr, 0)
+    return A
 
 
 def mzd_apply_p_right_trans_tri(A: Mzd, Q) -> None:

@@ -804,6 +804,51 @@ mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k) {  // brilliantrussian.c:97
   return B;
 }
 
+// ---- transposes and triangular inverses (transpose.hip, trsm.hip) ----------------------------------------------------
+mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {  // mzd.c:1118-1139
+  if (DST == nullptr) DST = result_init(A->ncols, A->nrows);
+  else if (DST->nrows != A->ncols || DST->ncols != A->nrows) die("mzd_transpose: Wrong size for return matrix.\n");
+  if (A->nrows == 0 || A->ncols == 0) return DST;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  // the result is always built in staging: DST may be A itself, a window with neighbours in its last word, or pinned
+  arena_reserve((find_pin(A) ? 0 : dev_words(A->nrows, A->ncols)) + dev_words(DST->nrows, DST->ncols));
+  const DevMat dA = operand(A, true);
+  DevMat dD;
+  dev_alloc(dD, DST->nrows, DST->ncols);
+  HIPDIE(m4ri_amd_transpose_dev(dD.p, dD.stride, dA.p, dA.stride, A->nrows, A->ncols, nullptr));
+  if (Pin *pd = find_pin(DST)) {
+    const DevMat dst = operand(DST, false);
+    HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, dD.p, dD.stride, DST->nrows, DST->ncols));
+    pd->dev_newer = true;
+  } else {
+    download(dD, DST);
+  }
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return DST;
+}
+
+static mzd_t *run_trtri_upper(mzd_t *A, const char *who) {  // triangular.c:518-547, triangular_russian.c:384-470
+  if (A->nrows != A->ncols) die("%s: matrix must be square and is found to be (%d) x (%d).\n", who, A->nrows, A->ncols);
+  if (A->nrows <= 1) return A;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  int dev = 0;
+  HIPDIE(hipGetDevice(&dev));
+  HIPDIE(m4ri_amd_init(dev));
+  arena_reserve(inout_words(A));
+  InOut io = inout_begin(A);
+  HIPDIE(m4ri_amd_trtri_upper_dev(io.d.p, io.d.stride, A->nrows, nullptr));
+  inout_end(io, A);
+  HIPDIE(hipDeviceSynchronize());
+  g_api_stats.calls += 1;
+  return A;
+}
+mzd_t *mzd_trtri_upper(mzd_t *A) { return run_trtri_upper(A, "mzd_trtri_upper"); }
+mzd_t *mzd_trtri_upper_russian(mzd_t *A, int k) { (void)k; return run_trtri_upper(A, "mzd_trtri_upper_russian"); }
+
 // ---- the table primitives of the elimination routines (elim.hip) -------------------------
 static word *arena_raw(size_t words) {  // plain words from the staging arena (256-byte granules)
   word *p = g_arena.base + g_arena.used;

@@ -329,3 +329,104 @@ int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64
 }
 
 }  // extern "C"
+
+// ---- inverse of a unit upper triangular matrix, in place ------------------------------------------------------------
+// mzd_trtri_upper (triangular.c:518-547: halves, two TRSMs on the off-diagonal block, recursion) and its base case
+// mzd_trtri_upper_russian (triangular_russian.c:384-470: column by column inside k-bit blocks, the rows above through
+// tables).  The inverse is unique, so the schedule is free; here it runs bottom-up on a clean copy W of the triangle
+// (strict upper part + unit diagonal, nothing else -- the caller's diagonal and lower triangle are neither read nor
+// written, as in the reference):
+//   1. all diagonal blocks of 512 rows inverted in one launch (the TRSM kernel above) and put back into W;
+//   2. for s = 512, 1024, ...: every pair of finished s-blocks [X00 ; X11] closes its off-diagonal block with two engine
+//      products,  W01 <- X00 * W01 * X11  ((U^-1)01 = U00^-1 U01 U11^-1 over GF(2));  254 products at n = 65536 instead of
+//      the ~1800 small ones a top-down recursion over TRSMs would launch;
+//   3. the strict upper triangle of W goes back into the caller's matrix.
+namespace {
+
+__device__ __forceinline__ word strict_upper_mask(int64_t i, int64_t w) {  // bits of word w at columns > i
+  const int64_t c0 = w * 64;
+  if (c0 > i) return ~(word)0;
+  if (c0 + 63 <= i) return 0;
+  return ((~(word)0) << (i - c0)) << 1;
+}
+
+__global__ __launch_bounds__(256) void trtri_clean_kernel(word *__restrict__ W, int64_t ws, const word *__restrict__ U, int64_t us,
+                                                          int64_t n, int64_t wn) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * wn) return;
+  const int64_t i = idx / wn, w = idx - i * wn;
+  word v = U[i * us + w] & strict_upper_mask(i, w);
+  if ((i >> 6) == w) v |= (word)1 << (i & 63);
+  if (w == wn - 1 && (n & 63)) v &= (~(word)0) >> (64 - (n & 63));
+  W[i * ws + w] = v;
+}
+
+__global__ __launch_bounds__(TB) void trtri_scatter_kernel(word *__restrict__ W, int64_t ws, const word *__restrict__ inv, int64_t n,
+                                                           int64_t wn) {
+  const int64_t r0 = (int64_t)blockIdx.x * TB, i = r0 + threadIdx.x;
+  if (i >= n) return;
+  const word *src = inv + ((int64_t)blockIdx.x * TB + threadIdx.x) * (TB / 64);
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w)
+    if (r0 / 64 + w < wn) W[i * ws + r0 / 64 + w] = src[w];
+}
+
+__global__ __launch_bounds__(256) void trtri_merge_kernel(word *__restrict__ U, int64_t us, const word *__restrict__ W, int64_t ws,
+                                                          int64_t n, int64_t wn) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * wn) return;
+  const int64_t i = idx / wn, w = idx - i * wn;
+  word m = strict_upper_mask(i, w);
+  if (w == wn - 1 && (n & 63)) m &= (~(word)0) >> (64 - (n & 63));
+  if (m == 0) return;
+  word *p = U + i * us + w;
+  *p = (*p & ~m) | (W[i * ws + w] & m);
+}
+
+struct TrtriScratch { word *buf = nullptr; size_t words = 0; };
+TrtriScratch g_trtri_scratch[16];
+
+int trtri_upper(word *U, int64_t us, int64_t n, hipStream_t st) {
+  if (n <= 1) return 0;
+  std::lock_guard<std::mutex> lk(g_trsm_mu);
+  int dev = 0;
+  HIPTRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  const int64_t wn = words_of(n), ws = (wn + 1) & ~(int64_t)1, nblk = (n + TB - 1) / TB;
+  int64_t smax = TB;
+  while (smax * 2 < n) smax *= 2;  // the largest level: pairs of smax-blocks
+  const int64_t wt = (words_of(smax) + 1) & ~(int64_t)1;
+  const size_t w_words = (size_t)n * (size_t)ws, t_words = (n > TB) ? (size_t)smax * (size_t)wt : 0,
+               inv_words = (size_t)nblk * TB * (TB / 64);
+  TrtriScratch &s = g_trtri_scratch[dev];
+  if (w_words + t_words + inv_words > s.words) {
+    if (s.buf) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.buf)); }
+    s.buf = nullptr; s.words = 0;
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.buf), (w_words + t_words + inv_words) * 8));
+    s.words = w_words + t_words + inv_words;
+  }
+  word *W = s.buf, *T = W + w_words, *inv = T + t_words;
+  const unsigned g = (unsigned)((n * wn + 255) / 256);
+  hipLaunchKernelGGL(trtri_clean_kernel, dim3(g), dim3(256), 0, st, W, ws, U, us, n, wn);
+  hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, W, ws, n, inv);
+  hipLaunchKernelGGL(trtri_scatter_kernel, dim3((unsigned)nblk), dim3(TB), 0, st, W, ws, inv, n, wn);
+  HIPTRY(hipGetLastError());
+  for (int64_t sz = TB; sz < n; sz *= 2)
+    for (int64_t r0 = 0; r0 + sz < n; r0 += 2 * sz) {
+      const int64_t mid = r0 + sz, s2 = (n - mid) < sz ? (n - mid) : sz;
+      word *W00 = W + r0 * ws + r0 / 64, *W01 = W + r0 * ws + mid / 64, *W11 = W + mid * ws + mid / 64;
+      HIPTRY(m4ri_amd_mul_dev(T, wt, W00, ws, W01, ws, sz, sz, s2, 0, 0, st));
+      HIPTRY(m4ri_amd_mul_dev(W01, ws, T, wt, W11, ws, sz, s2, s2, 0, 0, st));
+    }
+  hipLaunchKernelGGL(trtri_merge_kernel, dim3(g), dim3(256), 0, st, U, us, W, ws, n, wn);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// U (n x n bits) <- U^-1 for a unit upper triangular U: only the bits strictly above the diagonal are read and written.
+// Device pointer; asynchronous on `stream` (the scratch is grow-only per device, calls are serialised by a mutex).
+extern "C" int m4ri_amd_trtri_upper_dev(word *U, int64_t stride, int64_t n, void *stream) {
+  if (n < 0) return (int)hipErrorInvalidValue;
+  return trtri_upper(U, stride, n, (hipStream_t)stream);
+}

@@ -747,6 +747,34 @@ int32_t gf2o_kernel_left_pluq(gf2o_mat *A, gf2o_mat *R) {
   return r;
 }
 
+/* mzd_transpose (mzd.c:1118-1139): DST <- A^T, bit by bit (the reference's block schedule, mzd.c:700-1100, only decides
+ * in which order the bits move).  DST's bits beyond its columns are kept. */
+void gf2o_transpose(gf2o_mat *DST, const gf2o_mat *A) {
+  if (DST->nrows != A->ncols || DST->ncols != A->nrows) die("mzd_transpose: Wrong size for return matrix.\n");
+  for (int64_t i = 0; i < DST->nrows; ++i)
+    for (int64_t w = 0; w < DST->width; ++w) {
+      gf2o_word v = 0;
+      const int64_t jn = (w == DST->width - 1 && DST->ncols % 64) ? DST->ncols % 64 : 64;
+      for (int64_t j = 0; j < jn; ++j) v |= (gf2o_word)o_bit(A, w * 64 + j, i) << j;
+      gf2o_word *d = DST->data + i * DST->rowstride + w;
+      const gf2o_word m = (w == DST->width - 1) ? DST->high_bitmask : ~(gf2o_word)0;
+      *d = (*d & ~m) | (v & m);
+    }
+}
+
+/* mzd_trtri_upper / mzd_trtri_upper_russian (triangular.c:518-547, triangular_russian.c:378-470): A <- A^-1 in place for
+ * a unit upper triangular A.  The reference's base step, _mzd_trtri_upper_submatrix (triangular_russian.c:378-382),
+ * applied to the whole matrix: columns left to right, row i added from column i + 1 on to every row above it that has a
+ * bit in column i.  The reference applies it inside k-bit blocks and reaches the rows above a block through tables,
+ * and above 2 * L3 bits it halves and closes the off-diagonal block with two TRSMs; the inverse being unique, those
+ * change the order of the row additions, not the result.  Diagonal and lower triangle: never read, never written. */
+void gf2o_trtri_upper(gf2o_mat *A) {
+  if (A->nrows != A->ncols) die("mzd_trtri_upper: matrix must be square.\n");
+  for (int64_t i = 1; i < A->nrows; ++i)
+    for (int64_t j = 0; j < i; ++j)
+      if (o_bit(A, j, i)) o_row_add_from(A, j, i, i + 1);
+}
+
 /* mzd_inv_m4ri (brilliantrussian.c:971-997): the right block of the reduced row echelon form of [A | 0 | I] */
 void gf2o_inv(gf2o_mat *B, const gf2o_mat *A) {
   const int64_t n = A->nrows, nr = 64 * A->width;

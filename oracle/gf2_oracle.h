@@ -111,6 +111,11 @@ int gf2o_solve_left(gf2o_mat *A, gf2o_mat *B, int check);
 int32_t gf2o_kernel_left_pluq(gf2o_mat *A, gf2o_mat *R);
 void gf2o_inv(gf2o_mat *B, const gf2o_mat *A);
 
+/* mzd_transpose (m4ri/mzd.c:1118-1139) and the in-place inverse of a unit upper triangular matrix, mzd_trtri_upper /
+ * mzd_trtri_upper_russian (m4ri/triangular.c:518-547, triangular_russian.c:378-470). */
+void gf2o_transpose(gf2o_mat *DST, const gf2o_mat *A);
+void gf2o_trtri_upper(gf2o_mat *A);
+
 /* table primitives of the elimination routines: m4ri/brilliantrussian.c:163-211 (mzd_make_table: the Gray-code
  * chain T[i] = T[i-1] ^ M[r + inc[i-1]], first word masked below column c, last by the column mask, L[ord[i]] = i,
  * steps whose row does not exist skipped) and :213-601 (mzd_process_rows, 2..6: nt tables, the k-bit strip cut as

@@ -52,6 +52,8 @@ class Oracle:
             "gf2o_solve_left": (ctypes.c_int, [MzdPtr, MzdPtr, ctypes.c_int]),
             "gf2o_kernel_left_pluq": (ctypes.c_int32, [MzdPtr, MzdPtr]),
             "gf2o_inv": (None, [MzdPtr, MzdPtr]),
+            "gf2o_transpose": (None, [MzdPtr, MzdPtr]),
+            "gf2o_trtri_upper": (None, [MzdPtr]),
             "gf2o_ple_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_pluq_recursive": (ctypes.c_int32, [MzdPtr, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
             "gf2o_make_table": (None, [MzdPtr, _I, _I, _I, MzdPtr, ctypes.c_void_p]),
@@ -134,6 +136,17 @@ class Oracle:
         B = Mzd(A.nrows, A.ncols)
         self.L.gf2o_inv(B.ptr, A.ptr)
         return B
+
+    def transpose(self, A, DST=None):
+        from m4ri_amd.mzd import Mzd
+        if DST is None:
+            DST = Mzd(A.ncols, A.nrows)
+        self.L.gf2o_transpose(DST.ptr, A.ptr)
+        return DST
+
+    def trtri_upper(self, A):
+        self.L.gf2o_trtri_upper(A.ptr)
+        return A
 
     PLE_CUTOFF = 524288  # __M4RI_PLE_CUTOFF (m4ri/ple.h:40) of any build with an L3 of 4 MiB or more
 
@@ -221,6 +234,9 @@ class Reference:
         L.mzd_pluq_solve_left.restype, L.mzd_pluq_solve_left.argtypes = _I, [MzdPtr, _I, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), MzdPtr, _I, _I]
         L.mzd_kernel_left_pluq.restype, L.mzd_kernel_left_pluq.argtypes = MzdPtr, [MzdPtr, _I]
         L.mzd_inv_m4ri.restype, L.mzd_inv_m4ri.argtypes = MzdPtr, [MzdPtr, MzdPtr, _I]
+        L.mzd_transpose.restype, L.mzd_transpose.argtypes = MzdPtr, [MzdPtr, MzdPtr]
+        L.mzd_trtri_upper.restype, L.mzd_trtri_upper.argtypes = MzdPtr, [MzdPtr]
+        L.mzd_trtri_upper_russian.restype, L.mzd_trtri_upper_russian.argtypes = MzdPtr, [MzdPtr, _I]
         self.has_mp = hasattr(L, "mzd_mul_mp")
         if self.has_mp:
             L.mzd_mul_mp.restype, L.mzd_mul_mp.argtypes = sig4
@@ -276,6 +292,16 @@ class Reference:
 
     def inv(self, A):
         return from_struct_ptr(self.L.mzd_inv_m4ri(None, A.ptr, 0), self.L.mzd_free)
+
+    def transpose(self, A, DST=None):
+        return self._ret(DST, self.L.mzd_transpose(DST.ptr if DST is not None else None, A.ptr))
+
+    def trtri_upper(self, A, which="mzd_trtri_upper", k=0):
+        if which == "mzd_trtri_upper":
+            self.L.mzd_trtri_upper(A.ptr)
+        else:
+            self.L.mzd_trtri_upper_russian(A.ptr, k)
+        return A
 
     def ple(self, A, which="_mzd_ple_russian", k=0):
         """In place; returns (rank, P, Q)."""

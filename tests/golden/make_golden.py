@@ -325,8 +325,40 @@ def echelon_fixtures():
     json.dump(out, open(os.path.join(HERE, "echelon.json"), "w"), indent=1)
 
 
+TRTRI_CASES = [(8192 + 192, 61), (16384, 62), (20000, 63), (32768, 64)]
+TRANSPOSE_CASES = [(20000, 30001, 71), (4099, 65536, 72), (65536, 32768, 73)]
+
+
+def trtri_transpose_fixtures():
+    """mzd_trtri_upper (triangular.c:518-547: every case here takes its halving path) and mzd_transpose (mzd.c:1118-1139) of
+    the real reference; SHA-256 over the result's valid words -> trtri_transpose.json.  The inputs are the ones
+    tests/test_transpose_trtri_oracle.py's unit_upper(n, seed, keep_lower=True) and Mzd.random(m, n, seed) build."""
+    import hashlib
+    import json
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_transpose_trtri_oracle import unit_upper
+    out = []
+    for n, seed in TRTRI_CASES:
+        U = unit_upper(n, seed, True)
+        t = time.time()
+        ref.trtri_upper(U)
+        h = hashlib.sha256(U.masked().tobytes()).hexdigest()
+        print("trtri", n, h[:16], f"{time.time() - t:.1f}s", flush=True)
+        out.append({"op": "trtri", "n": n, "seed": seed, "sha256": h})
+    for m, n, seed in TRANSPOSE_CASES:
+        A = Mzd.random(m, n, seed)
+        t = time.time()
+        T = ref.transpose(A)
+        h = hashlib.sha256(T.masked().tobytes()).hexdigest()
+        print("transpose", m, n, h[:16], f"{time.time() - t:.1f}s", flush=True)
+        out.append({"op": "transpose", "m": m, "n": n, "seed": seed, "sha256": h})
+    json.dump(out, open(os.path.join(HERE, "trtri_transpose.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if "--echelon" in sys.argv:
+    if "--trtri" in sys.argv:
+        trtri_transpose_fixtures()
+    elif "--echelon" in sys.argv:
         echelon_fixtures()
     elif "--pluq" in sys.argv:
         pluq_fixtures()

@@ -35,6 +35,10 @@ CASES = {
     "solve_left_b_rows": ("m4ri_amd.mzd_solve_left(Mzd.init(4, 6), Mzd.init(5, 3))", "mzd_solve_left: A ncols (6) must be smaller than B nrows (5)"),
     "solve_left_b_rows_max": ("m4ri_amd.mzd_solve_left(Mzd.init(6, 4), Mzd.init(5, 3))", "mzd_solve_left: B nrows (5) must be equal to max of A nrows (6) and A ncols (4)"),
     "inv_not_square": ("m4ri_amd.mzd_inv_m4ri(Mzd.init(4, 5))", "mzd_inv_m4ri: A must be square"),
+    # mzd.c:1121-1123
+    "transpose_dst_size": ("m4ri_amd.mzd_transpose(Mzd.init(4, 5), Mzd.init(4, 5))", "mzd_transpose: Wrong size for return matrix."),
+    # triangular_russian.c:385 (an assert there)
+    "trtri_not_square": ("m4ri_amd.mzd_trtri_upper(Mzd.init(4, 5))", "mzd_trtri_upper: matrix must be square"),
 }
 
 
