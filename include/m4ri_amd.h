@@ -236,6 +236,10 @@ int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride,
 int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                       int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit,
                       void *stream);
+/* `batch` products of one shape in ONE launch: C_b (+)= A_b * B_b, X_b = X + b * x_bs (word offsets).  Plain M4RM leaves
+ * (no Strassen levels): for the many small equal products of a blocked algorithm. */
+int m4ri_amd_m4rm_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
+                            int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, void *stream);
 /* C = A ^ B on rows x ncols bits: the device twin of _mzd_add (mzd.c:1471-1583).  In-place allowed,
  * operands may have different strides; the last word of every row is written under the column mask
  * and the other bits of C's last word are kept (mzd.c:1489). */

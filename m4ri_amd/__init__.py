@@ -147,6 +147,7 @@ SYMBOLS = {
     "mzd_trtri_upper": (MzdPtr, [MzdPtr]),
     "mzd_trtri_upper_russian": (MzdPtr, [MzdPtr, _I]),
     "m4ri_amd_transpose_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _P]),
+    "m4ri_amd_m4rm_batch_dev": (_I, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "m4ri_amd_trtri_upper_dev": (_I, [_P, _I64, _I64, _P]),
     "m4ri_amd_echelonize_dev": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
     "m4ri_amd_apply_p_right_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),

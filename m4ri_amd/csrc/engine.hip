@@ -725,6 +725,21 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
   return mark_done(e, (hipStream_t)stream);
 }
 
+// `batch` products of one shape in one launch, C_b (+)= A_b * B_b with X_b = X + b * x_bs words: plain M4RM leaves, no
+// Strassen levels -- for the many small equal products of a blocked algorithm (the levels of the triangular inverse,
+// trsm.hip), where one launch per product costs more than the product.
+int m4ri_amd_m4rm_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
+                            int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, void *stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Engine *e = engine_for_current_device();
+  if (!e || m < 0 || l < 0 || n < 0 || batch < 0) return (int)hipErrorInvalidValue;
+  if (batch == 0 || m == 0 || n == 0) return 0;
+  reset_stats(e);
+  if (int rc = order_after_previous(e, (hipStream_t)stream)) return rc;
+  if (int rc = launch_leaf(e, (hipStream_t)stream, C, c_stride, c_bs, A, a_stride, a_bs, B, b_stride, b_bs, m, l, n, batch, add != 0, 0)) return rc;
+  return mark_done(e, (hipStream_t)stream);
+}
+
 int m4ri_amd_xor_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t rows, int64_t ncols, void *stream) {
   return (int)gf2_launch_xor_masked((hipStream_t)stream, C, c_stride, A, a_stride, B, b_stride, rows, ncols);

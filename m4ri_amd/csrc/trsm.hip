@@ -339,7 +339,8 @@ int m4ri_amd_trsm_upper_left_dev(const word *U, int64_t t_stride, word *B, int64
 //   1. all diagonal blocks of 512 rows inverted in one launch (the TRSM kernel above) and put back into W;
 //   2. for s = 512, 1024, ...: every pair of finished s-blocks [X00 ; X11] closes its off-diagonal block with two engine
 //      products,  W01 <- X00 * W01 * X11  ((U^-1)01 = U00^-1 U01 U11^-1 over GF(2));  254 products at n = 65536 instead of
-//      the ~1800 small ones a top-down recursion over TRSMs would launch;
+//      the ~1800 small ones a top-down recursion over TRSMs would launch, and the levels up to 4096 -- 240 of the 254 --
+//      are two batched launches each;
 //   3. the strict upper triangle of W goes back into the caller's matrix.
 namespace {
 
@@ -384,6 +385,9 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(word *__restrict__ U, 
 }
 
 struct TrtriScratch { word *buf = nullptr; size_t words = 0; };
+#ifndef TRTRI_BATCH_MAX
+#define TRTRI_BATCH_MAX 4096  // levels up to this block size run as batched launches
+#endif
 TrtriScratch g_trtri_scratch[16];
 
 int trtri_upper(word *U, int64_t us, int64_t n, hipStream_t st) {
@@ -411,13 +415,25 @@ int trtri_upper(word *U, int64_t us, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, W, ws, n, inv);
   hipLaunchKernelGGL(trtri_scatter_kernel, dim3((unsigned)nblk), dim3(TB), 0, st, W, ws, inv, n, wn);
   HIPTRY(hipGetLastError());
-  for (int64_t sz = TB; sz < n; sz *= 2)
-    for (int64_t r0 = 0; r0 + sz < n; r0 += 2 * sz) {
+  for (int64_t sz = TB; sz < n; sz *= 2) {
+    int64_t r0 = 0;
+    // the complete pairs of a small level are one batched launch each way (a pair starts every 2 sz rows and 2 sz columns,
+    // so the batch stride is constant): 240 of the 254 products at n = 65536 are in the levels up to 4096, launch-bound
+    // one by one (~35 us each)
+    const int64_t full = n / (2 * sz);
+    if (sz <= TRTRI_BATCH_MAX && full > 1) {
+      const int64_t wsz = sz / 64, pair = 2 * sz * ws + 2 * wsz;
+      HIPTRY(m4ri_amd_m4rm_batch_dev(T, wsz, sz * wsz, W, ws, pair, W + wsz, ws, pair, sz, sz, sz, full, 0, st));
+      HIPTRY(m4ri_amd_m4rm_batch_dev(W + wsz, ws, pair, T, wsz, sz * wsz, W + sz * ws + wsz, ws, pair, sz, sz, sz, full, 0, st));
+      r0 = full * 2 * sz;
+    }
+    for (; r0 + sz < n; r0 += 2 * sz) {
       const int64_t mid = r0 + sz, s2 = (n - mid) < sz ? (n - mid) : sz;
       word *W00 = W + r0 * ws + r0 / 64, *W01 = W + r0 * ws + mid / 64, *W11 = W + mid * ws + mid / 64;
       HIPTRY(m4ri_amd_mul_dev(T, wt, W00, ws, W01, ws, sz, sz, s2, 0, 0, st));
       HIPTRY(m4ri_amd_mul_dev(W01, ws, T, wt, W11, ws, sz, s2, s2, 0, 0, st));
     }
+  }
   hipLaunchKernelGGL(trtri_merge_kernel, dim3(g), dim3(256), 0, st, U, us, W, ws, n, wn);
   return (int)hipGetLastError();
 }
