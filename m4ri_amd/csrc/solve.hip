@@ -227,14 +227,34 @@ int m4ri_amd_kernel_left_pluq_dev(word *A, int64_t a_stride, int64_t m, int64_t 
 
 // mzd_inv_m4ri (brilliantrussian.c:971-997): Binv (n x n, device) <- the right block of the reduced row echelon form of
 // [A | 0 | I] (2 * 64 * ceil(n / 64) columns): A^-1 when A is invertible, whatever the elimination leaves otherwise.
+// An invertible A has one inverse however it is reached, so the common case takes the cheaper road -- PLUQ of A itself
+// (n columns instead of 2n), then A X = I through the decomposition (solve.c:41-97 with B = I) -- and only a singular A
+// goes through the reference's augmented elimination, whose leftovers are part of its result.
 int m4ri_amd_inv_dev(word *Binv, int64_t b_stride, const word *A, int64_t a_stride, int64_t n, void *stream) {
   if (n < 0) return (int)hipErrorInvalidValue;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t wn = words_of(n), cw = 2 * wn;
+  const int64_t wn = words_of(n), cw = 2 * wn, ws = (wn + 1) & ~(int64_t)1;
   word *C = nullptr;
-  HIPTRY(hipMalloc(reinterpret_cast<void **>(&C), (size_t)n * cw * 8));
-  auto run = [&]() -> int {
+  HIPTRY(hipMalloc(reinterpret_cast<void **>(&C), (size_t)n * (size_t)(cw > ws ? cw : ws) * 8));
+  auto by_decomposition = [&](bool &done) -> int {
+    done = false;
+    HIPTRY(hipMemcpy2DAsync(C, (size_t)ws * 8, A, (size_t)a_stride * 8, (size_t)wn * 8, (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (ws != wn) HIPTRY(hipMemset2DAsync(C + wn, (size_t)ws * 8, 0, 8, (size_t)n, st));
+    HIPTRY(m4ri_amd_mask_tail_dev(C, ws, n, n, st));
+    std::vector<int32_t> P((size_t)n), Q((size_t)n);
+    int32_t rank = 0;
+    if (int rc = m4ri_amd_pluq_dev(C, ws, n, n, P.data(), Q.data(), &rank, 0, st)) return rc;
+    if (rank != n) return 0;
+    HIPTRY(hipMemset2DAsync(Binv, (size_t)b_stride * 8, 0, (size_t)wn * 8, (size_t)n, st));
+    hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Binv, b_stride, (int64_t)0, (int64_t)0, n);
+    HIPTRY(hipGetLastError());
+    int ret = 0;
+    if (int rc = m4ri_amd_pluq_solve_left_dev(C, ws, n, n, rank, P.data(), Q.data(), Binv, b_stride, n, n, 0, 0, &ret, st)) return rc;
+    done = true;
+    return (int)hipStreamSynchronize(st);
+  };
+  auto by_elimination = [&]() -> int {
     HIPTRY(hipMemsetAsync(C, 0, (size_t)n * cw * 8, st));
     HIPTRY(hipMemcpy2DAsync(C, (size_t)cw * 8, A, (size_t)a_stride * 8, (size_t)wn * 8, (size_t)n, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, cw, (int64_t)0, wn * 64, n);
@@ -244,7 +264,9 @@ int m4ri_amd_inv_dev(word *Binv, int64_t b_stride, const word *A, int64_t a_stri
     HIPTRY(hipMemcpy2DAsync(Binv, (size_t)b_stride * 8, C + wn, (size_t)cw * 8, (size_t)wn * 8, (size_t)n, hipMemcpyDeviceToDevice, st));
     return (int)hipStreamSynchronize(st);
   };
-  const int rc = run();
+  bool done = false;
+  int rc = by_decomposition(done);
+  if (rc == 0 && !done) rc = by_elimination();
   (void)hipFree(C);
   return rc;
 }

@@ -31,6 +31,7 @@ int main(int argc, char **argv) {
   }
   const int only_new = argc > 2 && argv[2][0] == 'n'; /* "new": only mzd_trtri_upper and mzd_transpose (the others take minutes on the CPU) */
   double t;
+  word f9 = 0;
   mzd_t *X = mzd_copy(NULL, B), *A2 = mzd_copy(NULL, A), *A4 = mzd_copy(NULL, A), *A3 = mzd_copy(NULL, A), *Y = mzd_copy(NULL, B), *A5 = mzd_copy(NULL, A), *Ai = A;
   mzp_t *P = mzp_init(n), *Q = mzp_init(n);
   rci_t r;
@@ -52,9 +53,23 @@ int main(int argc, char **argv) {
   t = now();
   r = mzd_echelonize(A5, 1);
   printf("  mzd_echelonize full %d x %d : %.3f s (rank %d)\n", n, n, now() - t, r);
+  /* an invertible matrix the way bench/bench_invert.c:18-40 builds one: unit lower triangular times unit upper triangular
+   * (a random matrix of this size is singular more often than not, and mzd_inv_m4ri is meant for the other case) */
+  mzd_t *Lm = mzd_copy(NULL, B);
+  for (rci_t i = 0; i < n; ++i) {
+    for (wi_t w = i / 64 + 1; w < Lm->width; ++w) mzd_row(Lm, i)[w] = 0;
+    mzd_row(Lm, i)[i / 64] &= ((word)1 << (i % 64)) - 1;
+    mzd_row(Lm, i)[i / 64] |= (word)1 << (i % 64);
+  }
+  mzd_t *LU = mzd_mul(NULL, Lm, U, 0);
   t = now();
-  Ai = mzd_inv_m4ri(NULL, A, 0);
-  printf("  mzd_inv_m4ri        %d x %d : %.3f s\n", n, n, now() - t);
+  Ai = mzd_inv_m4ri(NULL, LU, 0);
+  printf("  mzd_inv_m4ri        %d x %d : %.3f s (invertible input)\n", n, n, now() - t);
+  t = now();
+  mzd_t *As = mzd_inv_m4ri(NULL, A, 0);
+  printf("  mzd_inv_m4ri        %d x %d : %.3f s (singular input: the augmented elimination's leftovers)\n", n, n, now() - t);
+  for (rci_t i = 0; i < n; ++i)
+    for (wi_t w = 0; w < As->width; ++w) f9 = f9 * 1099511628211ull ^ mzd_row(As, i)[w];
   }
   mzd_t *Ui = mzd_copy(NULL, U);
   t = now();
@@ -70,8 +85,8 @@ int main(int argc, char **argv) {
       f3 = f3 * 1099511628211ull ^ mzd_row(A4, i)[w]; f4 = f4 * 1099511628211ull ^ mzd_row(Y, i)[w];
       f5 = f5 * 1099511628211ull ^ mzd_row(A5, i)[w]; f6 = f6 * 1099511628211ull ^ mzd_row(Ai, i)[w];
       f7 = f7 * 1099511628211ull ^ mzd_row(Ui, i)[w]; f8 = f8 * 1099511628211ull ^ mzd_row(At, i)[w]; }
-  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx echelon %016llx inverse %016llx trtri %016llx transpose %016llx\n",
+  printf("  fingerprints: trsm %016llx ple %016llx pluq %016llx solve %016llx echelon %016llx inverse %016llx trtri %016llx transpose %016llx inverse(singular) %016llx\n",
          (unsigned long long)f1, (unsigned long long)f2, (unsigned long long)f3, (unsigned long long)f4, (unsigned long long)f5, (unsigned long long)f6,
-         (unsigned long long)f7, (unsigned long long)f8);
+         (unsigned long long)f7, (unsigned long long)f8, (unsigned long long)f9);
   return 0;
 }
