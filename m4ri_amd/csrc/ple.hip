@@ -600,6 +600,47 @@ __global__ __launch_bounds__(QT_THREADS) void qtri_gather_kernel(word *__restric
   }
 }
 
+// ---- 6. the panel step ---------------------------------------------------------------------------------------------
+// The blocks of 64 columns update only the words of their own panel (PLE_PANEL_WORDS words = 1024 columns); what lies to
+// the right of the panel is brought up to date once per panel:  U12 = L11^-1 * T1  on the panel's pivot rows (the TRSM of
+// trsm.hip against the multipliers among the pivot rows themselves), then  T2 ^= L21 * U12  on the rows below -- one
+// engine product with the multipliers where the decomposition stores them, in the panel's columns of A.  Both work in
+// "panel column" coordinates: row j of Lsq / Ubuf belongs to the panel's column j, and is zero when that column has no
+// pivot (rows below have zeros there as well).  The streaming rank-64 updates over the whole trailing matrix -- 366 GB
+// of HBM traffic in a 65536^2 decomposition, 100 of its 154 ms -- become 128 products.
+__global__ __launch_bounds__(256) void ple_panel_gather_kernel(const word *__restrict__ A, int64_t stride, int64_t pw0, int pwn, int64_t pend,
+                                                               int64_t wtrail, const int32_t *__restrict__ rowmap, word *__restrict__ Lsq,
+                                                               word *__restrict__ Ubuf, int64_t ustride) {
+  const int j       = blockIdx.x;  // panel column
+  const int32_t src = rowmap[j];
+  if (threadIdx.x < pwn) {
+    const int w = threadIdx.x;
+    word v = 0;
+    if (src >= 0) {
+      word piv = 0;  // the pivot columns of word w, below column j
+      for (int b = 0; b < 64; ++b)
+        if (64 * w + b < j && rowmap[64 * w + b] >= 0) piv |= (word)1 << b;
+      v = A[(int64_t)src * stride + pw0 + w] & piv;
+    }
+    Lsq[(int64_t)j * pwn + w] = v;
+  }
+  const word *row = src >= 0 ? A + (int64_t)src * stride + pend : nullptr;
+  for (int64_t w = threadIdx.x; w < ustride; w += 256) Ubuf[(int64_t)j * ustride + w] = (row && w < wtrail) ? row[w] : 0;
+}
+
+__global__ __launch_bounds__(256) void ple_panel_scatter_kernel(word *__restrict__ A, int64_t stride, int64_t pend, int64_t wtrail,
+                                                                const int32_t *__restrict__ rowmap, const word *__restrict__ Ubuf, int64_t ustride) {
+  const int32_t dst = rowmap[blockIdx.x];
+  if (dst < 0) return;
+  word *row = A + (int64_t)dst * stride + pend;
+  for (int64_t w = threadIdx.x; w < wtrail; w += 256) row[w] = Ubuf[(int64_t)blockIdx.x * ustride + w];
+}
+
+#ifndef PLE_PANEL_WORDS
+#define PLE_PANEL_WORDS 16  // words of a panel: 1024 columns (8 / 16 / 32: 122 / 117.5 / 117 ms at 65536^2, 20.6 / 19.1 / 18.3 at 16384^2) (M4RI_AMD_PLE_PANEL overrides, up to PLE_PANEL_MAX)
+#endif
+#define PLE_PANEL_MAX 32
+
 // ---- per-device scratch ------------------------------------------------------------------------------------------
 struct Scratch {
   word *V = nullptr, *Mc = nullptr, *Lc = nullptr, *pivmask = nullptr;
@@ -607,6 +648,9 @@ struct Scratch {
   PleBlock *blk = nullptr;
   PleBlock *hblk = nullptr;  // pinned host mirror
   int *lastrow = nullptr, *hlastrow = nullptr;
+  word *Lsq = nullptr, *Ubuf = nullptr;           // the panel step: multipliers among the pivot rows, the pivot rows' trailing parts
+  int32_t *rowmap = nullptr, *hrowmap = nullptr;  // panel column -> its pivot's row, or -1 (device; pinned host)
+  int64_t ubuf_words = 0;
   int64_t lc_blocks = 0;          // Lc holds 64 words per 64-column block of the matrix (a block's triangle is read later, on the side stream)
   hipStream_t side = nullptr;     // the pivot rows' own solves run here, off the critical path
   hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_copy = nullptr;
@@ -625,6 +669,18 @@ int reserve(Scratch &s, int64_t nrows, int64_t ncols) {
     HIPTRY(hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming));
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.lastrow), sizeof(int)));
     HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hlastrow), sizeof(int), hipHostMallocDefault));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Lsq), (size_t)PLE_PANEL_MAX * 64 * PLE_PANEL_MAX * 8));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.rowmap), (size_t)PLE_PANEL_MAX * 64 * 4));
+    HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&s.hrowmap), (size_t)2 * PLE_PANEL_MAX * 64 * 4, hipHostMallocDefault));  // two: see close_panel
+  }
+  {
+    const int64_t need = (int64_t)PLE_PANEL_MAX * 64 * ((words_of(ncols) + 1) & ~(int64_t)1);
+    if (need > s.ubuf_words) {
+      if (s.Ubuf) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.Ubuf)); }
+      s.Ubuf = nullptr; s.ubuf_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.Ubuf), (size_t)need * 8));
+      s.ubuf_words = need;
+    }
   }
   if (nrows > s.rows) {
     if (s.V) { HIPTRY(hipFree(s.V)); HIPTRY(hipFree(s.Mc)); }
@@ -670,7 +726,54 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
   const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
   static const bool wave_first = !(getenv("M4RI_AMD_PLE_WAVE") && atoi(getenv("M4RI_AMD_PLE_WAVE")) == 0);
   static const int variant     = getenv("M4RI_AMD_RU_TW") ? atoi(getenv("M4RI_AMD_RU_TW")) : RU_DEFAULT_TW;
+  static const bool panels = !(getenv("M4RI_AMD_PLE_PANELS") && atoi(getenv("M4RI_AMD_PLE_PANELS")) == 0);
+  static const int64_t panel_words = [] {
+    const char *e = getenv("M4RI_AMD_PLE_PANEL");
+    const int v   = e ? atoi(e) : PLE_PANEL_WORDS;
+    return (int64_t)(v < 1 ? 1 : v > PLE_PANEL_MAX ? PLE_PANEL_MAX : v);
+  }();
+  const int64_t wend = (c1 + 63) / 64;  // one past the last word of this run's columns
+  int64_t pw0 = -1, pend = width;       // the open panel: first word, one past its last word; pend = width: no panel step
+  int64_t prow0 = 0;                    // R.r0 when the panel was opened
+  int which = 0;                        // the host row map in use: the other one may still be on its way to the device
+  int32_t *hmap = s.hrowmap;
+  // bring the words to the right of the finished panel up to date (see "the panel step" above)
+  auto close_panel = [&]() -> int {
+    if (pw0 < 0) return 0;
+    const int64_t p0 = pw0, rp = R.r0 - prow0, pwn = pend - pw0, wtrail = width - pend;
+    pw0 = -1;
+    if (rp == 0 || wtrail <= 0) return 0;
+    const int64_t ustride = (wtrail + 1) & ~(int64_t)1, trailcols = ncols - pend * 64;
+    if (R.side_used) {  // the pivot rows' solves inside the panel write words the gather reads around
+      HIPTRY(hipEventRecord(s.ev_side, s.side));
+      HIPTRY(hipStreamWaitEvent(st, s.ev_side, 0));
+    }
+    HIPTRY(hipMemcpyAsync(s.rowmap, hmap, (size_t)pwn * 64 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ple_panel_gather_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, p0, (int)pwn, pend, wtrail, s.rowmap, s.Lsq,
+                       s.Ubuf, ustride);
+    HIPTRY(hipGetLastError());
+    HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lsq, pwn, s.Ubuf, ustride, pwn * 64, trailcols, 0, st));
+    hipLaunchKernelGGL(ple_panel_scatter_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, pend, wtrail, s.rowmap, s.Ubuf, ustride);
+    HIPTRY(hipGetLastError());
+    if (nrows - R.r0 > 0)
+      HIPTRY(m4ri_amd_mul_dev(A + R.r0 * stride + pend, stride, A + R.r0 * stride + p0, stride, s.Ubuf, ustride, nrows - R.r0, pwn * 64, trailcols, 1, 0,
+                              st));
+    // the next panel fills the OTHER host map; this one is reused a panel later, by when at least one block's record has
+    // been waited for that follows this copy in the stream
+    which ^= 1;
+    hmap = s.hrowmap + which * PLE_PANEL_MAX * 64;
+    return 0;
+  };
   for (int64_t wb = c0 / 64; wb * 64 < c1 && R.r0 < nrows; ++wb) {
+    if (panels && (pw0 < 0 || wb >= pend)) {
+      if (int rc = close_panel()) return rc;
+      pw0 = wb;
+      pend = (wb / panel_words + 1) * panel_words;
+      if (pend > wend) pend = wend;
+      prow0 = R.r0;
+      for (int64_t j = 0; j < (pend - pw0) * 64; ++j) hmap[j] = -1;
+      if (R.r0 >= nrows) break;
+    }
     const int64_t r0 = R.r0;
     const int ncb = (int)((c1 - wb * 64) < 64 ? (c1 - wb * 64) : 64);
     const int64_t nleft = nrows - r0;
@@ -679,9 +782,9 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
     // rows below, words to the right: C ^= (M L^-1) * U*, inner dimension = the block's rank, U* the pivot rows as they are;
     // dev_rank: the kernel takes the rank from the block's record (it is launched before the host has read it)
     auto update = [&](int rank, bool dev_rank) -> int {
-      if (wb + 1 >= width || nleft - rank <= 0) return 0;
+      if (wb + 1 >= pend || nleft - rank <= 0) return 0;
       const int64_t wfirst = vec ? ((wb + 1) & ~(int64_t)1) : (wb + 1);  // even tile origin; may take in word wb itself
-      const int64_t wn     = width - wfirst;
+      const int64_t wn     = pend - wfirst;                              // to the end of the panel (of the matrix without panels)
       const int skip       = (int)(wb + 1 - wfirst);
       word *C              = A + (r0 + rank) * stride + wfirst;
       const word *U        = A + r0 * stride + wfirst;
@@ -748,20 +851,23 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
       }
     }
     if (rank == 0) continue;  // nothing moved: the slice words are unchanged
-    if (wb + 1 < width) {
-      // the pivot rows among themselves on the words to the right (ple_russian.c:306-325): a unit lower triangular solve
-      // with the <= 64 x 64 triangle of their multipliers -- after the update has read them (ev_main), on the side stream:
-      // nothing later in the factorisation looks at these rows again
+    if (wb + 1 < pend) {
+      // the pivot rows among themselves on the words to the right (ple_russian.c:306-325), as far as the panel goes: a
+      // unit lower triangular solve with the <= 64 x 64 triangle of their multipliers -- after the update has read them
+      // (ev_main), on the side stream: no later block looks at these words again
+      const int64_t cend = pend * 64 < ncols ? pend * 64 : ncols;
       HIPTRY(hipStreamWaitEvent(s.side, s.ev_main, 0));
-      HIPTRY(m4ri_amd_trsm_lower_left_dev(Lc, 1, A + r0 * stride + wb + 1, stride, rank, ncols - (wb + 1) * 64, 0, s.side));
+      HIPTRY(m4ri_amd_trsm_lower_left_dev(Lc, 1, A + r0 * stride + wb + 1, stride, rank, cend - (wb + 1) * 64, 0, s.side));
       R.side_used = true;
     }
     for (int t = 0; t < rank; ++t) {
       R.P[r0 + t]                = s.hblk->swaprow[t];
       R.Q[c0 + (r0 - first) + t] = (int32_t)(wb * 64 + s.hblk->pivcol[t]);
+      if (pw0 >= 0) hmap[(wb - pw0) * 64 + s.hblk->pivcol[t]] = (int32_t)(r0 + t);
     }
     R.r0 += rank;
   }
+  if (int rc = close_panel()) return rc;
   *found = R.r0 - first;
   return 0;
 }

@@ -76,51 +76,99 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_base_kernel(const word *__r
 // ---- blocks of 512 rows through their inverses -------------------------------------------------------------------
 // A product call costs ~65 us whatever its size (pack, leaf prologue, split reduction), so a recursion that bottoms out
 // at 64 rows spends its time launching: 1023 products and 1024 base kernels for a 65536-row triangle.  The diagonal
-// blocks of 512 rows are inverted up front instead -- all of them in ONE launch, a workgroup per block, a thread per
-// column of the inverse (substitution on a unit vector, the block's rows broadcast), transposed through LDS -- and a
-// block's solve becomes X = T_bb^-1 * B_b, one product; the recursion stops at 512 rows (127 + 128 products).
+// blocks of 512 rows are inverted up front instead -- all of them in ONE launch, a workgroup per block (the kernel
+// below) -- and a block's solve becomes X = T_bb^-1 * B_b, one product; the recursion stops at 512 rows (127 + 128
+// products).
 #ifndef TRSM_TB
 #define TRSM_TB 512
 #endif
 constexpr int TB = TRSM_TB;  // rows of a diagonal block (256 / 512 / 1024: 44.0 / 38.8 / 37.7 ms at 65536^2, 6.2 / 5.2 / 5.8 ms at 16384^2)
 
+// The inverse of a block is built in LDS, in place, bottom-up (the first version let every thread substitute its own
+// column through all 512 rows: 512 dependent steps, 0.32 ms for a block, 0.19 ms with the rows in LDS -- nothing when all
+// blocks of a triangle are inverted in one launch, but the PLE inverts one block per panel, on its critical path):
+//   1. wave b inverts the 64 x 64 diagonal block b: lane j substitutes column j in one register, and the ballot of the
+//      64 lanes' new bits IS row i of the inverse, written over row i of the block (no later step reads it);
+//   2. s = 64, 128, 256: every pair of finished s-blocks closes its off-diagonal block,  X10 = X11 * (L10 * X00)  for a
+//      lower triangle,  X01 = X00 * (U01 * X11)  for an upper one -- two bit-matrix products per level, a thread per output
+//      word, the middle product in a second LDS array.
 template <bool UPPER>
 __global__ __launch_bounds__(TB) void trsm_invert_blocks_kernel(const word *__restrict__ T, int64_t t_stride, int64_t mb, word *__restrict__ Tinv) {
-  __shared__ word cols[TB][TB / 64 + 1];  // cols[j] = column j of the inverse (bit i = entry (i, j)); +1: bank spread
+  static_assert(TB <= 512 && TB % 128 == 0, "the in-LDS inversion holds a block of at most 512 rows");
+  constexpr int TW = TB / 64;
+  __shared__ word X[TB][TW];           // the block with its unit diagonal and the other triangle cleared; its inverse at the end
+  __shared__ word Mid[TB / 2][TW / 2];  // the middle product of a level: (TB / 2s) pairs x s rows x s / 64 words
   const int64_t r0 = (int64_t)blockIdx.x * TB;
   const int sz     = (int)((mb - r0) < TB ? (mb - r0) : TB);
-  const int j      = threadIdx.x;
   const word *blk  = T + r0 * t_stride + r0 / 64;  // the block's rows, from its own first column on
-  word x[TB / 64];
-#pragma unroll
-  for (int w = 0; w < TB / 64; ++w) x[w] = 0;
-  // T x = e_j by substitution.  Entries of x not computed yet are 0, so a row's diagonal, its other triangle and whatever
-  // lies beyond the block's columns never contribute.
-  for (int t = 0; t < sz; ++t) {
-    const int i     = UPPER ? sz - 1 - t : t;
-    const word *row = blk + (int64_t)i * t_stride;
-    word p = 0;
-#pragma unroll
-    for (int w = 0; w < TB / 64; ++w)
-      if (w * 64 < sz) p ^= row[w] & x[w];
-    const word bit = (word)((__popcll(p) & 1) ^ (i == j ? 1 : 0));
-#pragma unroll
-    for (int w = 0; w < TB / 64; ++w)
-      if (w == i / 64) x[w] |= bit << (i % 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x; idx < TB * TW; idx += TB) {
+    const int i = idx / TW, w = idx % TW;
+    word v = 0;
+    if (i < sz && w * 64 < sz) {
+      v = blk[(int64_t)i * t_stride + w];
+      // keep the proper triangle's columns inside the block: (i, c) with c < i (lower) or i < c < sz (upper)
+      word keep;
+      if (UPPER) {
+        keep = (w * 64 > i) ? ~(word)0 : (w * 64 + 63 <= i) ? 0 : (((~(word)0) << (i - w * 64)) << 1);
+        if (sz - w * 64 < 64) keep &= (~(word)0) >> (64 - (sz - w * 64));
+      } else {
+        keep = (w * 64 + 63 < i) ? ~(word)0 : (w * 64 >= i) ? 0 : (((word)1 << (i - w * 64)) - 1);
+      }
+      v &= keep;
+    }
+    if (w == i / 64) v |= (word)1 << (i % 64);  // rows beyond sz: identity, cut off at the end
+    X[i][w] = v;
   }
-#pragma unroll
-  for (int w = 0; w < TB / 64; ++w) cols[j][w] = (j < sz) ? x[w] : 0;
   __syncthreads();
-  // row i of the inverse: bit j = cols[j] bit i
+  {  // 1. the diagonal 64 x 64 blocks
+    word xcol = 0;  // column `lane` of the inverse so far: bit i = entry (i, lane)
+    for (int t = 0; t < 64; ++t) {
+      const int i      = UPPER ? 63 - t : t;
+      const word roww  = X[64 * wave + i][wave];
+      const int bit    = (__popcll(roww & xcol) & 1) ^ (i == lane ? 1 : 0);  // xcol has no bit i yet: the diagonal does not count
+      xcol |= (word)bit << i;
+      const word rowi = __ballot(bit);
+      if (lane == 0) X[64 * wave + i][wave] = rowi;
+    }
+  }
+  __syncthreads();
+  // 2. pairs of finished s-blocks
+#pragma unroll 1
+  for (int sb = 64; sb < TB; sb *= 2) {
+    const int sw = sb / 64, total = (TB / (2 * sb)) * sb * sw;
+    for (int o = threadIdx.x; o < total; o += TB) {  // Mid = L10 * X00  |  U01 * X11
+      const int pair = o / (sb * sw), rem = o - pair * sb * sw, i = rem / sw, w = rem - i * sw;
+      const int base = pair * 2 * sb;
+      const int arow = UPPER ? base + i : base + sb + i, acol = UPPER ? (base + sb) / 64 : base / 64;  // the off-diagonal block's row
+      const int brow = UPPER ? base + sb : base, bcol = UPPER ? (base + sb) / 64 : base / 64;            // the finished block next to it
+      word acc = 0;
+      for (int kw = 0; kw < sw; ++kw) {
+        const word aw = X[arow][acol + kw];
+#pragma unroll 8
+        for (int bt = 0; bt < 64; ++bt) acc ^= X[brow + kw * 64 + bt][bcol + w] & ((word)0 - ((aw >> bt) & 1));
+      }
+      Mid[pair * sb + i][w] = acc;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < total; o += TB) {  // X10 = X11 * Mid  |  X01 = X00 * Mid
+      const int pair = o / (sb * sw), rem = o - pair * sb * sw, i = rem / sw, w = rem - i * sw;
+      const int base = pair * 2 * sb;
+      const int arow = UPPER ? base + i : base + sb + i, acol = UPPER ? base / 64 : (base + sb) / 64;  // the finished block on this row
+      word acc = 0;
+      for (int kw = 0; kw < sw; ++kw) {
+        const word aw = X[arow][acol + kw];
+#pragma unroll 8
+        for (int bt = 0; bt < 64; ++bt) acc ^= Mid[pair * sb + kw * 64 + bt][w] & ((word)0 - ((aw >> bt) & 1));
+      }
+      X[arow][(UPPER ? (base + sb) / 64 : base / 64) + w] = acc;  // over the off-diagonal block, which Mid has replaced
+    }
+    __syncthreads();
+  }
   const int i = threadIdx.x;
-  word out[TB / 64];
+  word *dst   = Tinv + ((int64_t)blockIdx.x * TB + i) * TW;
 #pragma unroll
-  for (int w = 0; w < TB / 64; ++w) out[w] = 0;
-  if (i < sz)
-    for (int jj = 0; jj < sz; ++jj) out[jj / 64] |= ((cols[jj][i / 64] >> (i % 64)) & 1) << (jj % 64);
-  word *dst = Tinv + ((int64_t)blockIdx.x * TB + i) * (TB / 64);
-#pragma unroll
-  for (int w = 0; w < TB / 64; ++w) dst[w] = out[w];
+  for (int w = 0; w < TW; ++w) dst[w] = (i < sz) ? X[i][w] : 0;
 }
 
 struct TrsmScratch {
