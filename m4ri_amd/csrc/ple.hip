@@ -715,7 +715,41 @@ struct PleRun {
   int64_t r0;      // rows finished so far = pivots found so far
   int64_t cutoff;  // __M4RI_PLE_CUTOFF of the reference build being matched (words); 0: no recursion
   bool side_used = false;
+  // the open panel (see "the panel step"): first word, one past its last word, R.r0 when it was opened, and which of the two
+  // host row maps it fills (the other one may still be on its way to the device).  It stays open across the nodes of the
+  // recursion of _mzd_ple as long as they stay inside it.
+  int64_t pw0 = -1, pend = 0, prow0 = 0;
+  int which = 0;
 };
+
+// bring the words to the right of the finished panel up to date (see "the panel step" above)
+int close_panel(PleRun &R) {
+  if (R.pw0 < 0) return 0;
+  Scratch &s = *R.s;
+  word *A    = R.A;
+  hipStream_t st = R.st;
+  const int64_t stride = R.stride, p0 = R.pw0, pend = R.pend, rp = R.r0 - R.prow0, pwn = pend - p0, wtrail = R.width - pend;
+  R.pw0 = -1;
+  if (rp == 0 || wtrail <= 0) return 0;
+  const int64_t ustride = (wtrail + 1) & ~(int64_t)1, trailcols = R.ncols - pend * 64;
+  if (R.side_used) {  // the pivot rows' solves inside the panel write words the gather reads around
+    HIPTRY(hipEventRecord(s.ev_side, s.side));
+    HIPTRY(hipStreamWaitEvent(st, s.ev_side, 0));
+  }
+  HIPTRY(hipMemcpyAsync(s.rowmap, s.hrowmap + R.which * PLE_PANEL_MAX * 64, (size_t)pwn * 64 * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ple_panel_gather_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, p0, (int)pwn, pend, wtrail, s.rowmap, s.Lsq, s.Ubuf,
+                     ustride);
+  HIPTRY(hipGetLastError());
+  HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lsq, pwn, s.Ubuf, ustride, pwn * 64, trailcols, 0, st));
+  hipLaunchKernelGGL(ple_panel_scatter_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, pend, wtrail, s.rowmap, s.Ubuf, ustride);
+  HIPTRY(hipGetLastError());
+  if (R.nrows - R.r0 > 0)
+    HIPTRY(m4ri_amd_mul_dev(A + R.r0 * stride + pend, stride, A + R.r0 * stride + p0, stride, s.Ubuf, ustride, R.nrows - R.r0, pwn * 64, trailcols, 1, 0, st));
+  // the next panel fills the OTHER host map; this one is reused a panel later, by when at least one block's record has been
+  // waited for that follows this copy in the stream
+  R.which ^= 1;
+  return 0;
+}
 
 // Columns [c0, c1) (c0 on a word boundary) in blocks of 64: the t-th pivot found goes to Q[c0 + t].
 int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
@@ -726,54 +760,27 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
   const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && stride % 2 == 0;
   static const bool wave_first = !(getenv("M4RI_AMD_PLE_WAVE") && atoi(getenv("M4RI_AMD_PLE_WAVE")) == 0);
   static const int variant     = getenv("M4RI_AMD_RU_TW") ? atoi(getenv("M4RI_AMD_RU_TW")) : RU_DEFAULT_TW;
-  static const bool panels = !(getenv("M4RI_AMD_PLE_PANELS") && atoi(getenv("M4RI_AMD_PLE_PANELS")) == 0);
+  // panels pay from about 150 MiB of matrix on (a pass over the trailing matrix per block then costs more than the panel
+  // step's fixed ~0.25 ms per 16 blocks): 16384^2 16.2 ms without / 19.1 with, 32768^2 41.1 / 41.4, 65536^2 155 / 106;
+  // M4RI_AMD_PLE_PANELS=0 / 1 forces them off / on
+  static const int panels_env = getenv("M4RI_AMD_PLE_PANELS") ? atoi(getenv("M4RI_AMD_PLE_PANELS")) : -1;
+  const bool panels = panels_env >= 0 ? panels_env != 0 : nrows * width >= ((int64_t)3 << 23);
   static const int64_t panel_words = [] {
     const char *e = getenv("M4RI_AMD_PLE_PANEL");
     const int v   = e ? atoi(e) : PLE_PANEL_WORDS;
     return (int64_t)(v < 1 ? 1 : v > PLE_PANEL_MAX ? PLE_PANEL_MAX : v);
   }();
-  const int64_t wend = (c1 + 63) / 64;  // one past the last word of this run's columns
-  int64_t pw0 = -1, pend = width;       // the open panel: first word, one past its last word; pend = width: no panel step
-  int64_t prow0 = 0;                    // R.r0 when the panel was opened
-  int which = 0;                        // the host row map in use: the other one may still be on its way to the device
-  int32_t *hmap = s.hrowmap;
-  // bring the words to the right of the finished panel up to date (see "the panel step" above)
-  auto close_panel = [&]() -> int {
-    if (pw0 < 0) return 0;
-    const int64_t p0 = pw0, rp = R.r0 - prow0, pwn = pend - pw0, wtrail = width - pend;
-    pw0 = -1;
-    if (rp == 0 || wtrail <= 0) return 0;
-    const int64_t ustride = (wtrail + 1) & ~(int64_t)1, trailcols = ncols - pend * 64;
-    if (R.side_used) {  // the pivot rows' solves inside the panel write words the gather reads around
-      HIPTRY(hipEventRecord(s.ev_side, s.side));
-      HIPTRY(hipStreamWaitEvent(st, s.ev_side, 0));
-    }
-    HIPTRY(hipMemcpyAsync(s.rowmap, hmap, (size_t)pwn * 64 * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ple_panel_gather_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, p0, (int)pwn, pend, wtrail, s.rowmap, s.Lsq,
-                       s.Ubuf, ustride);
-    HIPTRY(hipGetLastError());
-    HIPTRY(m4ri_amd_trsm_lower_left_dev(s.Lsq, pwn, s.Ubuf, ustride, pwn * 64, trailcols, 0, st));
-    hipLaunchKernelGGL(ple_panel_scatter_kernel, dim3((unsigned)(pwn * 64)), dim3(256), 0, st, A, stride, pend, wtrail, s.rowmap, s.Ubuf, ustride);
-    HIPTRY(hipGetLastError());
-    if (nrows - R.r0 > 0)
-      HIPTRY(m4ri_amd_mul_dev(A + R.r0 * stride + pend, stride, A + R.r0 * stride + p0, stride, s.Ubuf, ustride, nrows - R.r0, pwn * 64, trailcols, 1, 0,
-                              st));
-    // the next panel fills the OTHER host map; this one is reused a panel later, by when at least one block's record has
-    // been waited for that follows this copy in the stream
-    which ^= 1;
-    hmap = s.hrowmap + which * PLE_PANEL_MAX * 64;
-    return 0;
-  };
   for (int64_t wb = c0 / 64; wb * 64 < c1 && R.r0 < nrows; ++wb) {
-    if (panels && (pw0 < 0 || wb >= pend)) {
-      if (int rc = close_panel()) return rc;
-      pw0 = wb;
-      pend = (wb / panel_words + 1) * panel_words;
-      if (pend > wend) pend = wend;
-      prow0 = R.r0;
-      for (int64_t j = 0; j < (pend - pw0) * 64; ++j) hmap[j] = -1;
-      if (R.r0 >= nrows) break;
+    if (panels && (R.pw0 < 0 || wb >= R.pend)) {
+      if (int rc = close_panel(R)) return rc;
+      R.pw0   = wb;
+      R.pend  = (wb / panel_words + 1) * panel_words;  // panels end on multiples of panel_words, whatever run of columns is being walked
+      if (R.pend > width) R.pend = width;
+      R.prow0 = R.r0;
+      int32_t *hm = s.hrowmap + R.which * PLE_PANEL_MAX * 64;
+      for (int64_t j = 0; j < (R.pend - R.pw0) * 64; ++j) hm[j] = -1;
     }
+    const int64_t pend = panels ? R.pend : width;  // how far this block's update and its pivot rows' solve reach
     const int64_t r0 = R.r0;
     const int ncb = (int)((c1 - wb * 64) < 64 ? (c1 - wb * 64) : 64);
     const int64_t nleft = nrows - r0;
@@ -863,12 +870,11 @@ int ple_blocks(PleRun &R, int64_t c0, int64_t c1, int64_t *found) {
     for (int t = 0; t < rank; ++t) {
       R.P[r0 + t]                = s.hblk->swaprow[t];
       R.Q[c0 + (r0 - first) + t] = (int32_t)(wb * 64 + s.hblk->pivcol[t]);
-      if (pw0 >= 0) hmap[(wb - pw0) * 64 + s.hblk->pivcol[t]] = (int32_t)(r0 + t);
+      if (R.pw0 >= 0) s.hrowmap[R.which * PLE_PANEL_MAX * 64 + (wb - R.pw0) * 64 + s.hblk->pivcol[t]] = (int32_t)(r0 + t);
     }
     R.r0 += rank;
   }
-  if (int rc = close_panel()) return rc;
-  *found = R.r0 - first;
+  *found = R.r0 - first;  // the panel stays open: the next run of columns may continue it (closed by ple_rec / the driver)
   return 0;
 }
 
@@ -907,6 +913,8 @@ int ple_rec(PleRun &R, int64_t rows, int64_t c0, int64_t c1, int64_t *found) {
   *found = 0;
   if (rows <= 0) return 0;
   Scratch &s = *R.s;
+  if (R.pw0 >= 0 && c0 / 64 + width > R.pend)  // the window reaches beyond the open panel, where the panel's update is still due
+    if (int rc = close_panel(R)) return rc;
   HIPTRY(hipMemsetAsync(s.lastrow, 0, sizeof(int), R.st));
   hipLaunchKernelGGL(ple_last_row_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, R.st, R.A, R.stride, R.r0, rows, c0 / 64, c0 / 64 + width,
                      s.lastrow);
@@ -950,7 +958,8 @@ int m4ri_amd_ple_dev(word *A, int64_t stride, int64_t nrows, int64_t ncols, int3
   const int64_t width = words_of(ncols);
   PleRun run{A, stride, nrows, ncols, width, P, Q, st, &s, 0, recursion_cutoff};
   int64_t found = 0;
-  const int rc_f = recursion_cutoff ? ple_rec(run, nrows, 0, ncols, &found) : ple_blocks(run, 0, ncols, &found);
+  int rc_f = recursion_cutoff ? ple_rec(run, nrows, 0, ncols, &found) : ple_blocks(run, 0, ncols, &found);
+  if (rc_f == 0) rc_f = close_panel(run);
   if (run.side_used) {  // the pivot rows' solves join here, also on an error path: the side stream works on the caller's matrix
     HIPTRY(hipEventRecord(s.ev_side, s.side));
     HIPTRY(hipStreamWaitEvent(st, s.ev_side, 0));

@@ -207,3 +207,19 @@ def test_solver_edge_shapes(oracle):
     I = Mzd.from_bits(np.eye(130, dtype=np.uint8))
     Io = I.copy()
     assert m4ri_amd.mzd_ple(I)[0] == 130 and I.equal(Io)
+
+
+@pytest.mark.parametrize("panel_words", [1, 2, 5])
+def test_panel_step_forced_on(panel_words):
+    """The panel step of the PLE (ple.hip: blocks update only their own panel, the rest of the matrix once per panel through a
+    TRSM and an engine product) switches itself on from about 150 MiB of matrix; here the whole parity suite of this file
+    runs again in a child process with panels of 64 / 128 / 320 columns forced on (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, M4RI_AMD_PLE_PANELS="1", M4RI_AMD_PLE_PANEL=str(panel_words))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ple.py"), "-x", "-q", "-m", "gpu", "-k", "not forced_on and not at_scale",
+                        "-p", "no:cacheprovider"], cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout

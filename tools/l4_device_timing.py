@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timings of the solvers above the multiply path (TRSM, PLE) with the matrices resident on the device (pinned)
-and from host memory.  usage: l4_device_timing.py [n ...]"""
+and from host memory.  usage: l4_device_timing.py [n ...]   (PLE_WHICH=_mzd_ple_russian: the flat flavour, also
+mzd_pluq / _mzd_pluq_russian; ONLY=ple: skip the triangular solves)"""
 import os
 import sys
 import time
@@ -17,7 +18,8 @@ def main():
     m4ri_amd.init(0)
     for n in sizes:
         A, B, T = Mzd.random(n, n, 1), Mzd.random(n, n, 2), Mzd.random(n, n, 3)
-        for what in ("ple", "trsm_lower", "trsm_upper"):
+        which = os.environ.get("PLE_WHICH", "mzd_ple")
+        for what in (("ple",) if os.environ.get("ONLY") == "ple" else ("ple", "trsm_lower", "trsm_upper")):
             for resident in (False, True):
                 X = (A if what == "ple" else B).copy()
                 if resident:
@@ -26,7 +28,7 @@ def main():
                         m4ri_amd.pin(T)
                 t = time.perf_counter()
                 if what == "ple":
-                    r, P, Q = m4ri_amd.mzd_ple(X)
+                    r, P, Q = m4ri_amd.mzd_ple(X, 0, which)
                 elif what == "trsm_lower":
                     m4ri_amd.mzd_trsm_lower_left(T, X)
                 else:
@@ -36,7 +38,7 @@ def main():
                     m4ri_amd.unpin(X)
                     if what != "ple":
                         m4ri_amd.unpin(T)
-                extra = f" rank {r}" if what == "ple" else ""
+                extra = f" rank {r} ({which})" if what == "ple" else ""
                 print(f"n={n:6d} {what:11s} {'resident' if resident else 'host    '} {dt * 1e3:9.1f} ms{extra}", flush=True)
 
 
