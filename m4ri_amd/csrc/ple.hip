@@ -601,7 +601,7 @@ __global__ __launch_bounds__(QT_THREADS) void qtri_gather_kernel(word *__restric
 }
 
 // ---- 6. the panel step ---------------------------------------------------------------------------------------------
-// The blocks of 64 columns update only the words of their own panel (PLE_PANEL_WORDS words = 1024 columns); what lies to
+// The blocks of 64 columns update only the words of their own panel (PLE_PANEL_WORDS words = 2048 columns); what lies to
 // the right of the panel is brought up to date once per panel:  U12 = L11^-1 * T1  on the panel's pivot rows (the TRSM of
 // trsm.hip against the multipliers among the pivot rows themselves), then  T2 ^= L21 * U12  on the rows below -- one
 // engine product with the multipliers where the decomposition stores them, in the panel's columns of A.  Both work in
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void ple_panel_scatter_kernel(word *__restrict
 }
 
 #ifndef PLE_PANEL_WORDS
-#define PLE_PANEL_WORDS 16  // words of a panel: 1024 columns (8 / 16 / 32: 122 / 117.5 / 117 ms at 65536^2, 20.6 / 19.1 / 18.3 at 16384^2) (M4RI_AMD_PLE_PANEL overrides, up to PLE_PANEL_MAX)
+#define PLE_PANEL_WORDS 32  // words of a panel: 2048 columns (16 / 24 / 32 words: 106.9 / 118.5 / 100.5 ms for mzd_ple at 65536^2, 101.5 / 97.3 / 95.5 for the flat flavour; a width that is not a power of two sits badly in the recursion's nodes) (M4RI_AMD_PLE_PANEL overrides, up to PLE_PANEL_MAX)
 #endif
 #define PLE_PANEL_MAX 32
 
