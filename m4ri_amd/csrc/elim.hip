@@ -7,6 +7,7 @@
 // are read through L2).  Two launches per call: the strip of every row is decoded into table row numbers first
 // (the strip itself lies inside the words the update rewrites), then every (row, 16-byte chunk) is updated.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "gf2_common.h"
 #include "../../include/m4ri_amd.h"
 
@@ -41,6 +42,28 @@ __global__ __launch_bounds__(EL_THREADS) void decode_strip_kernel(const word *__
     const word bm = kb >= 64 ? ~(word)0 : (((word)1 << kb) - 1);
     idx[i * 6 + t] = a.L[t][bits & bm];
     bits = kb >= 64 ? 0 : (bits >> kb);
+  }
+}
+
+// With several tables the lookups outweigh the matrix itself (six 8-bit tables over 65536 columns: 12 MB of table rows,
+// six reads per chunk), and a workgroup that walks whole rows pulls all of it through its XCD's 4 MB L2.  Here the
+// workgroups of XCD x (blockIdx % 8: the dispatcher deals them round-robin) keep to the x-th eighth of the columns, so
+// each L2 holds its own eighth of the tables: six tables 2.5 -> 2.9 TB/s over 65536 columns, 2.55 -> 3.3 over 32768; two
+// tables 4.7 -> 4.8 / 4.9 -> 5.2.  (Walking the eighth in narrower strips does not add to that, and the tables' slices in
+// LDS -- which caps the tile at 64 bytes of a row for six 8-bit tables -- are slower than L2: both measured.)
+template <typename V>
+__global__ __launch_bounds__(EL_THREADS) void apply_tables_slab_kernel(V *__restrict__ M, int64_t stride, int64_t startrow, int64_t rows, int64_t block,
+                                                                      int64_t wide, ProcArgs a, const int32_t *__restrict__ idx) {
+  const int xcd      = blockIdx.x & 7;
+  const int64_t nb   = gridDim.x >> 3, j = blockIdx.x >> 3;
+  const int64_t s0   = xcd * wide / 8, sw = (xcd + 1) * wide / 8 - s0;
+  const int64_t total = rows * sw;
+  for (int64_t e = j * EL_THREADS + threadIdx.x; e < total; e += nb * EL_THREADS) {
+    const int64_t i = e / sw, w = block + s0 + (e - i * sw);
+    V x = M[(startrow + i) * stride + w];
+    for (int t = 0; t < a.ntables; ++t)
+      x ^= reinterpret_cast<const V *>(a.T[t])[(int64_t)idx[i * 6 + t] * a.t_stride[t] + w];
+    M[(startrow + i) * stride + w] = x;
   }
 }
 
@@ -123,8 +146,14 @@ int m4ri_amd_process_rows_dev(word *M, int64_t stride, int64_t width, int64_t st
     typedef unsigned long long __attribute__((ext_vector_type(2))) word2;
     ProcArgs h = a;
     for (int t = 0; t < ntables; ++t) h.t_stride[t] /= 2;
-    hipLaunchKernelGGL((apply_tables_kernel<word2>), dim3(grid_for(rows * (wide / 2))), dim3(EL_THREADS), 0, st, reinterpret_cast<word2 *>(M),
-                       stride / 2, startrow, rows, block / 2, wide / 2, h, idx_scratch);
+    static const int slab_env = getenv("M4RI_AMD_ELIM_SLABS") ? atoi(getenv("M4RI_AMD_ELIM_SLABS")) : -1;
+    const bool slabs = slab_env >= 0 ? slab_env != 0 : (ntables >= 2 && wide / 2 >= 64);
+    if (slabs)
+      hipLaunchKernelGGL((apply_tables_slab_kernel<word2>), dim3((grid_for(rows * (wide / 2)) + 7) / 8 * 8), dim3(EL_THREADS), 0, st,
+                         reinterpret_cast<word2 *>(M), stride / 2, startrow, rows, block / 2, wide / 2, h, idx_scratch);
+    else
+      hipLaunchKernelGGL((apply_tables_kernel<word2>), dim3(grid_for(rows * (wide / 2))), dim3(EL_THREADS), 0, st, reinterpret_cast<word2 *>(M),
+                         stride / 2, startrow, rows, block / 2, wide / 2, h, idx_scratch);
   } else {
     hipLaunchKernelGGL((apply_tables_kernel<word>), dim3(grid_for(rows * wide)), dim3(EL_THREADS), 0, st, M, stride, startrow, rows, block, wide, a,
                        idx_scratch);
