@@ -16,6 +16,7 @@
 // The diagonal is never read (taken as 1) and neither is the other triangle, exactly like the reference.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <stdlib.h>
 #include "gf2_common.h"
 #include "../../include/m4ri_amd.h"
 
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(TB) void trsm_invert_blocks_kernel(const word *__re
 }
 
 struct TrsmScratch {
-  word *inv = nullptr, *tmp = nullptr;
-  size_t inv_words = 0, tmp_words = 0;
+  word *inv = nullptr, *tmp = nullptr, *big = nullptr, *mid = nullptr;  // big: inverses of 4096-row blocks; mid: the middle products while building them
+  size_t inv_words = 0, tmp_words = 0, big_words = 0, mid_words = 0;
   hipEvent_t last = nullptr;  // end of the previous solve that used the scratch (it may have run on another stream)
 };
 TrsmScratch g_trsm_scratch[16];
@@ -187,19 +188,20 @@ struct TrsmRun {
   int64_t bs, nb;
   int cutoff;
   hipStream_t st;
-  const word *inv;  // the inverted diagonal blocks, block k at inv + k * TB * (TB / 64)
-  word *tmp;        // TB x words_of(nb) words
+  const word *inv;  // the inverted diagonal blocks of `be` rows, block k at inv + k * be * (be / 64)
+  word *tmp;        // be x words_of(nb) words
+  int64_t be = TB;  // rows of an inverted block: TB, or TRSM_BIG when the bigger inverses were built
 };
 
 // rows [r0, r0 + mb) of the system, r0 a multiple of TB
 int solve_blocks(const TrsmRun &R, int64_t r0, int64_t mb) {
   const int64_t wn = words_of(R.nb);
   word *Bb = R.B + r0 * R.bs;
-  if (mb <= TB) {  // X = T_bb^-1 * B_b
+  if (mb <= R.be) {  // X = T_bb^-1 * B_b
     HIPTRY(hipMemcpy2DAsync(R.tmp, (size_t)wn * 8, Bb, (size_t)R.bs * 8, (size_t)wn * 8, (size_t)mb, hipMemcpyDeviceToDevice, R.st));
-    return m4ri_amd_mul_dev(Bb, R.bs, R.inv + (r0 / TB) * TB * (TB / 64), TB / 64, R.tmp, wn, mb, mb, R.nb, 0, R.cutoff, R.st);
+    return m4ri_amd_mul_dev(Bb, R.bs, R.inv + (r0 / R.be) * R.be * (R.be / 64), R.be / 64, R.tmp, wn, mb, mb, R.nb, 0, R.cutoff, R.st);
   }
-  const int64_t mb1 = (((mb - 1) / TB + 1) >> 1) * TB;  // halves on a block boundary
+  const int64_t mb1 = (((mb - 1) / R.be + 1) >> 1) * R.be;  // halves on a block boundary
   const word *Tr = R.T + r0 * R.ts + r0 / 64;           // this sub-triangle
   if (!R.upper) {
     if (int rc = solve_blocks(R, r0, mb1)) return rc;
@@ -209,6 +211,69 @@ int solve_blocks(const TrsmRun &R, int64_t r0, int64_t mb) {
   if (int rc = solve_blocks(R, r0 + mb1, mb - mb1)) return rc;
   HIPTRY(m4ri_amd_mul_dev(Bb, R.bs, Tr + mb1 / 64, R.ts, Bb + mb1 * R.bs, R.bs, mb1, mb - mb1, R.nb, 1, R.cutoff, R.st));
   return solve_blocks(R, r0, mb1);
+}
+
+// ---- inverses of 4096-row blocks ------------------------------------------------------------------------------------
+// With 512-row inverses a 65536-row solve still issues 128 block solves and 120 updates of 512 .. 4096 rows -- 248 of its
+// 255 products, 14 of its 34 ms, launch-bound.  For big systems the inverses of the 4096-row diagonal blocks are built
+// from the 512-row ones by three doubling levels (the scheme of trtri_upper below), every level a handful of BATCHED
+// launches over all blocks; the recursion then stops at 4096 rows: 16 block solves and 15 updates.
+#ifndef TRSM_BIG
+#define TRSM_BIG 4096
+#endif
+constexpr int64_t BIG = TRSM_BIG, BIGW = TRSM_BIG / 64;
+
+// I4: ng blocks of BIG rows x BIGW words; row r of the triangle -> its block's proper triangle, cleared elsewhere
+template <bool UPPER>
+__global__ __launch_bounds__(64) void trsm_big_clean_kernel(const word *__restrict__ T, int64_t ts, int64_t mb, word *__restrict__ I4) {
+  const int64_t r = blockIdx.x, g = r / BIG;
+  const int w     = threadIdx.x;  // word inside the block: BIGW == 64 threads
+  const int64_t c0 = g * BIG + 64 * w;
+  word v = 0;
+  if (r < mb && c0 < mb) {
+    v = T[r * ts + g * BIGW + w];
+    word keep;
+    if (UPPER) {
+      keep = (c0 > r) ? ~(word)0 : (c0 + 63 <= r) ? 0 : (((~(word)0) << (r - c0)) << 1);
+      if (mb - c0 < 64) keep &= (~(word)0) >> (64 - (mb - c0));
+    } else {
+      keep = (c0 + 63 < r) ? ~(word)0 : (c0 >= r) ? 0 : (((word)1 << (r - c0)) - 1);
+    }
+    v &= keep;
+  }
+  I4[r * BIGW + w] = v;
+}
+// the inverted TB-row blocks onto the diagonal of I4
+__global__ __launch_bounds__(TB) void trsm_big_scatter_kernel(const word *__restrict__ inv, int64_t nblk, word *__restrict__ I4) {
+  const int64_t b = blockIdx.x, i = threadIdx.x, r = b * TB + i;
+  const int64_t wl = ((b * TB) % BIG) / 64;  // the block's first word inside its BIG block
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) I4[r * BIGW + wl + w] = (b < nblk) ? inv[(b * TB + i) * (TB / 64) + w] : 0;
+}
+
+int build_big_inverses(bool upper, const word *T, int64_t ts, int64_t mb, TrsmScratch &s, hipStream_t st) {
+  static_assert(BIG % TB == 0 && BIGW == 64, "4096-row blocks, 64 words wide");
+  const int64_t ng = (mb + BIG - 1) / BIG, nblk = (mb + TB - 1) / TB;
+  if (upper) hipLaunchKernelGGL((trsm_big_clean_kernel<true>), dim3((unsigned)(ng * BIG)), dim3(64), 0, st, T, ts, mb, s.big);
+  else       hipLaunchKernelGGL((trsm_big_clean_kernel<false>), dim3((unsigned)(ng * BIG)), dim3(64), 0, st, T, ts, mb, s.big);
+  hipLaunchKernelGGL(trsm_big_scatter_kernel, dim3((unsigned)(ng * (BIG / TB))), dim3(TB), 0, st, s.inv, nblk, s.big);
+  HIPTRY(hipGetLastError());
+  const int64_t gs = BIG * BIGW;  // words between consecutive blocks
+  for (int64_t sb = TB; sb < BIG; sb *= 2) {
+    const int64_t sw = sb / 64;
+    for (int64_t base = 0; base < BIG; base += 2 * sb) {
+      word *X00 = s.big + base * BIGW + base / 64, *X11 = s.big + (base + sb) * BIGW + (base + sb) / 64;
+      word *off = upper ? s.big + base * BIGW + (base + sb) / 64 : s.big + (base + sb) * BIGW + base / 64;  // U01 | L10
+      if (upper) {  // X01 = X00 * U01 * X11
+        HIPTRY(m4ri_amd_m4rm_batch_dev(s.mid, sw, sb * sw, X00, BIGW, gs, off, BIGW, gs, sb, sb, sb, ng, 0, st));
+        HIPTRY(m4ri_amd_m4rm_batch_dev(off, BIGW, gs, s.mid, sw, sb * sw, X11, BIGW, gs, sb, sb, sb, ng, 0, st));
+      } else {      // X10 = X11 * L10 * X00
+        HIPTRY(m4ri_amd_m4rm_batch_dev(s.mid, sw, sb * sw, off, BIGW, gs, X00, BIGW, gs, sb, sb, sb, ng, 0, st));
+        HIPTRY(m4ri_amd_m4rm_batch_dev(off, BIGW, gs, X11, BIGW, gs, s.mid, sw, sb * sw, sb, sb, sb, ng, 0, st));
+      }
+    }
+  }
+  return 0;
 }
 
 int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb, int64_t nb, int cutoff, hipStream_t st) {
@@ -249,7 +314,34 @@ int solve(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int64_t mb
   if (upper) hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, mb, s.inv);
   else       hipLaunchKernelGGL((trsm_invert_blocks_kernel<false>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, mb, s.inv);
   HIPTRY(hipGetLastError());
-  const TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  static const int big_env = getenv("M4RI_AMD_TRSM_BIG") ? atoi(getenv("M4RI_AMD_TRSM_BIG")) : -1;
+  // from 4097 rows on, whatever the number of columns: these solves are bound by their launches (8192 x 512: 1.12 -> 0.75 ms,
+  // 16384 x 16384: 3.4 -> 1.4 ms, 32768^2: 9.4 -> 4.8, 65536^2: 33.3 -> 23.2; M4RI_AMD_TRSM_BIG=0 / 1 forces the choice)
+  if (big_env >= 0 ? (big_env != 0 && mb > BIG) : (mb > BIG)) {
+    const int64_t ng = (mb + BIG - 1) / BIG;
+    const size_t need_big = (size_t)ng * BIG * BIGW, need_mid = (size_t)ng * (BIG / 2) * (BIGW / 2), need_tmp4 = (size_t)BIG * (size_t)wn;
+    if (need_big > s.big_words) {
+      if (s.big) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.big)); }
+      s.big = nullptr; s.big_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.big), need_big * 8));
+      s.big_words = need_big;
+    }
+    if (need_mid > s.mid_words) {
+      if (s.mid) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.mid)); }
+      s.mid = nullptr; s.mid_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.mid), need_mid * 8));
+      s.mid_words = need_mid;
+    }
+    if (need_tmp4 > s.tmp_words) {
+      if (s.tmp) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.tmp)); }
+      s.tmp = nullptr; s.tmp_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.tmp), need_tmp4 * 8));
+      s.tmp_words = need_tmp4;
+    }
+    if (int rc = build_big_inverses(upper, T, ts, mb, s, st)) return rc;
+    R.inv = s.big; R.tmp = s.tmp; R.be = BIG;
+  }
   const int rc = solve_blocks(R, 0, mb);
   HIPTRY(hipEventRecord(s.last, st));
   return rc;

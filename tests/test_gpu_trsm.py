@@ -154,3 +154,33 @@ def test_large_right_solve_is_an_inverse():
         X = B.copy()
         (m4ri_amd.mzd_trsm_upper_right if False else getattr(m4ri_amd.lib(), "mzd_trsm_upper_right" if upper else "mzd_trsm_lower_right"))(Tc.ptr, X.ptr, 0)
         assert m4ri_amd.mzd_mul(None, X, Tc, 0).equal(B), "upper" if upper else "lower"
+
+
+BIG_SHAPES = [(4097, 200), (5000, 300), (8192, 64), (9000, 100), (12289, 70), (8200, 8300)]
+
+
+@pytest.mark.parametrize("mb,nb", BIG_SHAPES)
+@pytest.mark.parametrize("upper", [False, True])
+def test_trsm_big_shapes(oracle, mb, nb, upper):
+    """Systems of more than 4096 rows: the solver works with the inverses of 4096-row blocks (trsm.hip: build_big_inverses),
+    the last block ragged (test_trsm_big_blocks_off repeats the file with the 512-row blocks only)."""
+    T = Mzd.random(mb, mb, 300 + mb)
+    B = Mzd.random(mb, nb, 400 + nb)
+    want = (oracle.trsm_upper_left if upper else oracle.trsm_lower_left)(T, B.copy())
+    got = B.copy()
+    (m4ri_amd.mzd_trsm_upper_left if upper else m4ri_amd.mzd_trsm_lower_left)(T, got)
+    assert np.array_equal(got.valid_words(), want.valid_words())
+
+
+def test_trsm_big_blocks_off():
+    """The same shapes and the rest of this file in a child process with the 4096-row block inverses switched off: the
+    512-row path alone (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, M4RI_AMD_TRSM_BIG="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_trsm.py"), "-x", "-q", "-m", "gpu", "-k", "not blocks_off", "-p", "no:cacheprovider"],
+                       cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
