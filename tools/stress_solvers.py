@@ -39,6 +39,31 @@ def main():
                 seen.add(hashlib.sha256(B.masked().tobytes()).hexdigest())
             print(f"trsm {'upper' if upper else 'lower'} {mb}x{nb}: {reps} runs, {len(seen)} distinct result(s)", flush=True)
             bad += len(seen) != 1
+    # the panel step of the PLE switched on by size, the 4096-row block inverses of the TRSM, transposes, triangular inverses
+    big = max(3, reps // 8)
+    A0 = Mzd.random(45056, 45056, 21)
+    seen = set()
+    for _ in range(big):
+        A = A0.copy()
+        r, P, Q = m4ri_amd.mzd_ple(A, 0, "mzd_pluq")
+        seen.add(hashlib.sha256(A.masked().tobytes() + P.tobytes() + Q.tobytes()).hexdigest())
+    print(f"pluq 45056^2 (panels on): {big} runs, {len(seen)} distinct result(s), rank {r}", flush=True)
+    bad += len(seen) != 1
+    T, B0 = Mzd.random(20000, 20000, 22), Mzd.random(20000, 9000, 23)
+    for name, fn in (("trsm upper 20000x9000", lambda X: m4ri_amd.mzd_trsm_upper_left(T, X)), ("transpose 20000x9000", lambda X: m4ri_amd.mzd_transpose(X))):
+        seen = set()
+        for _ in range(big * 2):
+            out = fn(B0.copy())
+            seen.add(hashlib.sha256(out.masked().tobytes()).hexdigest())
+        print(f"{name}: {big * 2} runs, {len(seen)} distinct result(s)", flush=True)
+        bad += len(seen) != 1
+    seen = set()
+    for _ in range(big * 2):
+        U = T.copy()
+        m4ri_amd.mzd_trtri_upper(U)
+        seen.add(hashlib.sha256(U.masked().tobytes()).hexdigest())
+    print(f"trtri_upper 20000: {big * 2} runs, {len(seen)} distinct result(s)", flush=True)
+    bad += len(seen) != 1
     print("STRESS OK" if not bad else "STRESS FAILED")
     return bad
 
