@@ -37,8 +37,10 @@ __device__ unsigned long long tr_times[8192][6];
 
 namespace {
 
-constexpr int TR_THREADS = 512;  // 8 waves
-constexpr int TR_WORDS   = 16;   // tile width in words of A: 128 bytes per row
+#ifndef TR_WORDS
+#define TR_WORDS 16                       // tile width in words of A: 128 bytes per row (32 = 256 bytes, 16 waves: 3.43 vs 3.24 TB/s at 65536^2 but 5.3 vs 5.9 at 32768^2)
+#endif
+constexpr int TR_THREADS = 32 * TR_WORDS;  // a wave per two word columns
 constexpr int TR_GROUPS  = 16;   // 64-row groups per tile: 128 bytes per row of D
 #ifndef TR_PREFETCH
 #define TR_PREFETCH 3
@@ -46,7 +48,7 @@ constexpr int TR_GROUPS  = 16;   // 64-row groups per tile: 128 bytes per row of
 #ifndef TR_WAVES_PER_EU
 #define TR_WAVES_PER_EU 4
 #endif
-constexpr int TR_PITCH   = 18;   // LDS row pitch in words: 16-byte aligned, 36 banks apart (b128 reads conflict-free)
+constexpr int TR_PITCH   = TR_WORDS + 2;  // LDS row pitch in words: 16-byte aligned, 36 (68) banks apart (b128 reads conflict-free)
 
 // lane i holds row i of a 64 x 64 bit block in (lo, hi); on return lane j holds column j.  Six exchange stages (lane
 // distance = bit distance = 32, 16, ..., 1), none of them through LDS -- with ds_bpermute the six dependent LDS round
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(TR_THREADS) __attribute__((amdgpu_waves_per_eu(TR_W
   __shared__ __attribute__((aligned(16))) word ostage[TR_THREADS / 64][64][TR_GROUPS / 2];
   const int64_t wa = (ncols + 63) >> 6, wd = (nrows + 63) >> 6;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lr = t >> 3, lw = (t & 7) * 2;  // this thread's row within a group and its pair of words
+  const int lr = t / (TR_WORDS / 2), lw = (t % (TR_WORDS / 2)) * 2;  // this thread's row within a group and its pair of words
   const word dtail = (nrows & 63) ? ((~(word)0) >> (64 - (nrows & 63))) : ~(word)0;
 
   // a tile's load addresses: first row, and the thread's (clamped) word offsets
