@@ -378,15 +378,15 @@ __global__ __launch_bounds__(256) void trsm_right_base_kernel(const word *__rest
 // columns [c0, c0 + nb) of the system X T = B, c0 a multiple of TB: the same scheme as solve_blocks -- X_b = B_b * T_bb^-1
 int solve_right_blocks(const TrsmRun &R, int64_t mrows, int64_t c0, int64_t nb) {
   word *Bb = R.B + c0 / 64;
-  if (nb <= TB) {
+  if (nb <= R.be) {
     const int64_t wb = words_of(nb);
     HIPTRY(hipMemcpy2DAsync(R.tmp, (size_t)wb * 8, Bb, (size_t)R.bs * 8, (size_t)wb * 8, (size_t)mrows, hipMemcpyDeviceToDevice, R.st));
     if (nb % 64) HIPTRY(m4ri_amd_mask_tail_dev(R.tmp, wb, mrows, nb, R.st));  // the copy's last word may carry the columns behind the system
     // the product writes whole words of its nb columns: bits of B beyond column c0 + nb in that word are rewritten as zero,
     // which is what they are (B's own tail) whenever nb is not a multiple of 64 -- that only happens in the last block
-    return m4ri_amd_mul_dev(Bb, R.bs, R.tmp, wb, R.inv + (c0 / TB) * TB * (TB / 64), TB / 64, mrows, nb, nb, 0, R.cutoff, R.st);
+    return m4ri_amd_mul_dev(Bb, R.bs, R.tmp, wb, R.inv + (c0 / R.be) * R.be * (R.be / 64), R.be / 64, mrows, nb, nb, 0, R.cutoff, R.st);
   }
-  const int64_t nb1 = (((nb - 1) / TB + 1) >> 1) * TB;
+  const int64_t nb1 = (((nb - 1) / R.be + 1) >> 1) * R.be;
   const word *Tr = R.T + c0 * R.ts + c0 / 64;
   if (R.upper) {
     if (int rc = solve_right_blocks(R, mrows, c0, nb1)) return rc;
@@ -430,7 +430,32 @@ int solve_right(bool upper, const word *T, int64_t ts, word *B, int64_t bs, int6
   if (upper) hipLaunchKernelGGL((trsm_invert_blocks_kernel<true>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, nb, s.inv);
   else       hipLaunchKernelGGL((trsm_invert_blocks_kernel<false>), dim3((unsigned)nblk), dim3(TB), 0, st, T, ts, nb, s.inv);
   HIPTRY(hipGetLastError());
-  const TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  TrsmRun R{upper, T, ts, B, bs, nb, cutoff, st, s.inv, s.tmp};
+  static const int big_env = getenv("M4RI_AMD_TRSM_BIG") ? atoi(getenv("M4RI_AMD_TRSM_BIG")) : -1;
+  if (big_env >= 0 ? (big_env != 0 && nb > BIG) : (nb > BIG)) {  // the 4096-row block inverses, as in solve()
+    const int64_t ng = (nb + BIG - 1) / BIG;
+    const size_t need_big = (size_t)ng * BIG * BIGW, need_mid = (size_t)ng * (BIG / 2) * (BIGW / 2), need_tmp4 = (size_t)mb * BIGW;
+    if (need_big > s.big_words) {
+      if (s.big) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.big)); }
+      s.big = nullptr; s.big_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.big), need_big * 8));
+      s.big_words = need_big;
+    }
+    if (need_mid > s.mid_words) {
+      if (s.mid) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.mid)); }
+      s.mid = nullptr; s.mid_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.mid), need_mid * 8));
+      s.mid_words = need_mid;
+    }
+    if (need_tmp4 > s.tmp_words) {
+      if (s.tmp) { HIPTRY(hipDeviceSynchronize()); HIPTRY(hipFree(s.tmp)); }
+      s.tmp = nullptr; s.tmp_words = 0;
+      HIPTRY(hipMalloc(reinterpret_cast<void **>(&s.tmp), need_tmp4 * 8));
+      s.tmp_words = need_tmp4;
+    }
+    if (int rc = build_big_inverses(upper, T, ts, nb, s, st)) return rc;
+    R.inv = s.big; R.tmp = s.tmp; R.be = BIG;
+  }
   const int rc = solve_right_blocks(R, mb, 0, nb);
   HIPTRY(hipEventRecord(s.last, st));
   return rc;

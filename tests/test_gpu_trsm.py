@@ -172,6 +172,20 @@ def test_trsm_big_shapes(oracle, mb, nb, upper):
     assert np.array_equal(got.valid_words(), want.valid_words())
 
 
+@pytest.mark.parametrize("mb,nb", [(16, 4097), (20, 5000), (8, 8192), (12, 9000)])  # few rows: the oracle substitutes column by column
+@pytest.mark.parametrize("upper", [False, True])
+def test_right_trsm_big_shapes(oracle, mb, nb, upper):
+    """Right-hand solves against triangles of more than 4096 columns: the same 4096-row block inverses, used from the right."""
+    T = Mzd.random(nb, nb, 500 + nb)
+    idx = np.arange(nb)
+    T.valid_words()[idx, idx // 64] |= np.uint64(1) << (idx % 64).astype(np.uint64)
+    B = Mzd.random(mb, nb, 600 + mb)
+    want = (oracle.trsm_upper_right if upper else oracle.trsm_lower_right)(T, B.copy())
+    got = B.copy()
+    getattr(m4ri_amd.lib(), "mzd_trsm_upper_right" if upper else "mzd_trsm_lower_right")(T.ptr, got.ptr, 0)
+    assert np.array_equal(got.valid_words(), want.valid_words())
+
+
 def test_trsm_big_blocks_off():
     """The same shapes and the rest of this file in a child process with the 4096-row block inverses switched off: the
     512-row path alone (the switch is read once per process)."""
