@@ -218,9 +218,16 @@ def torch_exchange(dist, staged_device=None):
             for _, t, v in ins:
                 v.copy_(t)
             return
-        ops = [dist.P2POp(dist.isend, v, dst) for dst, v in sends] + [dist.P2POp(dist.irecv, v, src) for src, v in recvs]
+        # RCCL moves contiguous tensors only: the pieces are contiguous by construction (row slabs, whole buffers), but a view
+        # that is not goes through a contiguous temporary rather than aborting the job
+        outs = [(dst, v if v.is_contiguous() else v.contiguous()) for dst, v in sends]
+        ins = [(src, v if v.is_contiguous() else torch.empty(v.shape, dtype=v.dtype, device=v.device), v) for src, v in recvs]
+        ops = [dist.P2POp(dist.isend, t, dst) for dst, t in outs] + [dist.P2POp(dist.irecv, t, src) for src, t, _ in ins]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for _, t, v in ins:
+            if t is not v:
+                v.copy_(t)
     return exchange
 
 
