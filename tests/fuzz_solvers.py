@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz of the decomposition / echelon routines against the oracle on random shapes and structures (a script, not a
 pytest module; it lives under tests/ because it runs the checker; GPU box): PLE and PLUQ in both flavours (identity or the reference's recursion leftovers behind the rank), both echelon
-forms, the column permutations, left and right triangular solves.  usage: fuzz_solvers.py [seconds] [seed]"""
+forms, the column permutations, triangular solves (also above 4096 rows), triangular inverses, transposes, inverses.  usage: fuzz_solvers.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -54,7 +54,7 @@ def main():
         if big and rng.random() < 0.5:  # above the reference's recursion cutoff (width * rows > 524288 words)
             m, n = int(rng.integers(3000, 5000)), int(rng.integers(9000, 12000))
         A, kind = structured(rng, m, n)
-        what = ["ple", "ple_rec", "pluq", "pluq_rec", "ech0", "ech1", "perm", "trsm"][int(rng.integers(0, 8))]
+        what = ["ple", "ple_rec", "pluq", "pluq_rec", "ech0", "ech1", "perm", "trsm", "trsm_big", "trtri", "transpose", "inv"][int(rng.integers(0, 12))]
         ok = True
         if what in ("ple", "ple_rec", "pluq", "pluq_rec"):
             pluq, rec = what.startswith("pluq"), what.endswith("rec")
@@ -74,6 +74,36 @@ def main():
                 orc.apply_p_right(Ao, Q, trans)
                 m4ri_amd.mzd_apply_p_right(Ag, Q, trans)
                 ok = ok and np.array_equal(Ag.valid_words(), Ao.valid_words())
+        elif what == "trsm_big":  # more than 4096 rows: the 4096-row block inverses, ragged last block
+            mb, nb = int(rng.integers(4097, 9500)), int(rng.integers(1, 260))
+            T = Mzd.random(mb, mb, int(rng.integers(1, 1 << 30)))
+            B = Mzd.random(mb, nb, int(rng.integers(1, 1 << 30)))
+            upper = bool(rng.integers(0, 2))
+            Bo, Bg = B.copy(), B.copy()
+            (orc.trsm_upper_left if upper else orc.trsm_lower_left)(T, Bo)
+            (m4ri_amd.mzd_trsm_upper_left if upper else m4ri_amd.mzd_trsm_lower_left)(T, Bg)
+            ok = np.array_equal(Bg.valid_words(), Bo.valid_words())
+        elif what == "trtri":  # unit diagonal, the lower triangle junk that must survive
+            k = min(max(m, n), 2200)
+            U = Mzd.random(k, k, int(rng.integers(1, 1 << 30)))
+            idx = np.arange(k)
+            U.valid_words()[idx, idx // 64] |= np.uint64(1) << (idx % 64).astype(np.uint64)
+            Uo, Ug = U.copy(), U.copy()
+            orc.trtri_upper(Uo)
+            m4ri_amd.mzd_trtri_upper(Ug, ["mzd_trtri_upper", "mzd_trtri_upper_russian"][int(rng.integers(0, 2))])
+            ok = np.array_equal(Ug.valid_words(), Uo.valid_words())
+        elif what == "transpose":
+            ok = np.array_equal(m4ri_amd.mzd_transpose(A).valid_words(), orc.transpose(A).valid_words())
+        elif what == "inv":  # singular inputs (most structured ones) take the reference's augmented elimination, invertible ones the PLUQ road
+            k = min(m, 900)
+            if rng.random() < 0.5:
+                Lm, Um = Mzd.random(k, k, int(rng.integers(1, 1 << 30))).to_bits(), Mzd.random(k, k, int(rng.integers(1, 1 << 30))).to_bits()
+                Lm, Um = np.tril(Lm), np.triu(Um)
+                np.fill_diagonal(Lm, 1); np.fill_diagonal(Um, 1)
+                S = m4ri_amd.mzd_mul(None, Mzd.from_bits(Lm), Mzd.from_bits(Um), 0)
+            else:
+                S = structured(rng, k, k)[0]
+            ok = np.array_equal(m4ri_amd.mzd_inv_m4ri(S).valid_words(), orc.inv(S).valid_words())
         else:
             mb, nb = min(m, 700), min(n, 900)
             T = Mzd.random(mb, mb, int(rng.integers(1, 1 << 30)))
