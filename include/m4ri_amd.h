@@ -132,6 +132,7 @@ void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q);
 rci_t mzd_echelonize(mzd_t *A, int full);
 rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k);
 rci_t mzd_echelonize_pluq(mzd_t *A, int full);
+rci_t mzd_echelonize_naive(mzd_t *A, int full); /* m4ri/mzd.h:740 (mzd.c:208-233): plain Gaussian elimination -- same pivoting rule, same result */
 rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const double threshold);
 /* A <- A * P / A * P^T: the column transpositions (i, P[i]) on every row, i descending / ascending.
  * m4ri/mzp.h:142, :153 (mzp.c:193-260). */

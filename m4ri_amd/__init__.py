@@ -134,6 +134,7 @@ SYMBOLS = {
     "mzd_echelonize": (_I, [MzdPtr, _I]),
     "mzd_echelonize_m4ri": (_I, [MzdPtr, _I, _I]),
     "mzd_echelonize_pluq": (_I, [MzdPtr, _I]),
+    "mzd_echelonize_naive": (_I, [MzdPtr, _I]),
     "_mzd_echelonize_m4ri": (_I, [MzdPtr, _I, _I, _I, ctypes.c_double]),
     "m4ri_amd_ple_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),
     "m4ri_amd_pluq_dev": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _P]),

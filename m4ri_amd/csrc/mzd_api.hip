@@ -671,6 +671,7 @@ static rci_t run_echelonize(mzd_t *A, int full) {
 rci_t mzd_echelonize(mzd_t *A, int full) { return run_echelonize(A, full); }                  // echelonform.c:29-31
 rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k) { (void)k; return run_echelonize(A, full); }  // echelonform.c:33-35
 rci_t mzd_echelonize_pluq(mzd_t *A, int full) { return run_echelonize(A, full); }             // echelonform.c:37-139
+rci_t mzd_echelonize_naive(mzd_t *A, int full) { return run_echelonize(A, full); }            // mzd.c:208-233: plain Gauss(-Jordan), the same pivoting rule, the same matrix
 rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const double threshold) {  // brilliantrussian.c:603-841
   (void)k; (void)heuristic; (void)threshold;
   return run_echelonize(A, full);

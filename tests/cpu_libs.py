@@ -225,6 +225,7 @@ class Reference:
             fn.restype, fn.argtypes = _I, [MzdPtr, ctypes.POINTER(Mzp), ctypes.POINTER(Mzp), _I]
         L.mzd_echelonize.restype, L.mzd_echelonize.argtypes = _I, [MzdPtr, _I]
         L.mzd_echelonize_pluq.restype, L.mzd_echelonize_pluq.argtypes = _I, [MzdPtr, _I]
+        L.mzd_echelonize_naive.restype, L.mzd_echelonize_naive.argtypes = _I, [MzdPtr, _I]
         L.mzd_echelonize_m4ri.restype, L.mzd_echelonize_m4ri.argtypes = _I, [MzdPtr, _I, _I]
         L._mzd_echelonize_m4ri.restype, L._mzd_echelonize_m4ri.argtypes = _I, [MzdPtr, _I, _I, _I, ctypes.c_double]
         for name in ("mzd_apply_p_right", "mzd_apply_p_right_trans", "mzd_apply_p_left", "mzd_apply_p_left_trans"):

@@ -18,7 +18,7 @@ def test_echelon_forms_match_reference(oracle, reference, m, n, kind, full):
     Ao = A.copy()
     want = oracle.echelonize(Ao, full)
     for which, k in (("mzd_echelonize_m4ri", 0), ("mzd_echelonize_m4ri", 1), ("mzd_echelonize_m4ri", 3), ("mzd_echelonize_m4ri", 8),
-                     ("mzd_echelonize_pluq", 0), ("mzd_echelonize", 0)):
+                     ("mzd_echelonize_pluq", 0), ("mzd_echelonize", 0), ("mzd_echelonize_naive", 0)):
         Ar = A.copy()
         assert reference.echelonize(Ar, full, which, k) == want, (which, k)
         assert np.array_equal(Ar.valid_words(), Ao.valid_words()), (which, k)

@@ -14,7 +14,7 @@ from m4ri_amd.mzd import Mzd
 from test_ple_oracle import SHAPES, _defects, _make
 
 pytestmark = pytest.mark.gpu
-WHICH = ("mzd_echelonize", "mzd_echelonize_m4ri", "mzd_echelonize_pluq", "_mzd_echelonize_m4ri")
+WHICH = ("mzd_echelonize", "mzd_echelonize_m4ri", "mzd_echelonize_pluq", "_mzd_echelonize_m4ri", "mzd_echelonize_naive")
 
 
 @pytest.fixture(scope="module", autouse=True)
