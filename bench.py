@@ -120,7 +120,8 @@ def cpu_baseline(n_workload: int, budget_s: float = 75.0):
         ref.L.mzd_free(r)
     ts = ts[2:]
     out["config1"] = {"what": "bench_multiplication 4096 4096 4096: mzd_mul(NULL,A,B,0) incl. allocating C, srandom(17) + mzd_randomize inputs, "
-                              "sequential SSE2 build, 10 samples after 2 warm-ups",
+                              "sequential SSE2 build, 10 samples after 2 warm-ups (a fixed count in place of the reference's adaptive stop rule, "
+                              "bench/benchmarking.c:502-603: >= 2 samples until the 99 % CI is within 1 % of the mean)",
                       "seconds_mean": sum(ts) / len(ts), "seconds_min": min(ts), "bitops_per_sec": 4096 ** 3 / (sum(ts) / len(ts)), "cores": 1}
     # (2) the workload itself on all cores: mzd_mul_mp (OpenMP build), once, if a 16384^3 probe says it fits the budget
     omp = cpu_libs.reference(openmp=True, tag=tag) or cpu_libs.reference(openmp=True)
@@ -140,6 +141,15 @@ def cpu_baseline(n_workload: int, budget_s: float = 75.0):
             best = min(best, time.perf_counter() - t)
         out["openmp_16384"] = {"value": n ** 3 / best, "cores": ncpu, "sample": f"mzd_mul_mp {n}^3, OpenMP build, {ncpu} threads, best of 2: {best:.2f} s"}
         out.update({"value": n ** 3 / best, "cores": ncpu, "sample": out["openmp_16384"]["sample"]})
+        # BASELINE.md 3 asks for both calls on all cores: the OpenMP build's plain mzd_mul (row-parallel M4RM leaves,
+        # brilliantrussian.c:1121-1123, sequential Strassen) beside mzd_mul_mp (2 x 2 blocks of C, mp.c:206-228)
+        best_mul = 1e30
+        for _ in range(2):
+            t = time.perf_counter()
+            omp.mul(None, A, B, 0)
+            best_mul = min(best_mul, time.perf_counter() - t)
+        out["openmp_mzd_mul_16384"] = {"value": n ** 3 / best_mul, "cores": ncpu,
+                                        "sample": f"mzd_mul {n}^3, OpenMP build, {ncpu} threads, best of 2: {best_mul:.2f} s"}
         predicted = best * (n_workload / n) ** 2.807
         if n_workload > n and predicted <= budget_s:
             del A, B
@@ -244,6 +254,43 @@ def measure_leaf_traffic(argv_size, cutoff, timeout_s=240):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, detail
 
 
+def host_api_timing(A_dev, B_dev, M, L, N, cutoff, runs=3):
+    """The other timed region SURVEY.md 8(d) asks for: entry to return of the drop-in host entry point on ordinary
+    (pageable) host mzd_t matrices -- H2D of A and B, the device schedule, D2H of C -- next to the device-resident
+    number.  Two forms: C given (allocated and touched beforehand) and C == NULL, which is what the reference's
+    bench times (bench/bench_multiplication.c:85-107: mzd_mul(NULL, A, B, cutoff) including the allocation of C; here
+    the fresh 64-byte-aligned block's pages are first touched by the download).  min / median of `runs` after one warm-up."""
+    import ctypes
+    from m4ri_amd.mzd import Mzd
+    lib = m4ri_amd.lib()
+    Ah, Bh, Ch = Mzd(M, L), Mzd(L, N), Mzd(M, N)
+    Ah.valid_words()[:, :] = A_dev.cpu().numpy().view(np.uint64)   # the very operands of the timed steps, now in host memory
+    Bh.valid_words()[:, :] = B_dev.cpu().numpy().view(np.uint64)
+    Ch.buf.fill(0)                                                  # touch C's pages: "C given" means a matrix the caller already uses
+    out = {}
+    lib.mzd_mul(Ch.ptr, Ah.ptr, Bh.ptr, cutoff)                     # warm-up: staging arena, host pipeline threads
+    ts = []
+    for _ in range(runs):
+        t = time.perf_counter()
+        lib.mzd_mul(Ch.ptr, Ah.ptr, Bh.ptr, cutoff)
+        ts.append((time.perf_counter() - t) * 1e3)
+    ts.sort()
+    out["c_given_ms_min"], out["c_given_ms_median"] = ts[0], ts[len(ts) // 2]
+    ts = []
+    for _ in range(runs):
+        t = time.perf_counter()
+        r = lib.mzd_mul(None, Ah.ptr, Bh.ptr, cutoff)
+        ts.append((time.perf_counter() - t) * 1e3)
+        lib.m4ri_amd_result_free(r)
+    ts.sort()
+    out["c_null_ms_min"], out["c_null_ms_median"] = ts[0], ts[len(ts) // 2]
+    gib = 8.0 * (M * Ah.width + L * Bh.width + M * Ch.width) / 2 ** 30
+    out.update({"runs": runs, "GiB_over_pcie": gib, "bitops_per_sec": float(M) * L * N / (out["c_given_ms_min"] * 1e-3),
+                "what": "host mzd_mul(C, A, B, cutoff) on pageable mzd_t matrices, PCIe transfers (and for c_null the allocation of C) "
+                        "inside the timed region; never the headline `value`"})
+    return out
+
+
 def bytes_sched(m, l, n, levels):
     """HBM bytes of the DECLARED, UNFUSED Strassen-Winograd schedule for C = A*B with
     `levels` levels -- every operand read once and every result written once per kernel: a leaf `mul`
@@ -278,6 +325,22 @@ def sha_of_device_rows(t, chunk_rows=8192):
     return h.hexdigest()
 
 
+def self_launch(n_ranks: int) -> int:
+    """Re-run this very command line under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free
+    port) and return its exit code; the ranks' stdout is ours, so rank 0's JSON line is the command's output."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 # ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -296,6 +359,7 @@ def main():
     ap.add_argument("--grid", default="", help="blocks variant: gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
     ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the host-API (PCIe-inclusive) timing")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-verify", action="store_true", help="skip the SHA-256 check of C against the reference's")
     ap.add_argument("--probe", action="store_true", help="internal: one warm-up + one product, nothing else (run under rocprofv3)")
@@ -303,19 +367,35 @@ def main():
                     help="gloo: development aid -- several ranks may share one GPU, pieces are staged through the host")
     ap.add_argument("--check", action="store_true",
                     help="after timing, every rank recomputes the full product on its own GPU and compares the part of C it holds")
+    ap.add_argument("--seeds", default="", help="a,b: splitmix64 seeds of A and B (default 3,4; 5,6 for rect131072)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: initialise the process group anyway and run the N > 1 code path (its collectives, "
+                         "batches and fences) at world size 1 -- how a one-GPU box puts the RCCL path through its paces")
+    ap.add_argument("--dims", default="", help="m,l,n of a general product (overrides --size; ragged sizes exercise the uneven slabs)")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="strassen variant: row chunks per sub-product whose transport overlaps the products (1 = none; -1 = automatic)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it (the reference switches to its multi-core path inside the
+    # same command, bench/bench_multiplication.c:94-103): start the N ranks ourselves, one per GPU, and let rank 0 print
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.probe:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.variant == "auto":
-        args.variant = sharding.default_variant(world)
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never print an n_gpus the command did not ask for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist   # the distributed code path (normally N > 1)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if args.variant == "auto":
+                args.variant = "strassen"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
         if args.backend == "nccl":
@@ -331,10 +411,27 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     n = 16384 if args.workload == "leaf16384" else args.size
-    assert n % 64 == 0
     M, L, N = (131072, 8192, 131072) if args.workload == "rect131072" else (n, n, n)
-    wl, w = L // 64, N // 64  # words per row of A, and of B / C
+    if args.dims:
+        M, L, N = (int(x) for x in args.dims.split(","))
+        assert args.workload == "mul" and min(M, L, N) > 0
+    else:
+        assert n % 64 == 0
+    wl, w = (L + 63) // 64, (N + 63) // 64  # words per row of A, and of B / C
     seeds = (5, 6) if args.workload == "rect131072" else (3, 4)
+    if args.seeds:
+        seeds = tuple(int(x) for x in args.seeds.split(","))
+    auto = args.variant == "auto"
+    if auto:
+        args.variant = sharding.default_variant(world, M, L, N)
+    plan = None
+    if args.variant == "strassen" and multi:
+        plan = m4ri_amd.shard_plan(world, M, L, N, args.shard_levels)
+        if (plan.M, plan.L, plan.N) != (M, L, N):  # the slab-cyclic layout of this script holds unpadded slabs only
+            if not auto:
+                raise SystemExit(f"--variant strassen: {M}x{L}x{N} needs padding to {plan.M}x{plan.L}x{plan.N} in the slab-cyclic layout; "
+                                 "bench.py runs such sizes as row slabs (mzd_mul_mp pads them itself)")
+            args.variant = "slabs"
 
     def words(count):
         return torch.empty(max(1, int(count)), dtype=torch.int64, device="cuda")
@@ -350,17 +447,17 @@ def main():
         exchange = sharding.torch_exchange(dist, staged_device=("cuda" if args.backend == "gloo" else None))
     A = B = Cfull = None
     config_extra = {}
-    if args.variant == "blocks" and args.layout == "distributed" and world > 1:
+    if args.variant == "blocks" and args.layout == "distributed" and multi:
         args.layout = "owner"  # the blocks variant scatters from rank 0 by construction
-    need_full_inputs = world == 1 or args.layout == "owner" or args.variant == "blocks"
-    if need_full_inputs and (world == 1 or rank == 0):
+    need_full_inputs = not multi or args.layout == "owner" or args.variant == "blocks"
+    if need_full_inputs and (not multi or rank == 0):
         A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
         B = torch.empty((L, w), dtype=torch.int64, device="cuda")
         m4ri_amd.fill_dev(A.data_ptr(), wl, M, L, seeds[0], stream)
         m4ri_amd.fill_dev(B.data_ptr(), w, L, N, seeds[1], stream)
 
     # ---------------------------------------------------------------- N == 1 -----------------------
-    if world == 1:
+    if not multi:
         Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
 
         def step():
@@ -373,18 +470,22 @@ def main():
 
     # ---------------------------------------------------------------- N > 1, row slabs + all-gather of B
     elif args.variant == "slabs":
+        # slabs of ceil(rows / world) rows; the last one(s) may be short or empty (sharding.slab_cuts).  The gathered B is
+        # padded to world * kb rows so that the ONE collective keeps equal pieces; the product only reads its first L rows
         rc, bc = sharding.slab_cuts(M, world), sharding.slab_cuts(L, world)
-        mr, lr = rc[1], bc[1]                      # rows of this rank's slab of A / C, and of B
+        ka, kb = sharding.slab_rows(M, world), sharding.slab_rows(L, world)
+        mr, lr = rc[rank + 1] - rc[rank], bc[rank + 1] - bc[rank]   # rows of this rank's slab of A / C, and of B
         staged = args.backend == "gloo"
-        Bfull = torch.empty((L, w), dtype=torch.int64, device="cuda")
-        Cs = torch.empty((mr, w), dtype=torch.int64, device="cuda")
+        Bfull = torch.empty((world * kb, w), dtype=torch.int64, device="cuda")
+        Cs = torch.empty((max(mr, 1), w), dtype=torch.int64, device="cuda")[:mr]
+        As = torch.empty((max(mr, 1), wl), dtype=torch.int64, device="cuda")[:mr]
         if args.layout == "distributed":           # the slabs are where the inputs live
-            As = torch.empty((mr, wl), dtype=torch.int64, device="cuda")
-            Bs = torch.empty((lr, w), dtype=torch.int64, device="cuda")
-            m4ri_amd.fill_rows_dev(As.data_ptr(), wl, rc[rank], mr, L, seeds[0], stream)
-            m4ri_amd.fill_rows_dev(Bs.data_ptr(), w, bc[rank], lr, N, seeds[1], stream)
+            Bs = torch.zeros((kb, w), dtype=torch.int64, device="cuda")
+            if mr:
+                m4ri_amd.fill_rows_dev(As.data_ptr(), wl, rc[rank], mr, L, seeds[0], stream)
+            if lr:
+                m4ri_amd.fill_rows_dev(Bs.data_ptr(), w, bc[rank], lr, N, seeds[1], stream)
         else:
-            As = torch.empty((mr, wl), dtype=torch.int64, device="cuda")
             Bs = None
             if rank == 0:
                 Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
@@ -396,17 +497,20 @@ def main():
                     if rank == 0:
                         sends += [(r, A[rc[r]:rc[r + 1]].reshape(-1)), (r, B.reshape(-1))]
                     elif rank == r:
-                        recvs += [(0, As.reshape(-1)), (0, Bfull.reshape(-1))]
+                        recvs += [(0, As.reshape(-1)), (0, Bfull[:L].reshape(-1))]
                 if rank == 0:
                     As.copy_(A[:mr])
-                    Bfull.copy_(B)
-                exchange(sends, recvs)
+                    Bfull[:L].copy_(B)
+                exchange([x for x in sends if x[1].numel()], [x for x in recvs if x[1].numel()])
             else:
                 sharding.all_gather_rows(dist, Bfull, Bs, staged=staged)   # the ONE collective of the variant
-            m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr(), wl, Bfull.data_ptr(), w, mr, L, N, False, args.cutoff, stream)
+            if mr:
+                m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr(), wl, Bfull.data_ptr(), w, mr, L, N, False, args.cutoff, stream)
             if args.layout == "owner":
                 sends, recvs = [], []
                 for r in range(1, world):
+                    if rc[r + 1] == rc[r]:
+                        continue
                     if rank == 0:
                         recvs.append((r, Cfull[rc[r]:rc[r + 1]].reshape(-1)))
                     elif rank == r:
@@ -414,20 +518,22 @@ def main():
                 if rank == 0:
                     Cfull[:mr].copy_(Cs)
                 exchange(sends, recvs)
-        per_rank_product = [mr, L, N]
+        per_rank_product = [ka, L, N]
         config_extra.update({"parallelism": f"row slabs x{world} + all-gather of B", "variant": "slabs", "layout": args.layout,
-                             "bytes_over_links_per_step": 8 * L * w * (world - 1) // world * (1 if args.layout == "distributed" else 0),
-                             "collective": "all_gather_into_tensor(B) -- RCCL" if args.layout == "distributed" else "send/recv scatter + gather"})
+                             "slab_rows": [ka, kb],
+                             "bytes_over_links_per_step": 8 * kb * w * (world - 1) * (1 if args.layout == "distributed" else 0),
+                             "collective": "all_gather_into_tensor(B)" if args.layout == "distributed" else "batched send/recv scatter + gather"})
 
     # ---------------------------------------------------------------- N > 1, Strassen sub-products --
     elif args.variant == "strassen":
-        plan = m4ri_amd.shard_plan(world, M, L, N, args.shard_levels)
-        assert (plan.M, plan.L, plan.N) == (M, L, N), "bench sizes divide evenly: no padding"
         names = {"local_a": m4ri_amd.BUF_LOCAL_A, "local_b": m4ri_amd.BUF_LOCAL_B, "local_c": m4ri_amd.BUF_LOCAL_C,
                  "child_a": m4ri_amd.BUF_CHILD_A, "child_b": m4ri_amd.BUF_CHILD_B, "slabs_p": m4ri_amd.BUF_SLABS_P,
                  "oper_a": m4ri_amd.BUF_OPER_A, "oper_b": m4ri_amd.BUF_OPER_B, "prod": m4ri_amd.BUF_PROD}
         bufs = {k: words(m4ri_amd.shard_buffer_words(plan, rank, wh)) for k, wh in names.items()}
         runs_a, runs_b = sharding.local_rows(plan, rank, 0), sharding.local_rows(plan, rank, 1)
+        # row chunks per sub-product whose transport runs under the products (sharding.run_strassen_sharded): two when one
+        # product per rank is all there is to hide transfers behind and its halves keep the engine's Strassen depth
+        chunks = args.overlap if args.overlap > 0 else (2 if (plan.levels == 1 and plan.bm >= 4 * sharding.ENGINE_MIN_HALF[0]) else 1)
         sa, sb = runs_a[0][1], runs_b[0][1]
         if args.layout == "distributed":  # the slabs are where the inputs live: fill them straight from the streams
             for b, (g0, rows) in enumerate(runs_a):
@@ -473,11 +579,12 @@ def main():
             m4ri_amd.shard_down_dev(plan, rank, bufs["local_a"].data_ptr(), wl, bufs["local_b"].data_ptr(), w,
                                     bufs["child_a"].data_ptr(), bufs["child_b"].data_ptr(), stream)
 
-        def do_product(jl, j):
-            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * jl * plan.bm * plan.cwn, plan.cwn,
-                             bufs["oper_a"].data_ptr() + 8 * jl * plan.bm * plan.cwl, plan.cwl,
+        def do_product(jl, j, row0=0, rows=None):
+            rows = plan.bm if rows is None else rows
+            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwn, plan.cwn,
+                             bufs["oper_a"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwl, plan.cwl,
                              bufs["oper_b"].data_ptr() + 8 * jl * plan.bl * plan.cwn, plan.cwn,
-                             plan.bm, plan.bl, plan.cwn * 64, False, args.cutoff, stream)
+                             rows, plan.bl, plan.cwn * 64, False, args.cutoff, stream)
 
         def do_up():
             m4ri_amd.shard_up_dev(plan, rank, bufs["slabs_p"].data_ptr(), bufs["local_c"].data_ptr(), w, False, stream)
@@ -485,14 +592,16 @@ def main():
         def step():
             if args.layout == "owner":
                 scatter_from_owner()
-            sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s))
+            sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks)
             if args.layout == "owner":
                 gather_to_owner()
         per_rank_product = [plan.bm, plan.bl, plan.cwn * 64]
         moved = sum(pc.words * 8 for side, j, r, pc in sharding.strassen_pieces(plan, (0, 1, 2)) if pc.holder != pc.owner)
         config_extra.update({"parallelism": f"strassen-sharded x{world}", "variant": "strassen", "layout": args.layout, "sharded_levels": plan.levels,
                              "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
-                             "bytes_over_links_per_step": moved, "links_used": world * (world - 1),
+                             "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": chunks,
+                             "collective": f"batched isend/irecv (one group per batch: operands out per round and row chunk, products back "
+                                           f"per chunk; {len(sharding.chunk_bounds(plan, chunks))} chunk(s) x {-(-plan.nprod // world)} round(s))",
                              "scatter_gather_bytes_per_step": (8 * (M * wl + L * w + M * w) * (world - 1) // world) if args.layout == "owner" else 0})
 
     # ---------------------------------------------------------------- N > 1, blocks of C -----------
@@ -568,7 +677,11 @@ def main():
             region = sharding.run_sharded(bplan, multiply, xor_rows, send_recv)
             gather_blocks(region)
         per_rank_product = [r1 - r0, k1 - k0, c1 - c0]
-        config_extra.update({"parallelism": f"blocks {list(bplan.grid)}", "variant": "blocks", "layout": "owner", "grid": list(bplan.grid)})
+        config_extra.update({"parallelism": f"blocks {list(bplan.grid)}", "variant": "blocks", "layout": "owner", "grid": list(bplan.grid),
+                             "collective": "batched isend/irecv: scatter from rank 0, pairwise XOR exchange, gather to rank 0"})
+    if dist is not None:
+        config_extra.update({"backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (pieces staged through the host: development aid)",
+                             "ranks": dist.get_world_size()})
 
     # ---------------------------------------------------------------- probe mode (under rocprofv3) --
     if args.probe:
@@ -607,7 +720,7 @@ def main():
 
     # ---------------------------------------------------------------- correctness of what was timed --
     verified = None
-    if world == 1 and not args.no_verify and args.workload != "leaf16384":
+    if not multi and not args.no_verify and args.workload != "leaf16384":
         want = golden_sha("mul", M, L, N, seeds)
         if want is not None:
             got = sha_of_device_rows(Cfull)
@@ -616,7 +729,42 @@ def main():
             if got != want:
                 print(json.dumps({"error": "C differs from the reference", "sha256": got, "expected": want}), flush=True)
                 raise SystemExit(4)
-    if args.check and world > 1:
+    if multi and not args.no_verify and args.workload != "leaf16384":
+        # the distributed result against the reference's: gather the ranks' rows of C on rank 0 (outside the timed region,
+        # over the same transport) and compare its SHA-256 with the golden one, when tests/golden holds one for this product
+        want = golden_sha("mul", M, L, N, seeds)
+        if want is not None:
+            if Cfull is None and rank == 0:
+                Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+            if args.layout == "distributed" and args.variant in ("slabs", "strassen"):
+                def rows_of(r):
+                    if args.variant == "slabs":
+                        return [(rc[r], rc[r + 1] - rc[r], 0)]
+                    rr = sharding.local_rows(plan, r, 0)
+                    return [(g0, rows, b * rr[0][1] * w) for b, (g0, rows) in enumerate(rr)]
+                mine = Cs.reshape(-1) if args.variant == "slabs" else bufs["local_c"]
+                sends, recvs = [], []
+                for r in range(world):
+                    for g0, rows, off in rows_of(r):
+                        if rows == 0:
+                            continue
+                        if rank == 0 and r == 0:
+                            Cfull[g0:g0 + rows].reshape(-1).copy_(mine[off:off + rows * w])
+                        elif rank == 0:
+                            recvs.append((r, Cfull[g0:g0 + rows].reshape(-1)))
+                        elif rank == r:
+                            sends.append((0, mine[off:off + rows * w]))
+                exchange(sends, recvs)
+            if rank == 0:
+                torch.cuda.synchronize()
+                got = sha_of_device_rows(Cfull)
+                verified = {"sha256": got, "matches_reference": got == want,
+                            "what": f"C of the last timed step, gathered from the {world} ranks, vs the real reference's product of the same inputs "
+                                    "(tests/golden/sha256.json)"}
+                if got != want:
+                    print(json.dumps({"error": "C differs from the reference", "sha256": got, "expected": want}), flush=True)
+                    raise SystemExit(4)
+    if args.check and multi:
         fullA = torch.empty((M, wl), dtype=torch.int64, device="cuda")
         fullB = torch.empty((L, w), dtype=torch.int64, device="cuda")
         m4ri_amd.fill_dev(fullA.data_ptr(), wl, M, L, seeds[0], stream)
@@ -651,7 +799,7 @@ def main():
         leaf_ops = float(stats.leaf_m) * stats.leaf_l * stats.leaf_n * stats.leaf_products
         leaf_ms_per_product = leaf_launch_ms * max(1, int(stats.leaf_launches))
         traffic, traffic_detail = None, "not measured for this configuration"
-        if world == 1 and args.workload == "mul" and not args.no_traffic:
+        if not multi and args.workload == "mul" and not args.no_traffic:
             traffic, traffic_detail = measure_leaf_traffic(n, args.cutoff)
         out = {
             "metric": "gf2_matmul_n3_equiv_bitops_per_sec",
@@ -674,7 +822,7 @@ def main():
                 "m": M, "l": L, "n": N,
                 "ops_counted": "m*l*n bit multiply-accumulates (one AND+XOR = 1 op), classical count credited to Strassen",
                 "input": f"splitmix64 seeds {seeds[0]} (A), {seeds[1]} (B), uniform bits, resident in HBM"
-                         + ("" if world == 1 else " (slab-cyclic over the ranks)" if args.layout == "distributed" else " of rank 0; C gathered to rank 0"),
+                         + ("" if not multi else " (slab-cyclic over the ranks)" if args.layout == "distributed" else " of rank 0; C gathered to rank 0"),
                 "per_rank_product": per_rank_product,
                 "strassen_levels": int(stats.levels),
                 "leaf_shape": [int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n)],
@@ -718,7 +866,7 @@ def main():
             # the whole product against the HBM roofline in SURVEY.md 8(d)'s terms (schedule bytes of
             # this rank's products / step time); the compulsory bytes beside it
             pm, pl, pn = per_rank_product
-            nprod_rank = 1 if (world == 1 or args.variant != "strassen") else len(sharding.owned_products(plan, 0))
+            nprod_rank = 1 if (not multi or args.variant != "strassen") else len(sharding.owned_products(plan, 0))
             bs = float(bytes_sched(pm, pl, pn, int(stats.levels))) * nprod_rank
             out["roofline_schedule"] = {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -732,7 +880,13 @@ def main():
                         "our fused three-level passes move far fewer bytes; copy_peak = this GPU's measured "
                         "device-to-device copy rate (read + write bytes)",
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and args.workload != "leaf16384" and not args.no_api:
+            try:
+                out["api"] = host_api_timing(A, B, M, L, N, args.cutoff)
+                out["api_ms"] = out["api"]["c_given_ms_min"]
+            except Exception as e:  # reported beside the number, never required for it
+                out["api"] = {"error": repr(e)}
+        if not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n)
             except Exception as e:  # the baseline is reported, never required for the GPU number

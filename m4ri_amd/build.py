@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libm4ri_amd.so")
 SOURCES = ["m4rm_leaf.hip", "a4_pack.hip", "m4rm8q_leaf.hip", "aux_kernels.hip", "engine.hip", "mzd_api.hip", "multi.hip", "trsm.hip", "ple.hip", "elim.hip", "echelon.hip", "solve.hip", "transpose.hip", "io.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fvisibility-inlines-hidden"]
 
 
 def _hipcc() -> str:
@@ -25,6 +25,28 @@ def _hipcc() -> str:
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found: libm4ri_amd.so cannot be built (no CPU fallback exists)")
     return exe
+
+
+def declared_functions() -> list[str]:
+    """The functions include/m4ri_amd.h declares: M4RI's own names for this path and the m4ri_amd_* extensions.
+    They are the library's whole dynamic symbol table (export_map)."""
+    import re
+    text = open(os.path.join(HERE, "..", "include", "m4ri_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def export_map() -> str:
+    """Linker version script with the explicit export list.  The library is an LD_PRELOAD interposer: every stray
+    global (the engine's gf2_* launchers, libstdc++ template instantiations) would be a collision risk in the host
+    program, so only the declared names leave the .so; everything else is local."""
+    path = os.path.join(OBJ, "exports.map")
+    text = "{\n  global:\n" + "".join(f"    {n};\n" for n in declared_functions()) + "  local:\n    *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -56,8 +78,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lz"])
+    emap = export_map()
+    if force or jobs or _stale(LIB, objs + [emap]):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, f"-Wl,--version-script={emap}", "-ldl", "-lz"])
     return LIB
 
 

@@ -147,45 +147,113 @@ def owned_products(plan, rank):
     return list(range(rank, plan.nprod, plan.world))
 
 
-def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local):
+class _Done:
+    """Handle of an exchange that has already completed (synchronous transports)."""
+    def wait(self):
+        return None
+
+
+def _post(exchange, sends, recvs):
+    """Start one batch on the transport and return its handle (.wait()).  A transport with a `post` attribute moves the
+    batch asynchronously (torch_exchange under RCCL: the batch runs on the communicator's stream, wait() makes the compute
+    stream wait for it, the host never blocks); a plain callable completes before returning."""
+    post = getattr(exchange, "post", None)
+    if post is not None:
+        return post(sends, recvs)
+    exchange(sends, recvs)
+    return _Done()
+
+
+def chunk_bounds(plan, chunks: int):
+    """Row chunks of a sub-product for the overlapped schedule: chunk c = the slabs of ranks [W c / chunks, W (c+1) / chunks),
+    i.e. rows [cut(r_lo), cut(r_hi)) of the sub-product's A operand and of its result -- whole pieces, nothing is cut.
+    Returns [(r_lo, r_hi, row0, rows)], empty chunks dropped."""
+    import m4ri_amd
+    out = []
+    for c in range(max(1, chunks)):
+        lo, hi = plan.world * c // max(1, chunks), plan.world * (c + 1) // max(1, chunks)
+        r0 = int(m4ri_amd.lib().m4ri_amd_shard_cut(plan.bm, plan.world, lo))
+        r1 = int(m4ri_amd.lib().m4ri_amd_shard_cut(plan.bm, plan.world, hi))
+        if hi > lo:
+            out.append((lo, hi, r0, r1 - r0))
+    return out
+
+
+def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks: int = 1):
     """One product C = A*B over plan.world ranks; this is rank `rank`'s part.
 
     bufs: dict of 1-D word tensors/arrays keyed 'child_a', 'child_b', 'slabs_p', 'oper_a', 'oper_b', 'prod'
           (sizes: m4ri_amd.shard_buffer_words).
     down():            local parents of A and B -> bufs['child_a'], bufs['child_b']   (local Winograd down pass)
-    product(jl, j):    bufs['prod'][jl] = bufs['oper_a'][jl] * bufs['oper_b'][jl]      (owned sub-product number jl)
+    product(jl, j, row0, rows): rows [row0, row0 + rows) of bufs['prod'][jl] = the same rows of bufs['oper_a'][jl]
+                       times bufs['oper_b'][jl]                                        (owned sub-product number jl)
     up():              bufs['slabs_p'] -> local parent of C                            (local Winograd up pass)
-    exchange(sends, recvs): sends = [(dst_rank, view)], recvs = [(src_rank, view)], each list in the
-                       canonical piece order; must complete before returning.
+    exchange:          the transport: exchange(sends, recvs) with sends = [(dst_rank, view)], recvs = [(src_rank, view)],
+                       each list in the canonical piece order; optionally exchange.post(sends, recvs) -> handle with
+                       .wait() for transports that run a batch in the background (see _post).
     copy_local(dst_view, src_view): a piece whose holder and owner are this rank.
+
+    The schedule (the reference's block-parallel template has no transport to hide, m4ri/mp.c:191-228; here the pieces
+    cross xGMI links, so the walk is laid out for overlap).  Sub-products are multiplied in ROUNDS (round q = the q-th
+    owned product of every rank, j in [q W, (q+1) W)), each in `chunks` row chunks (chunk_bounds).  All ranks post the
+    same sequence of batches, every batch one group of point-to-point transfers:
+
+        down;  for every round q:  post B(q), post A(q, 0), ..., post A(q, chunks-1)        <- everything outbound, at once
+        for every round q, chunk c:  wait B(q) [c == 0], wait A(q, c);  product rows of chunk c;  post P(q, c)
+        wait every P;  up
+
+    A product needs ALL of its B operand but only chunk c's rows of A for chunk c's rows of the result, and result rows
+    are needed nowhere before the up pass: so A(q, c+1) and every later round's operands travel while chunk (q, c) is
+    multiplied, and P(q, c) travels back under the next chunk's product.  Exposed on the links are B(0), A(0, 0) and the
+    last P only.  chunks = 1 with a synchronous transport is the plain three-phase walk (same batches, same bits).
     """
     child = {0: bufs["child_a"], 1: bufs["child_b"]}
     oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
+    W = plan.world
+    rounds = -(-plan.nprod // W)
+    bounds = chunk_bounds(plan, chunks)
+    table = {}
+    for side, j, r, pc in strassen_pieces(plan, (0, 1, 2)):
+        table.setdefault((side, j // W), []).append((r, pc))
+
+    def batch(side, q, r_lo, r_hi):
+        sends, recvs = [], []
+        for r, pc in table.get((side, q), ()):
+            if not (r_lo <= r < r_hi):
+                continue
+            if side < 2:   # operand slab: holder -> owner
+                src = child[side][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
+                dst = oper[side][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
+                frm, to = pc.holder, pc.owner
+            else:          # product slab: owner -> holder
+                src = bufs["prod"][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
+                dst = bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
+                frm, to = pc.owner, pc.holder
+            if frm == rank and to == rank:
+                copy_local(dst, src)
+            elif frm == rank:
+                sends.append((to, src))
+            elif to == rank:
+                recvs.append((frm, dst))
+        return _post(exchange, sends, recvs)
+
     down()
-    sends, recvs = [], []
-    for side, j, r, pc in strassen_pieces(plan, (0, 1)):
-        src = child[side][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
-        dst = oper[side][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
-        if pc.holder == rank and pc.owner == rank:
-            copy_local(dst, src)
-        elif pc.holder == rank:
-            sends.append((pc.owner, src))
-        elif pc.owner == rank:
-            recvs.append((pc.holder, dst))
-    exchange(sends, recvs)
-    for jl, j in enumerate(owned_products(plan, rank)):
-        product(jl, j)
-    sends, recvs = [], []
-    for side, j, r, pc in strassen_pieces(plan, (2,)):
-        src = bufs["prod"][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
-        dst = bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
-        if pc.holder == rank and pc.owner == rank:
-            copy_local(dst, src)
-        elif pc.owner == rank:
-            sends.append((pc.holder, src))
-        elif pc.holder == rank:
-            recvs.append((pc.owner, dst))
-    exchange(sends, recvs)
+    inbound = {}
+    for q in range(rounds):
+        inbound[(1, q)] = batch(1, q, 0, W)
+        for c, (lo, hi, _, _) in enumerate(bounds):
+            inbound[(0, q, c)] = batch(0, q, lo, hi)
+    owned = owned_products(plan, rank)
+    returns = []
+    for q in range(rounds):
+        inbound[(1, q)].wait()
+        for c, (lo, hi, row0, rows) in enumerate(bounds):
+            inbound[(0, q, c)].wait()
+            if q < len(owned) and rows:
+                product(q, owned[q], row0, rows)
+            returns.append(batch(2, q, lo, hi))
+    for h in returns:
+        h.wait()
     up()
 
 
@@ -201,14 +269,29 @@ def local_rows(plan, rank, which):
 
 def torch_exchange(dist, staged_device=None):
     """Transport over torch.distributed P2P ops (backend nccl == RCCL: every piece is one send/recv pair on
-    the direct xGMI link between its two ranks; all pieces of a phase are posted as one batch, so all links
+    the direct xGMI link between its two ranks; all pieces of a batch are posted as one group, so all links
     of the mesh work concurrently).  staged_device: tensors live on that device but the backend (gloo)
-    cannot move them -- stage through the host (development / one-GPU tests only)."""
+    cannot move them -- stage through the host (development / one-GPU tests only).
+
+    The returned callable completes a batch before returning; its `.post(sends, recvs)` starts the batch and returns a
+    handle whose wait() orders the CURRENT stream behind it (RCCL: the host does not block, so transfers overlap whatever
+    the compute stream is doing meanwhile; gloo / staged: the batch is complete when post returns)."""
     import torch
 
-    def exchange(sends, recvs):
+    class _Pending:
+        def __init__(self, reqs, copies):
+            self.reqs, self.copies = reqs, copies
+
+        def wait(self):
+            for req in self.reqs:
+                req.wait()
+            for t, v in self.copies:
+                v.copy_(t)
+            self.reqs, self.copies = [], []
+
+    def post(sends, recvs):
         if not sends and not recvs:
-            return
+            return _Done()
         if staged_device is not None:
             outs = [(dst, v.cpu()) for dst, v in sends]
             ins = [(src, torch.empty(v.shape, dtype=v.dtype), v) for src, v in recvs]
@@ -217,17 +300,18 @@ def torch_exchange(dist, staged_device=None):
                 req.wait()
             for _, t, v in ins:
                 v.copy_(t)
-            return
+            return _Done()
         # RCCL moves contiguous tensors only: the pieces are contiguous by construction (row slabs, whole buffers), but a view
         # that is not goes through a contiguous temporary rather than aborting the job
         outs = [(dst, v if v.is_contiguous() else v.contiguous()) for dst, v in sends]
         ins = [(src, v if v.is_contiguous() else torch.empty(v.shape, dtype=v.dtype, device=v.device), v) for src, v in recvs]
         ops = [dist.P2POp(dist.isend, t, dst) for dst, t in outs] + [dist.P2POp(dist.irecv, t, src) for src, t, _ in ins]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for _, t, v in ins:
-            if t is not v:
-                v.copy_(t)
+        return _Pending(dist.batch_isend_irecv(ops), [(t, v) for _, t, v in ins if t is not v])
+
+    def exchange(sends, recvs):
+        post(sends, recvs).wait()
+
+    exchange.post = post
     return exchange
 
 
@@ -239,15 +323,25 @@ def torch_exchange(dist, staged_device=None):
 # variant gives up is Strassen depth in the row direction (a slab of m/W rows has log2(W) levels fewer), which is
 # why the Strassen-sharded variant overtakes it at 8 GPUs while the slabs win at 2 and 4.
 # ==================================================================================================
+def slab_rows(rows: int, world: int) -> int:
+    """Rows of a full slab: ceil(rows / W)."""
+    return -(-rows // world)
+
+
 def slab_cuts(rows: int, world: int):
-    """Row boundaries of the W slabs (equal slabs; the all-gather wants equal pieces: rows must divide)."""
-    assert rows % world == 0, (rows, world)
-    return [k * (rows // world) for k in range(world + 1)]
+    """Row boundaries of the W slabs: slab r = rows [r k, (r+1) k) clipped to the matrix, k = ceil(rows / W).  When
+    W does not divide `rows` the last slab is short (and with rows < W(W-1) trailing slabs may be empty): global row g
+    always sits at position g of the gathered buffer, so a ragged size needs no second code path -- the ranks' buffers
+    are padded to k rows and the gathered one to W k, the collective keeps equal pieces (all_gather_rows)."""
+    k = slab_rows(rows, world)
+    return [min(r * k, rows) for r in range(world + 1)]
 
 
 def all_gather_rows(dist, full, mine, staged=False):
-    """full (W * k rows) <- the ranks' `mine` (k rows each) in rank order: dist.all_gather_into_tensor, or its
-    host-staged equivalent for backends that cannot move device tensors (gloo in the one-GPU tests)."""
+    """full (W * k rows) <- the ranks' `mine` (k rows each, the short last slab padded) in rank order:
+    dist.all_gather_into_tensor, or its host-staged equivalent for backends that cannot move device tensors (gloo
+    in the one-GPU tests)."""
+    assert full.shape[0] == dist.get_world_size() * mine.shape[0], (tuple(full.shape), tuple(mine.shape))
     import torch
     if not staged:
         dist.all_gather_into_tensor(full.view(-1), mine.contiguous().view(-1))
@@ -259,7 +353,25 @@ def all_gather_rows(dist, full, mine, staged=False):
         full[r * k:(r + 1) * k].copy_(t)
 
 
-def default_variant(world: int) -> str:
-    """slabs up to 4 ranks (one all-gather of B; 2 ranks share a single link, which the Strassen-sharded exchange
-    would saturate), the Strassen sub-products from 5 ranks on (arithmetic for n = 65536)."""
-    return "slabs" if world <= 4 else "strassen"
+# the single-GPU engine's own rule for one more Strassen-Winograd level (engine.hip: default depth): a leaf keeps at
+# least one 4096-row tile, 4096 columns and 8192 inner bits
+ENGINE_MIN_HALF = (4096, 8192, 4096)
+
+
+def default_variant(world: int, m: int = 0, l: int = 0, n: int = 0) -> str:
+    """What `--variant auto` hands out to the ranks.
+
+    * up to 4 ranks: row slabs (one all-gather of B; 2 ranks share a single link, which the Strassen-sharded exchange
+      would saturate);
+    * from 5 ranks on: the sub-products of the top Strassen level(s) -- but only for a product the single-GPU engine
+      would itself split once more in all three dimensions.  A short inner dimension (BASELINE.json configs[4]:
+      131072 x 8192 x 131072, l/2 < 8192) or a thin operand leaves nothing for a Strassen level to save: such shapes
+      take row slabs of A and C with B replicated at every world size, no reduction (the reference's
+      own row parallelism, m4ri/brilliantrussian.c:1121-1123).
+    The owner layout and the blocks variant scatter from rank 0 inside the timed region and are never selected here.
+    """
+    if world <= 4:
+        return "slabs"
+    if m and l and n and (m // 2 < ENGINE_MIN_HALF[0] or l // 2 < ENGINE_MIN_HALF[1] or n // 2 < ENGINE_MIN_HALF[2]):
+        return "slabs"
+    return "strassen"

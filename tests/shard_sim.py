@@ -50,7 +50,7 @@ def local_parent(plan, rank, which, M: Mzd, width_words):
     return out
 
 
-def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange):
+def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
     """Rank `rank`'s whole part on CPU arrays; returns its local parent of C and its row runs."""
     LA = local_parent(plan, rank, 0, A, plan.L // 64)
     LB = local_parent(plan, rank, 1, B, plan.N // 64)
@@ -66,11 +66,14 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange):
                 ch = down(X, bside, plan.levels)
                 bufs[key][:plan.nprod * s * cw] = np.concatenate([c.reshape(-1) for c in ch])
 
-    def do_product(jl, j):
-        a = Mzd(plan.bm, plan.cwl * 64, buf=bufs["oper_a"][jl * plan.bm * plan.cwl:(jl + 1) * plan.bm * plan.cwl], rowstride=plan.cwl)
+    def do_product(jl, j, row0=0, rows=None):
+        rows = plan.bm if rows is None else rows
+        a0 = jl * plan.bm * plan.cwl + row0 * plan.cwl
+        a = Mzd(rows, plan.cwl * 64, buf=bufs["oper_a"][a0:a0 + rows * plan.cwl], rowstride=plan.cwl)
         b = Mzd(plan.bl, plan.cwn * 64, buf=bufs["oper_b"][jl * plan.bl * plan.cwn:(jl + 1) * plan.bl * plan.cwn], rowstride=plan.cwn)
         p = oracle.mul(None, a.copy(), b.copy(), 0)
-        bufs["prod"][jl * plan.bm * plan.cwn:(jl + 1) * plan.bm * plan.cwn] = p.masked().reshape(-1)
+        p0 = jl * plan.bm * plan.cwn + row0 * plan.cwn
+        bufs["prod"][p0:p0 + rows * plan.cwn] = p.masked().reshape(-1)
 
     def do_up():
         if sa:
@@ -82,7 +85,7 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange):
     def copy_local(dst, src):
         dst[:] = src
 
-    sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local)
+    sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local, chunks=chunks)
     return out["C"], sharding.local_rows(plan, rank, 0)
 
 

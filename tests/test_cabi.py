@@ -41,6 +41,15 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert n in names, f"{n} is bound but not declared in include/m4ri_amd.h"
 
 
+def test_nothing_but_the_declared_names_is_exported():
+    """The library is an LD_PRELOAD interposer: every stray global is a collision risk in the host program.  Its dynamic
+    symbol table is exactly the header's list (m4ri_amd/build.py: export_map) -- no gf2_* launchers, no libstdc++
+    template instantiations."""
+    out = subprocess.run(["nm", "-D", "--defined-only", m4ri_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(declared_functions()), sorted(exported ^ set(declared_functions()))
+
+
 def test_m4ri_drop_in_names_present():
     # SURVEY.md 8(b): the symbols a replacement for this path must export
     need = ["mzd_mul", "mzd_addmul", "_mzd_mul_even", "_mzd_addmul_even", "_mzd_addmul", "mzd_mul_m4rm",

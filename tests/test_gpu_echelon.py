@@ -101,8 +101,7 @@ def test_echelon_forms_at_scale_vs_reference_sha256():
     """Against SHA-256 values of the real reference's mzd_echelonize_m4ri / mzd_echelonize_pluq results
     (tests/golden/echelon.json, make_golden.py --echelon)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "echelon.json")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/echelon.json not generated")
+    assert os.path.exists(path), "committed fixture tests/golden/echelon.json is missing"
     for e in json.load(open(path)):
         A = _defects(e["m"], e["n"], e["seed"], e["m"] // 16, e["m"] // 64)
         r = m4ri_amd.mzd_echelonize(A, e["full"])

@@ -121,3 +121,95 @@ def test_baseline_sizes_through_the_sharded_path_vs_reference_sha256(m, l, n, se
     C = Mzd.init(m, n)
     m4ri_amd.mul_multi(C, A, B, False, 0, 0)
     assert hashlib.sha256(C.masked().tobytes()).hexdigest() == want[0]
+
+
+# ---- bench.py as the driver runs it: the command itself starts the ranks ---------------------------------------------
+def _bench(args, timeout=900):
+    """`python bench.py ...` exactly as typed (no launcher around it); returns rank 0's JSON line and the whole stdout."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0]), r.stdout
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it runs two ranks and says so (the reference switches to its
+    multi-core path inside the same command, bench/bench_multiplication.c:94-103); a --gpus request is never answered with
+    a one-GPU line."""
+    out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["variant"] == "slabs"
+    assert "all_gather" in out["config"]["collective"] and stdout.count("-> OK") == 2
+    out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--variant", "strassen", "--overlap", "2"])
+    assert out["n_gpus"] == 2 and out["config"]["overlap_chunks"] == 2 and stdout.count("-> OK") == 2
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--size", "8192", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout   # a launcher that started one rank for --gpus 8: refuse, do not print n_gpus 1
+
+
+def test_bench_config5_at_8_ranks_takes_row_slabs_and_matches_the_reference():
+    """BASELINE.json configs[4] (131072 x 8192 x 131072) at 8 ranks: `auto` = row slabs of A and C + ONE all-gather of B
+    (the reference's row parallelism, m4ri/brilliantrussian.c:1121-1123), never the Strassen split; the gathered
+    C against the real reference's SHA-256, and every rank's slab against the product it recomputes alone."""
+    out, stdout = _bench(["--workload", "rect131072", "--gpus", "8", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["variant"] == "slabs" and out["config"]["per_rank_product"] == [16384, 8192, 131072]
+    assert out["verified"]["matches_reference"] is True and stdout.count("-> OK") == 8
+
+
+def test_bench_ragged_slabs_match_the_reference():
+    """Row slabs when the world size divides nothing: 100003 x 50021 x 70017 over 3 ranks (slabs of 33335 / 33335 / 33333 rows
+    of A, 16674 / 16674 / 16673 of B, the gathered B padded), gathered C vs the reference's SHA-256."""
+    out, stdout = _bench(["--dims", "100003,50021,70017", "--seeds", "21,22", "--gpus", "3", "--backend", "gloo", "--check", "--steps", "1",
+                          "--warmup", "1", "--no-cpu-baseline"], timeout=1500)
+    assert out["n_gpus"] == 3 and out["config"]["variant"] == "slabs" and out["config"]["slab_rows"] == [33335, 16674]
+    assert out["verified"]["matches_reference"] is True and stdout.count("-> OK") == 3
+
+
+# ---- RCCL on the lease: the nccl backend at world size 1 -------------------------------------------------------------------
+_NCCL_PROBE = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from m4ri_amd import sharding
+x = sharding.torch_exchange(dist)
+x([], [])                                                   # an empty batch is a no-op, not an RCCL call
+a = torch.arange(1 << 16, dtype=torch.int64, device="cuda"); b = torch.zeros_like(a)
+x([(0, a)], [(0, b)])                                       # one self-addressed send/recv pair in one group
+torch.cuda.synchronize(); assert torch.equal(a, b)
+c = torch.zeros_like(a); d = torch.zeros((64, 1024), dtype=torch.int64, device="cuda")
+h1 = x.post([(0, a), (0, a[:4096])], [(0, c), (0, d[:, :64])])    # two pairs, one into a NON-contiguous view (temporary + copy back)
+h2 = x.post([(0, c)], [(0, b)])                             # a second batch queued behind the first before either is waited for
+h1.wait(); h2.wait(); torch.cuda.synchronize()
+assert torch.equal(c, a) and torch.equal(d[:, :64].reshape(-1), a[:4096]) and not d[:, 64:].any()
+mine = torch.arange(5 * 7, dtype=torch.int64, device="cuda").reshape(5, 7); full = torch.empty((5, 7), dtype=torch.int64, device="cuda")
+sharding.all_gather_rows(dist, full, mine)                  # the slabs variant's one collective
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks
+dist.barrier(); torch.cuda.synchronize()
+assert torch.equal(full, mine) and float(t.item()) == 1.5
+dist.destroy_process_group()
+print("RCCL world-size-1 probe OK")
+'''
+
+
+def test_rccl_backend_at_world_size_1():
+    """The transport code of the N > 1 path (sharding.torch_exchange incl. its asynchronous post/wait, all_gather_rows, the
+    barrier and the max-reduce of bench.py) through the real nccl (= RCCL) backend, the only way a one-GPU box can: world
+    size 1, self-addressed batches.  API misuse shows up here, not in the driver's 8-GPU run."""
+    r = subprocess.run([sys.executable, "-c", _NCCL_PROBE, ROOT, "29541"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "probe OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("variant", ["strassen", "slabs"])
+def test_bench_distributed_code_path_under_rccl_at_world_size_1(variant):
+    """bench.py's whole N > 1 code path (process group, fences, batches, collective, timing reduce, gathered-C check) with the
+    nccl backend at world size 1 (--force-dist): what the driver's multi-GPU run executes, minus the links."""
+    out, stdout = _bench(["--gpus", "1", "--force-dist", "--variant", variant, "--size", "16384", "--steps", "2", "--warmup", "1", "--check"])
+    assert out["n_gpus"] == 1 and out["config"]["variant"] == variant and "RCCL" in out["config"]["backend"] and stdout.count("-> OK") == 1

@@ -24,13 +24,19 @@ def sha_matches(M, op, m, l, n, seed_a, cutoff=0):
     same inputs (tests/golden/sha256.json, make_golden.py --sha): beside the 64-bit FNV fingerprints."""
     import hashlib
     import json
-    p = os.path.join(GOLD, "sha256.json")
-    if not os.path.exists(p):
-        return True
+    p = golden_file("sha256.json")
     for e in json.load(open(p)):
         if (e["op"], e["m"], e["l"], e["n"], e["seed_a"], e["cutoff"]) == (op, m, l, n, seed_a, cutoff):
             return hashlib.sha256(M.masked().tobytes()).hexdigest() == e["sha256"]
-    return True
+    raise AssertionError(f"tests/golden/sha256.json holds no entry for {op} {m}x{l}x{n} seed {seed_a} cutoff {cutoff}: "
+                         "a lost fixture must fail the test, not soften it")
+
+
+def golden_file(name):
+    """A committed fixture of tests/golden: its absence is a test failure (the parity claim rests on it), never a skip."""
+    p = os.path.join(GOLD, name)
+    assert os.path.exists(p), f"committed fixture tests/golden/{name} is missing"
+    return p
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -227,8 +233,7 @@ def test_config2_leaf_16384_vs_reference_fingerprint(oracle):
     reference's product by fingerprint (golden), seeds as in the fixture."""
     z = np.load(os.path.join(GOLD, "fingerprints.npz"))
     i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (16384, 16384, 16384)]
-    if not i:
-        pytest.skip("16384^3 fixture not generated")
+    assert i, "tests/golden/fingerprints.npz holds no 16384^3 entry (BASELINE.json configs[1])"
     sa, sb, _ = (int(x) for x in z["seeds"][i[0]])
     n = 16384
     A, B = dev_random(n, n, sa), dev_random(n, n, sb)
@@ -265,11 +270,10 @@ def test_config3_65536_strassen_properties(oracle):
     st = m4ri_amd.get_stats()
     assert st.levels == 3 and st.leaf_products == 343 and (st.leaf_m, st.leaf_l, st.leaf_n) == (8192, 8192, 8192)
     hC = to_host(C, n, n)
-    xl = os.path.join(GOLD, "fingerprints_xl.npz")
-    if os.path.exists(xl):
-        z = np.load(xl)
-        i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (n, n, n)][0]
-        assert oracle.fingerprint(hC) == int(z["fp"][i])
+    z = np.load(golden_file("fingerprints_xl.npz"))
+    i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (n, n, n)]
+    assert i, "fingerprints_xl.npz holds no 65536^3 entry"
+    assert oracle.fingerprint(hC) == int(z["fp"][i[0]])
     assert sha_matches(hC, "mul", n, n, n, 3)
     assert freivalds(oracle, to_host(A, n, n), to_host(B, n, n), hC, n, n, n, 77)
     # different schedule (2 levels, 16384^3 leaves), same bits
@@ -292,12 +296,10 @@ def test_config5_rectangular_131072(oracle):
     C = torch.empty((m, n // 64), dtype=torch.int64, device="cuda")
     m4ri_amd.mul_dev(C.data_ptr(), n // 64, A.data_ptr(), l // 64, B.data_ptr(), n // 64, m, l, n)
     hC = to_host(C, m, n)
-    xl = os.path.join(GOLD, "fingerprints_xl.npz")
-    if os.path.exists(xl):
-        z = np.load(xl)
-        i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (m, l, n)]
-        if i:
-            assert oracle.fingerprint(hC) == int(z["fp"][i[0]])
+    z = np.load(golden_file("fingerprints_xl.npz"))
+    i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (m, l, n)]
+    assert i, "fingerprints_xl.npz holds no 131072 x 8192 x 131072 entry"
+    assert oracle.fingerprint(hC) == int(z["fp"][i[0]])
     assert sha_matches(hC, "mul", m, l, n, 5)
     assert freivalds(oracle, to_host(A, m, l), to_host(B, l, n), hC, m, l, n, 78)
 
@@ -536,9 +538,7 @@ def test_131072_cubed_vs_reference_fingerprint(oracle):
     """131072^3 (four Strassen levels, 2401 leaves, ~70 GiB of workspace; seeds 7, 8) against the real
     reference's fingerprint (tests/golden/fingerprints_xxl.npz, half an hour of reference CPU time) and
     Freivalds' identity; the depth-first top level gives the same bits."""
-    xxl = os.path.join(GOLD, "fingerprints_xxl.npz")
-    if not os.path.exists(xxl):
-        pytest.skip("tests/golden/fingerprints_xxl.npz not generated (make_golden.py --xxl)")
+    xxl = golden_file("fingerprints_xxl.npz")
     z = np.load(xxl)
     m, l, n = (int(x) for x in z["meta"][0][:3])
     sa, sb = int(z["seeds"][0][0]), int(z["seeds"][0][1])
@@ -585,9 +585,7 @@ def test_products_on_different_streams_share_the_workspace_safely():
 def test_262144_cubed_vs_reference_fingerprint(oracle):
     """262144^3 (8 GiB per matrix; five Strassen levels, the top two depth-first; seeds 9, 10) against the
     real reference's fingerprint (tests/golden/fingerprints_huge.npz, make_golden.py --huge)."""
-    huge = os.path.join(GOLD, "fingerprints_huge.npz")
-    if not os.path.exists(huge):
-        pytest.skip("tests/golden/fingerprints_huge.npz not generated")
+    huge = golden_file("fingerprints_huge.npz")
     z = np.load(huge)
     m, l, n = (int(x) for x in z["meta"][0][:3])
     A, B = dev_random(m, l, int(z["seeds"][0][0])), dev_random(l, n, int(z["seeds"][0][1]))
@@ -601,9 +599,7 @@ def test_large_ragged_shapes_vs_reference_fingerprints(oracle):
     """Large products off every grid (all three remainder strips, partly filled tiles, an inner dimension
     that is not a multiple of 64, one accumulate) against the real reference's fingerprints
     (tests/golden/fingerprints_ragged_xl.npz, make_golden.py --ragged-xl)."""
-    path = os.path.join(GOLD, "fingerprints_ragged_xl.npz")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/fingerprints_ragged_xl.npz not generated")
+    path = golden_file("fingerprints_ragged_xl.npz")
     z = np.load(path)
     for op, (m, l, n, par), (sa, sb, sc), fp in zip(z["ops"], z["meta"], z["seeds"], z["fp"]):
         m, l, n, par = int(m), int(l), int(n), int(par)
@@ -629,9 +625,7 @@ def test_large_windowed_addmul_vs_reference_parent_fingerprint(oracle, pinned):
     and with the three parents pinned (windows used in place on the device).  (The reference applied to the
     windows themselves differs in the last word column: its < 54-column fallback mishandles a windowed B
     with non-zero excess; that fingerprint is stored too and must NOT be what we produce.)"""
-    path = os.path.join(GOLD, "fingerprint_window_xl.npz")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/fingerprint_window_xl.npz not generated")
+    path = golden_file("fingerprint_window_xl.npz")
     W = dict(pa=(30000, 30000, 41), pb=(30000, 30000, 42), pc=(30000, 30000, 43),
              a=(100, 64, 20100, 16448 + 37), b=(7, 128, 7 + 16384 + 37, 128 + 21000 + 5), c=(9000, 6400, 29000, 6400 + 21000 + 5))
     Pa, Pb, Pc = (Mzd.random(*W[k]) for k in ("pa", "pb", "pc"))

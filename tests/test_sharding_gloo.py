@@ -115,24 +115,47 @@ def _slab_worker(rank, world, port, m, l, n, out_dir):
     orc = cpu_libs.oracle()
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
     rc, bc = sharding.slab_cuts(m, world), sharding.slab_cuts(l, world)
-    mine_b = torch.from_numpy(B.masked()[bc[rank]:bc[rank + 1]].view(np.int64).copy())
-    full_b = torch.empty((l, B.width), dtype=torch.int64)
+    kb = sharding.slab_rows(l, world)
+    mine_b = torch.zeros((kb, B.width), dtype=torch.int64)           # the short last slab is padded: equal pieces for the collective
+    mine_b[:bc[rank + 1] - bc[rank]] = torch.from_numpy(B.masked()[bc[rank]:bc[rank + 1]].view(np.int64).copy())
+    full_b = torch.empty((world * kb, B.width), dtype=torch.int64)
     sharding.all_gather_rows(dist, full_b, mine_b, staged=True)      # the variant's one collective (bench.py: RCCL all-gather)
     Bg = Mzd(l, n)
-    Bg.valid_words()[:, :] = full_b.numpy().view(np.uint64)
-    As = A.window(rc[rank], 0, rc[rank + 1], l).copy()
-    C = orc.mul(None, As, Bg, 0)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=np.array([rc[rank], rc[rank + 1]]), words=C.masked())
+    Bg.valid_words()[:, :] = full_b[:l].numpy().view(np.uint64)
+    if rc[rank + 1] > rc[rank]:
+        As = A.window(rc[rank], 0, rc[rank + 1], l).copy()
+        words = orc.mul(None, As, Bg, 0).masked()
+    else:
+        words = np.zeros((0, Bg.width if n % 64 == 0 else (n + 63) // 64), dtype=np.uint64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=np.array([rc[rank], rc[rank + 1]]), words=words)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_row_slabs_with_all_gather(tmp_path, oracle):
-    world, (m, l, n) = 2, (300, 256, 321)
+@pytest.mark.parametrize("world,m,l,n", [(2, 300, 256, 321), (2, 301, 257, 130),   # ragged: the last slab one row short
+                                         (3, 100, 64, 70), (3, 4, 5, 64)])          # W does not divide anything; an EMPTY last slab of A
+def test_row_slabs_with_all_gather(tmp_path, oracle, world, m, l, n):
     mp.spawn(_slab_worker, args=(world, _free_port(), m, l, n, str(tmp_path)), nprocs=world, join=True)
     want = oracle.mul(None, Mzd.random(m, l, 3), Mzd.random(l, n, 4), 0).masked()
+    seen = 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         r0, r1 = (int(x) for x in z["rows"])
         assert np.array_equal(z["words"], want[r0:r1])
+        seen += r1 - r0
+    assert seen == m
+
+
+def test_slab_cuts_and_default_variant():
+    assert sharding.slab_cuts(65536, 8) == [8192 * k for k in range(9)]
+    assert sharding.slab_cuts(10, 4) == [0, 3, 6, 9, 10] and sharding.slab_cuts(4, 3) == [0, 2, 4, 4] and sharding.slab_rows(4, 3) == 2
+    for rows, world in ((1, 8), (7, 8), (100003, 8), (65537, 3)):
+        c = sharding.slab_cuts(rows, world)
+        assert c[0] == 0 and c[-1] == rows and all(a <= b for a, b in zip(c, c[1:])) and max(b - a for a, b in zip(c, c[1:])) == sharding.slab_rows(rows, world)
     assert sharding.default_variant(2) == "slabs" and sharding.default_variant(4) == "slabs" and sharding.default_variant(8) == "strassen"
+    # shape-aware: BASELINE.json configs[3] shards the top Strassen level, configs[4] (l = 8192: nothing for a level to save) takes
+    # row slabs + one all-gather of B at every world size, and so does any thin product
+    assert sharding.default_variant(8, 65536, 65536, 65536) == "strassen"
+    assert sharding.default_variant(8, 131072, 8192, 131072) == "slabs"
+    assert sharding.default_variant(8, 4096, 65536, 65536) == "slabs" and sharding.default_variant(8, 65536, 65536, 4096) == "slabs"
+    assert sharding.default_variant(4, 65536, 65536, 65536) == "slabs"

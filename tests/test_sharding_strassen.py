@@ -55,10 +55,11 @@ def test_plan_arithmetic():
             assert (cover == 1).all()
 
 
+@pytest.mark.parametrize("chunks", [1, 2, 3])   # row chunks of the overlapped schedule: same batches on every rank, same bits
 @pytest.mark.parametrize("world,levels,m,l,n", [(2, 1, 64, 128, 128), (2, 2, 100, 256, 256), (3, 1, 77, 130, 65),
                                                 (4, 2, 203, 300, 257), (8, 1, 130, 129, 200), (8, 2, 64, 512, 256),
                                                 (5, 2, 7, 64, 64)])   # more ranks than rows per block: empty slabs
-def test_all_ranks_in_one_process(oracle, world, levels, m, l, n):
+def test_all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks):
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
     plan = m4ri_amd.shard_plan(world, m, l, n, levels)
     mail, lock, barrier = {}, threading.Lock(), threading.Barrier(world)
@@ -78,7 +79,7 @@ def test_all_ranks_in_one_process(oracle, world, levels, m, l, n):
 
     def work(rank):
         try:
-            parts[rank] = shard_sim.rank_part(plan, rank, A, B, oracle, make_exchange(rank))
+            parts[rank] = shard_sim.rank_part(plan, rank, A, B, oracle, make_exchange(rank), chunks=chunks)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
             barrier.abort()
@@ -102,7 +103,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, levels, m, l, n, out_dir):
+def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -115,16 +116,18 @@ def _worker(rank, world, port, levels, m, l, n, out_dir):
     def exchange(sends, recvs):  # numpy views <-> torch tensors sharing memory: the transport is sharding.torch_exchange
         torch_x([(d, torch.from_numpy(v.view(np.int64))) for d, v in sends], [(s, torch.from_numpy(v.view(np.int64))) for s, v in recvs])
 
-    CL, runs = shard_sim.rank_part(plan, rank, A, B, orc, exchange)
+    exchange.post = lambda sends, recvs: torch_x.post([(d, torch.from_numpy(v.view(np.int64))) for d, v in sends],
+                                                      [(s, torch.from_numpy(v.view(np.int64))) for s, v in recvs])
+    CL, runs = shard_sim.rank_part(plan, rank, A, B, orc, exchange, chunks=chunks)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=CL, runs=np.array(runs))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("levels,m,l,n", [(1, 200, 256, 320), (2, 131, 257, 129)])
-def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n):
+@pytest.mark.parametrize("levels,m,l,n,chunks", [(1, 200, 256, 320, 1), (2, 131, 257, 129, 1), (1, 200, 256, 320, 2), (2, 131, 257, 129, 2)])
+def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n, chunks):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path), chunks), nprocs=world, join=True)
     plan = m4ri_amd.shard_plan(world, m, l, n, levels)
     parts = {}
     for r in range(world):
@@ -132,3 +135,14 @@ def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n):
         parts[r] = (z["C"], [tuple(int(x) for x in row) for row in z["runs"]])
     got = shard_sim.assemble(plan, parts, m, n)
     assert np.array_equal(got, oracle.mul(None, Mzd.random(m, l, 3), Mzd.random(l, n, 4), 0).masked())
+
+
+def test_chunk_bounds_cover_the_rows_once():
+    """The overlapped schedule's row chunks are whole slabs, tile the sub-product's rows and never cut a piece."""
+    for world, m, chunks in ((8, 65536, 2), (8, 65536, 4), (8, 65536, 3), (4, 65536, 2), (3, 1001, 2), (5, 7, 2), (2, 64, 1)):
+        plan = m4ri_amd.shard_plan(world, m, 4096, 4096)
+        b = sharding.chunk_bounds(plan, chunks)
+        assert b[0][2] == 0 and sum(x[3] for x in b) == plan.bm and all(x[2] + x[3] == y[2] for x, y in zip(b, b[1:]))
+        assert b[0][0] == 0 and b[-1][1] == world and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    plan = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
+    assert [x[2:] for x in sharding.chunk_bounds(plan, 2)] == [(0, 16384), (16384, 16384)]   # halves of a 32768-row sub-product
