@@ -142,14 +142,17 @@ def cpu_baseline(n_workload: int, budget_s: float = 75.0):
         out["openmp_16384"] = {"value": n ** 3 / best, "cores": ncpu, "sample": f"mzd_mul_mp {n}^3, OpenMP build, {ncpu} threads, best of 2: {best:.2f} s"}
         out.update({"value": n ** 3 / best, "cores": ncpu, "sample": out["openmp_16384"]["sample"]})
         # BASELINE.md 3 asks for both calls on all cores: the OpenMP build's plain mzd_mul (row-parallel M4RM leaves,
-        # brilliantrussian.c:1121-1123, sequential Strassen) beside mzd_mul_mp (2 x 2 blocks of C, mp.c:206-228)
-        best_mul = 1e30
-        for _ in range(2):
-            t = time.perf_counter()
-            omp.mul(None, A, B, 0)
-            best_mul = min(best_mul, time.perf_counter() - t)
-        out["openmp_mzd_mul_16384"] = {"value": n ** 3 / best_mul, "cores": ncpu,
-                                        "sample": f"mzd_mul {n}^3, OpenMP build, {ncpu} threads, best of 2: {best_mul:.2f} s"}
+        # brilliantrussian.c:1121-1123, sequential Strassen) beside mzd_mul_mp (2 x 2 blocks of C, mp.c:206-228).  It forks and
+        # joins a team per table step and gets SLOWER with cores (16384^3 on 256 threads: 19.7 s against 0.92 s sequential,
+        # profiles/r03_bench65536_first.json), so the sample is one 8192^3 product
+        n8 = 8192
+        A8, B8 = Mzd.random(n8, n8, 3), Mzd.random(n8, n8, 4)
+        t = time.perf_counter()
+        omp.mul(None, A8, B8, 0)
+        t_mul = time.perf_counter() - t
+        out["openmp_mzd_mul_8192"] = {"value": n8 ** 3 / t_mul, "cores": ncpu,
+                                      "sample": f"mzd_mul {n8}^3, OpenMP build, {ncpu} threads, 1 run: {t_mul:.2f} s"}
+        del A8, B8
         predicted = best * (n_workload / n) ** 2.807
         if n_workload > n and predicted <= budget_s:
             del A, B

@@ -12,6 +12,7 @@
 // colour type 0 or 3, non-interlaced) with any of the five scanline filters.
 #include <zlib.h>
 #include <dlfcn.h>
+#include <cctype>
 #include <cinttypes>
 #include <cstdarg>
 #include <cstdio>
@@ -110,37 +111,69 @@ mzd_t *mzd_from_str(rci_t m, rci_t n, const char *str) {  // io.c:350-357
   return A;
 }
 
-mzd_t *mzd_from_jcf(const char *fn, int verbose) {  // io.c:297-348
-  FILE *fh = fopen(fn, "r");
-  if (!fh) {
+// JCF reader.  The format is a stream of whitespace-separated decimal integers: "rows cols modulus" and an entry count, then
+// one signed 1-based column index per entry, a NEGATIVE index opening the next row (io.h:160-180).  Own structure: the file
+// is slurped and walked by a small integer tokenizer (the reference drives fscanf directly, io.c:297-348); the diagnostics
+// are kept word for word so that callers parsing stdout see the same text.  Where the reference writes outside the matrix
+// (a first index that is positive addresses row -1; an index 0 addresses column -1) this reader dies with the message
+// the reference uses for an index beyond the last row / column.
+mzd_t *mzd_from_jcf(const char *fn, int verbose) {
+  struct IntStream {
+    std::string text;
+    size_t at = 0;
+    bool load(const char *path) {
+      FILE *fh = fopen(path, "r");
+      if (!fh) return false;
+      char chunk[1 << 16];
+      for (size_t got; (got = fread(chunk, 1, sizeof chunk, fh)) > 0;) text.append(chunk, got);
+      fclose(fh);
+      return true;
+    }
+    bool next(long long &value) {  // false at the end of the file or at the first token that is not an integer
+      while (at < text.size() && isspace((unsigned char)text[at])) ++at;
+      if (at >= text.size()) return false;
+      char *stop = nullptr;
+      const long long v = strtoll(text.c_str() + at, &stop, 10);
+      if (stop == text.c_str() + at) return false;
+      at    = (size_t)(stop - text.c_str());
+      value = v;
+      return true;
+    }
+  } in;
+  if (!in.load(fn)) {
     if (verbose) printf("Could not open file '%s' for reading\n", fn);
     return NULL;
   }
-  rci_t m = 0, n = 0;
-  int p = 0;
-  int64_t nonzero = 0;
-  mzd_t *A = NULL;
-  if (fscanf(fh, "%d %d %d\n%" SCNd64 "\n\n", &m, &n, &p, &nonzero) != 4) {
-    if (verbose) printf("File '%s' does not seem to be in JCF format.", fn);
-    fclose(fh);
+  long long header[4] = {0, 0, 0, 0};  // rows, columns, modulus, number of entries
+  for (long long &h : header)
+    if (!in.next(h)) {
+      if (verbose) printf("File '%s' does not seem to be in JCF format.", fn);
+      return NULL;
+    }
+  const long long nrows = header[0], ncols = header[1], modulus = header[2], entries = header[3];
+  if (modulus != 2) {
+    if (verbose) printf("Expected p==2 but found p==%d\n", (int)modulus);
     return NULL;
   }
-  if (p != 2) {
-    if (verbose) printf("Expected p==2 but found p==%d\n", p);
-    fclose(fh);
+  if (nrows < 0 || ncols < 0 || nrows > 0x7fffffffLL || ncols > 0x7fffffffLL) {
+    if (verbose) printf("File '%s' does not seem to be in JCF format.", fn);
     return NULL;
   }
   if (verbose)
-    printf("reading %d x %d matrix with at most %" PRId64 " non-zero entries (density at most: %6.5f)\n", m, n, nonzero,
-           ((double)nonzero) / ((double)m * n));
-  A = new_matrix(m, n);
-  rci_t i = -1, j = 0;
-  while (fscanf(fh, "%d\n", &j) == 1) {
-    if (j < 0) { i++; j = -j; }
-    if (((j - 1) >= n) || (i >= m)) die("trying to write to (%d,%d) in %d x %d matrix\n", i, j - 1, m, n);
-    write_bit(A, i, j - 1, 1);
+    printf("reading %d x %d matrix with at most %" PRId64 " non-zero entries (density at most: %6.5f)\n", (int)nrows, (int)ncols,
+           (int64_t)entries, ((double)entries) / ((double)nrows * ncols));
+  mzd_t *A      = new_matrix((rci_t)nrows, (rci_t)ncols);
+  long long row = -1;  // no row is open until the first negative index
+  for (long long token; in.next(token);) {
+    if (token < 0) {
+      ++row;
+      token = -token;
+    }
+    const long long col = token - 1;
+    if (row < 0 || row >= nrows || col < 0 || col >= ncols)
+      die("trying to write to (%d,%d) in %d x %d matrix\n", (int)row, (int)col, (int)nrows, (int)ncols);
+    write_bit(A, (rci_t)row, (rci_t)col, 1);
   }
-  fclose(fh);
   return A;
 }
 
@@ -189,6 +222,11 @@ int mzd_to_png(const mzd_t *A, const char *fn, int compression_level, const char
   std::vector<unsigned char> comp(clen);
   if (compression_level < -1 || compression_level > 9) compression_level = -1;
   if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), compression_level) != Z_OK) {
+    if (verbose) printf("error writing PNG file\n");
+    fclose(fh);
+    return 1;
+  }
+  if ((uint64_t)clen > 0x7fffffffull) {  // a PNG chunk length is 31 bits; one IDAT per file is all this writer makes
     if (verbose) printf("error writing PNG file\n");
     fclose(fh);
     return 1;
@@ -260,7 +298,14 @@ mzd_t *mzd_from_png(const char *fn, int verbose) {  // io.c:72-191
     return NULL;
   }
   const size_t rowbytes = ((size_t)n + 7) / 8;
-  std::vector<unsigned char> raw((size_t)m * (rowbytes + 1));
+  // the header of an untrusted file promises m * (rowbytes + 1) bytes of scanlines: believe it only if the IDAT stream could
+  // inflate to that (deflate expands at most ~1032 : 1), instead of allocating up to 2^59 bytes and dying in bad_alloc
+  const unsigned __int128 promised = (unsigned __int128)m * (rowbytes + 1);
+  if (promised > (unsigned __int128)idat.size() * 1040u + 65536u) {
+    if (verbose) printf("Could not read file '%s'\n", fn);
+    return NULL;
+  }
+  std::vector<unsigned char> raw((size_t)promised);
   uLongf rlen = (uLongf)raw.size();
   if (!raw.empty() && (uncompress(raw.data(), &rlen, idat.data(), (uLong)idat.size()) != Z_OK || rlen != raw.size())) {
     if (verbose) printf("Could not read file '%s'\n", fn);

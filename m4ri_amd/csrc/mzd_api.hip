@@ -451,8 +451,20 @@ void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff, bool right = fal
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
-  arena_reserve((find_pin(T) ? 0 : dev_words(T->nrows, T->ncols)) + inout_words(B));
-  const DevMat dT = operand(T, true);
+  // T as the solver wants it: bits beyond its last column clean (trsm.hip: solve()).  A ragged window into a pinned parent
+  // carries the parent's neighbouring columns in its last word: such a T is solved from a masked copy, like an in/out matrix
+  Pin *pinT             = find_pin(T);
+  const bool t_staged   = pinT && T->ncols % 64 != 0 && T->ncols != pinT->ncols;
+  arena_reserve(((pinT && !t_staged) ? 0 : dev_words(T->nrows, T->ncols)) + inout_words(B));
+  DevMat dT;
+  if (t_staged) {
+    dev_alloc(dT, T->nrows, T->ncols);
+    const DevMat src = operand(T, false);
+    HIPDIE(hipMemcpy2DAsync(dT.p, (size_t)dT.stride * 8, src.p, (size_t)src.stride * 8, (size_t)T->width * 8, (size_t)T->nrows, hipMemcpyDeviceToDevice, nullptr));
+    HIPDIE(m4ri_amd_mask_tail_dev(dT.p, dT.stride, T->nrows, T->ncols, nullptr));
+  } else {
+    dT = operand(T, true);
+  }
   InOut io        = inout_begin(B);
   if (right && upper) HIPDIE(m4ri_amd_trsm_upper_right_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
   else if (right)     HIPDIE(m4ri_amd_trsm_lower_right_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
@@ -498,8 +510,23 @@ mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c) {  // mzd.c:142-157
   if (r && c) {
     void *p = nullptr;
     const size_t bytes = (size_t)r * (size_t)A->rowstride * 8;
-    if (posix_memalign(&p, 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
-    memset(p, 0, bytes);
+    // large blocks: 2 MiB-aligned (whole transparent huge pages) and zeroed by a few threads -- a fresh 512 MiB result
+    // costs 87 ms of page faults under one memset, more than the 65536^3 product it receives (bench.py: api.c_null_ms)
+    const bool big = bytes >= ((size_t)8 << 20);
+    if (posix_memalign(&p, big ? ((size_t)2 << 20) : 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
+    if (big) {
+      const size_t nt = 8, per = ((bytes / nt) + 4095) & ~(size_t)4095;
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < nt; ++k) {
+        const size_t at = k * per;
+        if (at >= bytes) break;
+        const size_t len = bytes - at < per ? bytes - at : per;
+        th.emplace_back([=] { memset(static_cast<char *>(p) + at, 0, len); });
+      }
+      for (std::thread &t : th) t.join();
+    } else {
+      memset(p, 0, bytes);
+    }
     A->data = static_cast<word *>(p);
   }
   return A;
@@ -952,19 +979,26 @@ void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L)
   W.data  = M->data + (int64_t)r * M->rowstride;
   W.nrows = (r + k <= M->nrows) ? k : (M->nrows > r ? M->nrows - r : 0);
   W.flags |= FLAG_WINDOW;
-  arena_reserve((find_pin(&W) ? 0 : dev_words(W.nrows, W.ncols)) + dev_words(T->nrows, T->ncols) + (((size_t)twokay / 2 + 1 + 31) & ~(size_t)31) + 64);
+  Pin *pinT = find_pin(T);  // a pinned T IS its device copy: build the table there (the host copy goes stale like any pinned result)
+  arena_reserve((find_pin(&W) ? 0 : dev_words(W.nrows, W.ncols)) + (pinT ? 0 : dev_words(T->nrows, T->ncols)) + (((size_t)twokay / 2 + 1 + 31) & ~(size_t)31) + 64);
   DevMat dM{};
   if (W.nrows > 0) dM = operand(&W, true);
   DevMat dT;
-  dev_alloc(dT, T->nrows, T->ncols);
   const int64_t home = c / 64, wide = M->width - home;
-  // the table's present content, unmasked (rows whose source row is missing keep it, and T[0] seeds the chain)
-  HIPDIE(hipMemcpy2D(dT.p + home, (size_t)dT.stride * 8, T->data + home, (size_t)T->rowstride * 8, (size_t)wide * 8, (size_t)twokay, hipMemcpyHostToDevice));
+  if (pinT) {
+    dT = operand(T, false);
+  } else {
+    dev_alloc(dT, T->nrows, T->ncols);
+    // the table's present content, unmasked (rows whose source row is missing keep it, and T[0] seeds the chain)
+    HIPDIE(hipMemcpy2D(dT.p + home, (size_t)dT.stride * 8, T->data + home, (size_t)T->rowstride * 8, (size_t)wide * 8, (size_t)twokay, hipMemcpyHostToDevice));
+  }
   int32_t *dj = reinterpret_cast<int32_t *>(arena_raw((size_t)twokay / 2 + 1));
   HIPDIE(hipMemcpyAsync(dj, jstar.data(), (size_t)twokay * 4, hipMemcpyHostToDevice, nullptr));
   HIPDIE(m4ri_amd_make_table_dev(dM.p, dM.stride, W.nrows, M->ncols, 0, c, k, dT.p, dT.p, dT.stride, dj, nullptr));
-  HIPDIE(hipMemcpy2D(T->data + (int64_t)T->rowstride + home, (size_t)T->rowstride * 8, dT.p + dT.stride + home, (size_t)dT.stride * 8, (size_t)wide * 8,
-                     (size_t)(twokay - 1), hipMemcpyDeviceToHost));
+  if (pinT) pinT->dev_newer = true;
+  else
+    HIPDIE(hipMemcpy2D(T->data + (int64_t)T->rowstride + home, (size_t)T->rowstride * 8, dT.p + dT.stride + home, (size_t)dT.stride * 8, (size_t)wide * 8,
+                       (size_t)(twokay - 1), hipMemcpyDeviceToHost));
   HIPDIE(hipDeviceSynchronize());
 }
 

@@ -123,7 +123,7 @@ int m4ri_amd_apply_p_left_dev(word *A, int64_t stride, int64_t nrows, int64_t nc
   std::vector<int32_t> moved, from;
   for (int64_t r = 0; r < nrows; ++r)
     if (src[(size_t)r] != r) { moved.push_back((int32_t)r); from.push_back(src[(size_t)r]); }
-  if (moved.empty()) return 0;
+  if (moved.empty()) return (int)hipStreamSynchronize(st);  // "blocking": whatever the caller queued on A is complete on return
   const int64_t width = words_of(ncols), k = (int64_t)moved.size();
   word *tmp = nullptr;
   int32_t *d_idx = nullptr;
@@ -222,7 +222,8 @@ int m4ri_amd_kernel_left_pluq_dev(word *A, int64_t a_stride, int64_t m, int64_t 
   }
   hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, st, R, r_stride, (int64_t)r, (int64_t)0, kc);        // :179
   HIPTRY(hipGetLastError());
-  return m4ri_amd_apply_p_left_dev(R, r_stride, n, kc, Q.data(), n, 1, st);                                                                   // :180
+  if (int rc = m4ri_amd_apply_p_left_dev(R, r_stride, n, kc, Q.data(), n, 1, st)) return rc;                                                  // :180
+  return (int)hipStreamSynchronize(st);  // blocking as documented, also when Q moves no row (apply_p returns early then)
 }
 
 // mzd_inv_m4ri (brilliantrussian.c:971-997): Binv (n x n, device) <- the right block of the reduced row echelon form of

@@ -1,9 +1,12 @@
 """The reference's I/O formats (m4ri/io.c:49-357) as libm4ri_amd.so provides them -- pure
 host code, no GPU needed.  mzd_from_str, mzd_from_jcf and mzd_fprint_row are compared with the real reference
-build; the PNG pair cannot be (the reference build in oracle/_ref has no libpng: __M4RI_HAVE_LIBPNG = 0, so the
-PNG codec's parity against libm4ri is UNPINNED): it is checked against the PNG specification instead -- an
-independent decoder/encoder in this file (zlib + struct), the pixel convention of io.c:148-178 / :254-287
-(leftmost pixel = lowest bit, set bit = black = sample 0), and round trips."""
+build.  The PNG pair cannot be compared with libm4ri itself (png.h is not in this image, so the reference's io.c builds
+with __M4RI_HAVE_LIBPNG = 0); it is pinned against the two third-party PNG implementations that ARE here, for the
+reference's pixel convention (io.c:148-178, :254-287: leftmost pixel = lowest bit, set bit = black = sample 0):
+  * libpng itself -- the library the reference reads and writes through -- via ctypes on libpng16.so.16 (simplified
+    png_image_* API): it decodes what mzd_to_png wrote, and it encodes (1-bit palette, colour type 3) what mzd_from_png reads;
+  * Pillow's PNG plugin (its own chunk parser / writer on zlib): 1-bit grayscale both ways;
+and beside them an independent decoder/encoder in this file (zlib + struct) for the scanline filters and split IDATs."""
 import ctypes
 import os
 import struct
@@ -179,3 +182,120 @@ def test_png_read_rejects_what_the_reference_rejects(tmp_path):
     data[8:8 + 25] = struct.pack(">I", 13) + b"IHDR" + body + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(body)) & 0xFFFFFFFF)
     (tmp_path / "rgb.png").write_bytes(bytes(data))
     assert m4ri_amd.mzd_from_png(str(tmp_path / "rgb.png")) is None
+
+
+# ---- pinned against third-party PNG implementations: libpng (ctypes) and Pillow ----------------------------------------
+class _PngImage(ctypes.Structure):  # png.h: png_image (simplified API), PNG_IMAGE_VERSION 1
+    _fields_ = [("opaque", ctypes.c_void_p), ("version", ctypes.c_uint32), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("format", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("colormap_entries", ctypes.c_uint32),
+                ("warning_or_error", ctypes.c_uint32), ("message", ctypes.c_char * 64)]
+
+
+_PNG_FORMAT_GRAY, _PNG_FORMAT_RGB_COLORMAP = 0, 2 | 8  # png.h: PNG_FORMAT_FLAG_COLOR = 2, PNG_FORMAT_FLAG_COLORMAP = 8
+
+
+def _libpng():
+    import ctypes.util
+    name = ctypes.util.find_library("png16") or "libpng16.so.16"
+    try:
+        L = ctypes.CDLL(name)
+    except OSError:
+        pytest.fail("libpng16.so.16 is part of this image: the PNG codec is pinned against it")
+    L.png_image_begin_read_from_file.argtypes = [ctypes.POINTER(_PngImage), ctypes.c_char_p]
+    L.png_image_finish_read.argtypes = [ctypes.POINTER(_PngImage), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.png_image_write_to_file.argtypes = [ctypes.POINTER(_PngImage), ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.png_image_free.argtypes = [ctypes.POINTER(_PngImage)]
+    return L
+
+
+def _libpng_read_gray8(path):
+    L, img = _libpng(), _PngImage()
+    img.version = 1
+    assert L.png_image_begin_read_from_file(ctypes.byref(img), os.fsencode(path)), img.message
+    img.format = _PNG_FORMAT_GRAY
+    px = np.zeros((img.height, img.width), dtype=np.uint8)
+    assert L.png_image_finish_read(ctypes.byref(img), None, px.ctypes.data_as(ctypes.c_void_p), 0, None), img.message
+    L.png_image_free(ctypes.byref(img))
+    return px
+
+
+def _libpng_write_palette1(path, index):
+    """index: h x w array of 0/1 palette indices -> a colour-type-3 PNG; libpng picks bit depth 1 for a 2-entry colormap."""
+    L, img = _libpng(), _PngImage()
+    img.version, img.height, img.width = 1, index.shape[0], index.shape[1]
+    img.format, img.colormap_entries = _PNG_FORMAT_RGB_COLORMAP, 2
+    cmap = np.array([[0, 0, 0], [255, 255, 255]], dtype=np.uint8)
+    buf = np.ascontiguousarray(index, dtype=np.uint8)
+    assert L.png_image_write_to_file(ctypes.byref(img), os.fsencode(path), 0, buf.ctypes.data_as(ctypes.c_void_p), 0,
+                                     cmap.ctypes.data_as(ctypes.c_void_p)), img.message
+
+
+PNG_SHAPES = [(1, 1), (3, 8), (5, 9), (10, 64), (7, 65), (33, 130), (64, 200), (200, 1023)]
+
+
+@pytest.mark.parametrize("m,n", PNG_SHAPES)
+def test_png_written_here_decodes_in_libpng_and_pillow(tmp_path, m, n):
+    """mzd_to_png's files through the reference's own PNG library and through Pillow: entry 1 = black (sample 0),
+    entry 0 = white, column 0 = leftmost pixel, row 0 on top (io.c:254-287)."""
+    from PIL import Image
+    A = Mzd.random(m, n, 300 + n)
+    p = str(tmp_path / "a.png")
+    for level in (-1, 0, 9):
+        assert m4ri_amd.mzd_to_png(A, p, level, "pinned") == 0
+        want = (1 - A.to_bits()).astype(np.uint8) * 255
+        assert np.array_equal(_libpng_read_gray8(p), want)
+        with Image.open(p) as im:
+            assert im.mode == "1" and im.size == (n, m) and im.info.get("Software") == "M4RI" and im.info.get("Comment") == "pinned"
+            assert np.array_equal(np.array(im.convert("L")), want)
+
+
+@pytest.mark.parametrize("m,n", PNG_SHAPES)
+def test_png_written_by_libpng_and_pillow_reads_here(tmp_path, m, n):
+    """mzd_from_png on files made by third parties.  The reference takes the packed bits as they are -- leftmost pixel =
+    lowest bit (png_set_packswap) -- and complements them (io.c:148-178): for a grayscale file a black pixel is a 1, for a
+    palette file (colour type 3, which it accepts as well) palette INDEX 0 is a 1, whatever the palette says."""
+    from PIL import Image
+    rng = np.random.default_rng(7 * m + n)
+    px = (rng.random((m, n)) < 0.5).astype(np.uint8)
+    p = str(tmp_path / "pil.png")
+    Image.fromarray(px * 255).convert("1").save(p, optimize=bool(n % 2))     # 1-bit grayscale, Pillow's writer
+    A = m4ri_amd.mzd_from_png(p)
+    assert (A.nrows, A.ncols) == (m, n) and np.array_equal(A.to_bits(), 1 - px)
+    assert not (A.valid_words()[:, -1] & ~np.uint64(A.high_bitmask)).any()
+    q = str(tmp_path / "libpng.png")
+    _libpng_write_palette1(q, px)                                             # 1-bit palette, libpng's writer
+    raw = open(q, "rb").read()
+    assert raw[24] == 1 and raw[25] == 3, "libpng wrote bit depth 1, colour type 3"
+    B = m4ri_amd.mzd_from_png(q)
+    assert (B.nrows, B.ncols) == (m, n) and np.array_equal(B.to_bits(), 1 - px)
+
+
+def test_png_reader_refuses_a_header_its_data_cannot_back(tmp_path):
+    """An IHDR promising 2^31-1 x 2^31-1 pixels over a few bytes of IDAT is refused (NULL), not allocated."""
+    data = bytearray(_png_encode_1bit(np.zeros((2, 2), dtype=np.uint8), [0]))
+    body = struct.pack(">IIBBBBB", 0x7fffffff, 0x7fffffff, 1, 0, 0, 0, 0)
+    data[8:8 + 25] = struct.pack(">I", 13) + b"IHDR" + body + struct.pack(">I", zlib.crc32(b"IHDR" + body) & 0xFFFFFFFF)
+    (tmp_path / "huge.png").write_bytes(bytes(data))
+    assert m4ri_amd.mzd_from_png(str(tmp_path / "huge.png")) is None
+
+
+def test_jcf_reader_edge_cases(tmp_path, reference):
+    """Free-form whitespace is the format's own (the reference parses with fscanf); a truncated header is refused; an index
+    that addresses a cell outside the matrix is fatal -- including the two the reference does not catch (a positive FIRST
+    index = row -1, an index 0 = column -1), which die here instead of writing out of bounds."""
+    import subprocess
+    import sys
+    RL = _ref_bind(reference)
+    p = tmp_path / "ws.jcf"
+    p.write_text("3   4 2 5\n\n\n  -1 3\t4\n-2\n\n-4 1\n")       # 3 rows opened: (0;0,2,3), (1;1), (2;3,0)
+    got = m4ri_amd.mzd_from_jcf(str(p))
+    want = from_struct_ptr(RL.mzd_from_jcf(str(p).encode(), 0), RL.mzd_free)
+    assert got.equal(want) and got.to_bits().tolist() == [[1, 0, 1, 1], [0, 1, 0, 0], [1, 0, 0, 1]]
+    (tmp_path / "short.jcf").write_text("3 4 2\n")
+    assert m4ri_amd.mzd_from_jcf(str(tmp_path / "short.jcf")) is None and not RL.mzd_from_jcf(str(tmp_path / "short.jcf").encode(), 0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for text, where in (("2 2 2\n1\n\n-3\n", "(0,2)"), ("2 2 2\n3\n\n-1\n-1\n-1\n", "(2,0)"), ("2 2 2\n1\n\n1\n", "(-1,0)"), ("2 2 2\n1\n\n-1\n0\n", "(0,-1)")):
+        (tmp_path / "bad.jcf").write_text(text)
+        code = f"import m4ri_amd\nm4ri_amd.mzd_from_jcf({str(tmp_path / 'bad.jcf')!r})\nprint('SURVIVED')\n"
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+        assert r.returncode < 0 and f"trying to write to {where} in 2 x 2 matrix" in r.stderr and "SURVIVED" not in r.stdout, (text, r.stderr[-300:])
