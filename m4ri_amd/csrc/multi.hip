@@ -215,33 +215,44 @@ int ensure_ranks() {
   }
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
-  for (Rank &r : g_ranks) {
-    (void)hipSetDevice(r.device);
-    if (r.arena) (void)hipFree(r.arena);
-    if (r.stream) (void)hipStreamDestroy(r.stream);
-    if (r.ev_down) (void)hipEventDestroy(r.ev_down);
-    if (r.ev_prod) (void)hipEventDestroy(r.ev_prod);
-  }
-  g_ranks.assign(g_devices.size(), Rank{});
-  for (size_t i = 0; i < g_ranks.size(); ++i) {
-    Rank &r  = g_ranks[i];
-    r.device = g_devices[i];
-    HIPTRY(m4ri_amd_init(r.device));  // binds the device + creates its engine
-    HIPTRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-    HIPTRY(hipEventCreateWithFlags(&r.ev_down, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&r.ev_prod, hipEventDisableTiming));
-    for (size_t k = 0; k < g_ranks.size(); ++k) {  // direct xGMI copies between every pair
-      const int other = g_devices[k];
-      int can         = 0;
-      if (other != r.device && hipDeviceCanAccessPeer(&can, r.device, other) == hipSuccess && can) {
-        const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return (int)e;
-        (void)hipGetLastError();
+  auto drop_all = [&]() {  // streams, events and arenas of every rank that has them; leaves g_ranks empty
+    for (Rank &r : g_ranks) {
+      (void)hipSetDevice(r.device);
+      if (r.arena) (void)hipFree(r.arena);
+      if (r.stream) (void)hipStreamDestroy(r.stream);
+      if (r.ev_down) (void)hipEventDestroy(r.ev_down);
+      if (r.ev_prod) (void)hipEventDestroy(r.ev_prod);
+    }
+    g_ranks.clear();
+  };
+  drop_all();
+  // a failure half way must not leave ranks that LOOK configured (same size, same ids, null streams) nor another current
+  // device behind: on any error everything made so far is dropped and the caller's device restored
+  auto build = [&]() -> int {
+    g_ranks.assign(g_devices.size(), Rank{});
+    for (size_t i = 0; i < g_ranks.size(); ++i) {
+      Rank &r  = g_ranks[i];
+      r.device = g_devices[i];
+      HIPTRY(m4ri_amd_init(r.device));  // binds the device + creates its engine
+      HIPTRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+      HIPTRY(hipEventCreateWithFlags(&r.ev_down, hipEventDisableTiming));
+      HIPTRY(hipEventCreateWithFlags(&r.ev_prod, hipEventDisableTiming));
+      for (size_t k = 0; k < g_ranks.size(); ++k) {  // direct xGMI copies between every pair
+        const int other = g_devices[k];
+        int can         = 0;
+        if (other != r.device && hipDeviceCanAccessPeer(&can, r.device, other) == hipSuccess && can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return (int)e;
+          (void)hipGetLastError();
+        }
       }
     }
-  }
-  HIPTRY(hipSetDevice(cur));
-  return 0;
+    return 0;
+  };
+  const int rc = build();
+  if (rc) drop_all();
+  (void)hipSetDevice(cur);
+  return rc;
 }
 
 int carve(Rank &r, const m4ri_amd_shard_plan &p, int rank) {
@@ -399,11 +410,11 @@ extern "C" {
 
 int m4ri_amd_set_devices(int n, const int *ids) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
-  if (n < 0 || (n > 0 && !ids) || n > 64) return -1;
+  if (n < 0 || (n > 0 && !ids) || n > 64) return -1;  // up to 64 RANKS (ids may repeat) ...
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
   for (int i = 0; i < n; ++i)
-    if (ids[i] < 0 || ids[i] >= have) return -1;
+    if (ids[i] < 0 || ids[i] >= have || ids[i] >= 16) return -1;  // ... on device ids the per-device tables (arena, scratch: 16 entries) hold
   g_devices.assign(ids, ids + n);
   g_devices_set = n > 0;  // n == 0: back to the default (M4RI_AMD_DEVICES or every visible device)
   return 0;

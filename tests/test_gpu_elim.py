@@ -75,3 +75,38 @@ def test_edge_ranges_and_small_k(oracle):
         oracle.process_rows(Mo, 0, 100, c, k, To, Lo)
         ec.call_process_rows(m4ri_amd.lib(), Mg, 0, 100, c, k, Tg, Lg)
         assert np.array_equal(Mo.rows(), Mg.rows()), (r, c, k, nt)
+
+
+@pytest.mark.parametrize("pin_m", [False, True])
+def test_tables_pinned_on_the_device(oracle, pin_m):
+    """mzd_make_table into a PINNED T (and from a pinned M): the table is built inside T's device copy -- which is what
+    mzd_process_rows then reads -- and T's host copy is stale until sync.  (Round 2 seeded the table from, and wrote it back
+    to, the host copy only: the row processing that followed read a stale device copy.)"""
+    nrows, ncols, r, c, k, nt = 600, 1500, 40, 130, 24, 3
+    M = Mzd.random(nrows, ncols, 77)
+    Mo = M.copy()
+    kb = ec.split_k(k, nt)
+    Tg = [Mzd.random(1 << b, ncols, 90 + i) for i, b in enumerate(kb)]     # dirty tables: stale rows / seeds must come from HERE
+    To = [t.copy() for t in Tg]
+    for t, o in zip(Tg, To):
+        o.rows()[:, :] = t.rows()
+        m4ri_amd.pin(t)
+    if pin_m:
+        m4ri_amd.pin(M)
+    Lg = [np.zeros(1 << b, dtype=np.int32) for b in kb]
+    Lo = [np.zeros(1 << b, dtype=np.int32) for b in kb]
+    off = 0
+    for t in range(nt):
+        oracle.make_table(Mo, r + off, c + off, kb[t], To[t], Lo[t])
+        _gpu_make(M, r + off, c + off, kb[t], Tg[t], Lg[t])
+        assert m4ri_amd.is_pinned(Tg[t]) == 2, "a pinned table is built on the device: its host copy is stale"
+        off += kb[t]
+    oracle.process_rows(Mo, r + k, nrows, c, k, To, Lo)
+    ec.call_process_rows(m4ri_amd.lib(), M, r + k, nrows, c, k, Tg, Lg)
+    if pin_m:
+        m4ri_amd.unpin(M)
+    for t in Tg:
+        m4ri_amd.unpin(t)
+    for a, b, la, lb in zip(To, Tg, Lo, Lg):
+        assert np.array_equal(a.rows(), b.rows()) and np.array_equal(la, lb)
+    assert np.array_equal(M.rows(), Mo.rows())

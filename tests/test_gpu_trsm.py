@@ -198,3 +198,29 @@ def test_trsm_big_blocks_off():
                        cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("mb", [700, 1500])
+def test_solves_on_ragged_windows_of_pinned_parents(oracle, mb):
+    """T = a window of a PINNED parent whose column count is off the word grid: its last word carries the parent's
+    neighbouring columns on the device.  Upper-left, lower-left and both right-hand solves must not see them (the shim solves
+    from a masked copy of such a T, mzd_api.hip: run_trsm), nor touch anything outside B's window."""
+    n = 2100
+    PT, PB, PR = Mzd.random(n, n, 71), Mzd.random(n, n, 72), Mzd.random(n, n, 73)
+    HT, HB, HR = PT.copy(), PB.copy(), PR.copy()
+    for P in (PT, PB, PR):
+        m4ri_amd.pin(P)
+    t, h = PT.window(5, 64, 5 + mb, 64 + mb), HT.window(5, 64, 5 + mb, 64 + mb)          # mb x mb, ragged last word
+    b, hb = PB.window(11, 128, 11 + mb, 128 + 777), HB.window(11, 128, 11 + mb, 128 + 777)   # mb x 777 (left solves)
+    r, hr = PR.window(3, 0, 3 + 500, mb), HR.window(3, 0, 3 + 500, mb)                       # 500 x mb (right solves)
+    m4ri_amd.mzd_trsm_upper_left(t, b)
+    oracle.trsm_upper_left(h, hb)
+    m4ri_amd.mzd_trsm_lower_left(t, b)
+    oracle.trsm_lower_left(h, hb)
+    m4ri_amd.lib().mzd_trsm_upper_right(t.ptr, r.ptr, 0)
+    oracle.trsm_upper_right(h, hr)
+    m4ri_amd.lib().mzd_trsm_lower_right(t.ptr, r.ptr, 0)
+    oracle.trsm_lower_right(h, hr)
+    for P in (PT, PB, PR):
+        m4ri_amd.unpin(P)
+    assert np.array_equal(PT.rows(), HT.rows()) and np.array_equal(PB.rows(), HB.rows()) and np.array_equal(PR.rows(), HR.rows())
