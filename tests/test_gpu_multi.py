@@ -153,6 +153,17 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode != 0 and '"n_gpus"' not in r.stdout   # a launcher that started one rank for --gpus 8: refuse, do not print n_gpus 1
 
 
+def test_bench_overlapped_strassen_schedule_at_8_ranks():
+    """BASELINE.json configs[3]'s execution path at 8 ranks with the transport overlapped (two row chunks per sub-product:
+    operands of chunk 1 and the products of chunk 0 travel under the multiplications): every rank's slabs of C against the
+    product it recomputes alone.  (gloo on one GPU completes every batch when it is posted: the bits and the batch order are
+    what is tested here, the overlap itself needs links.)"""
+    out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--overlap", "2"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == 2
+    assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
+
+
 def test_bench_config5_at_8_ranks_takes_row_slabs_and_matches_the_reference():
     """BASELINE.json configs[4] (131072 x 8192 x 131072) at 8 ranks: `auto` = row slabs of A and C + ONE all-gather of B
     (the reference's row parallelism, m4ri/brilliantrussian.c:1121-1123), never the Strassen split; the gathered
