@@ -375,8 +375,9 @@ def main():
                     help="--gpus 1 only: initialise the process group anyway and run the N > 1 code path (its collectives, "
                          "batches and fences) at world size 1 -- how a one-GPU box puts the RCCL path through its paces")
     ap.add_argument("--dims", default="", help="m,l,n of a general product (overrides --size; ragged sizes exercise the uneven slabs)")
-    ap.add_argument("--overlap", type=int, default=-1,
-                    help="strassen variant: row chunks per sub-product whose transport overlaps the products (1 = none; -1 = automatic)")
+    ap.add_argument("--overlap", default="",
+                    help="strassen variant: R or RxC -- row (x column) chunks per sub-product whose transport overlaps the products "
+                         "(1 = none; default: 2 when a rank owns one large sub-product, else 1)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher around it (the reference switches to its multi-core path inside the
@@ -534,10 +535,16 @@ def main():
                  "oper_a": m4ri_amd.BUF_OPER_A, "oper_b": m4ri_amd.BUF_OPER_B, "prod": m4ri_amd.BUF_PROD}
         bufs = {k: words(m4ri_amd.shard_buffer_words(plan, rank, wh)) for k, wh in names.items()}
         runs_a, runs_b = sharding.local_rows(plan, rank, 0), sharding.local_rows(plan, rank, 1)
-        # row chunks per sub-product whose transport runs under the products (sharding.run_strassen_sharded): two when one
-        # product per rank is all there is to hide transfers behind and its halves keep the engine's Strassen depth
-        chunks = args.overlap if args.overlap > 0 else (2 if (plan.levels == 1 and plan.bm >= 4 * sharding.ENGINE_MIN_HALF[0]) else 1)
         sa, sb = runs_a[0][1], runs_b[0][1]
+        # units per sub-product whose transport runs under the products (sharding.run_strassen_sharded).  Default: two ROW chunks when
+        # one product per rank is all there is to hide transfers behind and its halves keep the engine's Strassen depth (measured:
+        # two 16384 x 32768 x 32768 halves cost 1.00 - 1.03 of the whole).  Column chunks on top (--overlap 2x2) expose less on the
+        # links but their quarter-size leaf batches fill the chip 1.5 times: 4 x 1.29 ms against 4.10 ms, a net loss
+        # (profiles/r03_rank_shapes_timing.log) -- available, not the default
+        if args.overlap:
+            chunks = sharding.parse_chunks(args.overlap)
+        else:
+            chunks = (2, 1) if (plan.levels == 1 and plan.bm >= 4 * sharding.ENGINE_MIN_HALF[0]) else (1, 1)
         if args.layout == "distributed":  # the slabs are where the inputs live: fill them straight from the streams
             for b, (g0, rows) in enumerate(runs_a):
                 m4ri_amd.fill_rows_dev(bufs["local_a"].data_ptr() + 8 * b * sa * wl, wl, g0, rows, L, seeds[0], stream)
@@ -582,12 +589,13 @@ def main():
             m4ri_amd.shard_down_dev(plan, rank, bufs["local_a"].data_ptr(), wl, bufs["local_b"].data_ptr(), w,
                                     bufs["child_a"].data_ptr(), bufs["child_b"].data_ptr(), stream)
 
-        def do_product(jl, j, row0=0, rows=None):
+        def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
             rows = plan.bm if rows is None else rows
-            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwn, plan.cwn,
+            w1 = plan.cwn if w1 is None else w1
+            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * ((jl * plan.bm + row0) * plan.cwn + w0), plan.cwn,
                              bufs["oper_a"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwl, plan.cwl,
-                             bufs["oper_b"].data_ptr() + 8 * jl * plan.bl * plan.cwn, plan.cwn,
-                             rows, plan.bl, plan.cwn * 64, False, args.cutoff, stream)
+                             bufs["oper_b"].data_ptr() + 8 * (jl * plan.bl * plan.cwn + w0), plan.cwn,
+                             rows, plan.bl, (w1 - w0) * 64, False, args.cutoff, stream)
 
         def do_up():
             m4ri_amd.shard_up_dev(plan, rank, bufs["slabs_p"].data_ptr(), bufs["local_c"].data_ptr(), w, False, stream)
@@ -602,9 +610,10 @@ def main():
         moved = sum(pc.words * 8 for side, j, r, pc in sharding.strassen_pieces(plan, (0, 1, 2)) if pc.holder != pc.owner)
         config_extra.update({"parallelism": f"strassen-sharded x{world}", "variant": "strassen", "layout": args.layout, "sharded_levels": plan.levels,
                              "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
-                             "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": chunks,
-                             "collective": f"batched isend/irecv (one group per batch: operands out per round and row chunk, products back "
-                                           f"per chunk; {len(sharding.chunk_bounds(plan, chunks))} chunk(s) x {-(-plan.nprod // world)} round(s))",
+                             "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": list(chunks),
+                             "collective": f"batched isend/irecv (one group per batch: operands out per round and row / column chunk, products back "
+                                           f"per unit; {len(sharding.chunk_bounds(plan, chunks[0]))} x {len(sharding.column_bounds(plan, chunks[1]))} unit(s) "
+                                           f"x {-(-plan.nprod // world)} round(s))",
                              "scatter_gather_bytes_per_step": (8 * (M * wl + L * w + M * w) * (world - 1) // world) if args.layout == "owner" else 0})
 
     # ---------------------------------------------------------------- N > 1, blocks of C -----------

@@ -179,55 +179,86 @@ def chunk_bounds(plan, chunks: int):
     return out
 
 
-def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks: int = 1):
+def column_bounds(plan, col_chunks: int):
+    """Column chunks of a sub-product's B operand and result, in whole words: [(w0, w1)] over the plan.cwn words of a row."""
+    cc = max(1, min(col_chunks, plan.cwn))
+    cuts = [plan.cwn * h // cc for h in range(cc + 1)]
+    return [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+
+
+def parse_chunks(spec):
+    """'2' -> (2, 1); '2x2' -> (2, 2); an int or a pair passes through."""
+    if isinstance(spec, (tuple, list)):
+        return int(spec[0]), int(spec[1])
+    if isinstance(spec, int):
+        return spec, 1
+    a, _, b = str(spec).lower().partition("x")
+    return int(a), int(b) if b else 1
+
+
+def _cols(view, row_words, w0, w1):
+    """Words [w0, w1) of every row of a piece stored as whole rows of `row_words` words (a 2-D strided view; torch and numpy alike)."""
+    if w0 == 0 and w1 == row_words:
+        return view
+    return view.reshape(-1, row_words)[:, w0:w1]
+
+
+def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1):
     """One product C = A*B over plan.world ranks; this is rank `rank`'s part.
 
     bufs: dict of 1-D word tensors/arrays keyed 'child_a', 'child_b', 'slabs_p', 'oper_a', 'oper_b', 'prod'
           (sizes: m4ri_amd.shard_buffer_words).
     down():            local parents of A and B -> bufs['child_a'], bufs['child_b']   (local Winograd down pass)
-    product(jl, j, row0, rows): rows [row0, row0 + rows) of bufs['prod'][jl] = the same rows of bufs['oper_a'][jl]
-                       times bufs['oper_b'][jl]                                        (owned sub-product number jl)
+    product(jl, j, row0, rows, w0, w1): rows [row0, row0 + rows), words [w0, w1) of bufs['prod'][jl] = the same rows of
+                       bufs['oper_a'][jl] times the same word columns of bufs['oper_b'][jl]   (owned sub-product number jl)
     up():              bufs['slabs_p'] -> local parent of C                            (local Winograd up pass)
     exchange:          the transport: exchange(sends, recvs) with sends = [(dst_rank, view)], recvs = [(src_rank, view)],
                        each list in the canonical piece order; optionally exchange.post(sends, recvs) -> handle with
                        .wait() for transports that run a batch in the background (see _post).
     copy_local(dst_view, src_view): a piece whose holder and owner are this rank.
+    chunks:            row chunks, or (row chunks, column chunks) / 'RxC', per sub-product (see below).
 
     The schedule (the reference's block-parallel template has no transport to hide, m4ri/mp.c:191-228; here the pieces
     cross xGMI links, so the walk is laid out for overlap).  Sub-products are multiplied in ROUNDS (round q = the q-th
-    owned product of every rank, j in [q W, (q+1) W)), each in `chunks` row chunks (chunk_bounds).  All ranks post the
-    same sequence of batches, every batch one group of point-to-point transfers:
+    owned product of every rank, j in [q W, (q+1) W)), each as R x C units: row chunk c (chunk_bounds: whole slabs) times
+    column chunk h (column_bounds: whole words).  Unit (c, h) needs rows c of the A operand and columns h of the B operand
+    and nothing else, and its part of the result is needed nowhere before the up pass.  All ranks post the same sequence of
+    batches, every batch one group of point-to-point transfers:
 
-        down;  for every round q:  post B(q), post A(q, 0), ..., post A(q, chunks-1)        <- everything outbound, at once
-        for every round q, chunk c:  wait B(q) [c == 0], wait A(q, c);  product rows of chunk c;  post P(q, c)
+        down;  for every round q, unit (c, h) in row-major order:  post B(q, h), A(q, c) unless already posted  <- all outbound, at once
+        for every round q, unit (c, h):  wait B(q, h), A(q, c);  product of the unit;  post P(q, c, h)
         wait every P;  up
 
-    A product needs ALL of its B operand but only chunk c's rows of A for chunk c's rows of the result, and result rows
-    are needed nowhere before the up pass: so A(q, c+1) and every later round's operands travel while chunk (q, c) is
-    multiplied, and P(q, c) travels back under the next chunk's product.  Exposed on the links are B(0), A(0, 0) and the
-    last P only.  chunks = 1 with a synchronous transport is the plain three-phase walk (same batches, same bits).
+    so every operand chunk but the first unit's travels while an earlier unit is multiplied, and every result chunk but the
+    last travels back under a later unit: exposed on the links are B(0, 0), A(0, 0) and the last P only.  chunks = 1 with a
+    synchronous transport is the plain three-phase walk (same bits in every case).  Column chunks are strided views of the
+    row-slab pieces; the transport packs what it cannot move as it is (torch_exchange: a contiguous temporary).
     """
     child = {0: bufs["child_a"], 1: bufs["child_b"]}
     oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
     W = plan.world
     rounds = -(-plan.nprod // W)
-    bounds = chunk_bounds(plan, chunks)
+    rchunks, cchunks = parse_chunks(chunks)
+    bounds = chunk_bounds(plan, rchunks)
+    cbounds = column_bounds(plan, cchunks)
     table = {}
     for side, j, r, pc in strassen_pieces(plan, (0, 1, 2)):
         table.setdefault((side, j // W), []).append((r, pc))
 
-    def batch(side, q, r_lo, r_hi):
+    def batch(side, q, r_lo, r_hi, w0=0, w1=None):
+        row_words = plan.cwl if side == 0 else plan.cwn
+        w1 = row_words if w1 is None else w1
         sends, recvs = [], []
         for r, pc in table.get((side, q), ()):
             if not (r_lo <= r < r_hi):
                 continue
             if side < 2:   # operand slab: holder -> owner
-                src = child[side][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
-                dst = oper[side][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
+                src = _cols(child[side][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
+                dst = _cols(oper[side][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
                 frm, to = pc.holder, pc.owner
             else:          # product slab: owner -> holder
-                src = bufs["prod"][pc.owner_off:pc.owner_off + pc.words] if pc.owner == rank else None
-                dst = bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words] if pc.holder == rank else None
+                src = _cols(bufs["prod"][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
+                dst = _cols(bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
                 frm, to = pc.owner, pc.holder
             if frm == rank and to == rank:
                 copy_local(dst, src)
@@ -240,20 +271,24 @@ def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_loc
     down()
     inbound = {}
     for q in range(rounds):
-        inbound[(1, q)] = batch(1, q, 0, W)
         for c, (lo, hi, _, _) in enumerate(bounds):
-            inbound[(0, q, c)] = batch(0, q, lo, hi)
+            for h, (w0, w1) in enumerate(cbounds):
+                if (1, q, h) not in inbound:
+                    inbound[(1, q, h)] = batch(1, q, 0, W, w0, w1)
+                if (0, q, c) not in inbound:
+                    inbound[(0, q, c)] = batch(0, q, lo, hi)
     owned = owned_products(plan, rank)
     returns = []
     for q in range(rounds):
-        inbound[(1, q)].wait()
         for c, (lo, hi, row0, rows) in enumerate(bounds):
-            inbound[(0, q, c)].wait()
-            if q < len(owned) and rows:
-                product(q, owned[q], row0, rows)
-            returns.append(batch(2, q, lo, hi))
-    for h in returns:
-        h.wait()
+            for h, (w0, w1) in enumerate(cbounds):
+                inbound[(1, q, h)].wait()
+                inbound[(0, q, c)].wait()
+                if q < len(owned) and rows:
+                    product(q, owned[q], row0, rows, w0, w1)
+                returns.append(batch(2, q, lo, hi, w0, w1))
+    for hnd in returns:
+        hnd.wait()
     up()
 
 

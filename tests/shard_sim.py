@@ -66,14 +66,15 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
                 ch = down(X, bside, plan.levels)
                 bufs[key][:plan.nprod * s * cw] = np.concatenate([c.reshape(-1) for c in ch])
 
-    def do_product(jl, j, row0=0, rows=None):
+    def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
         rows = plan.bm if rows is None else rows
+        w1 = plan.cwn if w1 is None else w1
         a0 = jl * plan.bm * plan.cwl + row0 * plan.cwl
         a = Mzd(rows, plan.cwl * 64, buf=bufs["oper_a"][a0:a0 + rows * plan.cwl], rowstride=plan.cwl)
-        b = Mzd(plan.bl, plan.cwn * 64, buf=bufs["oper_b"][jl * plan.bl * plan.cwn:(jl + 1) * plan.bl * plan.cwn], rowstride=plan.cwn)
+        b = Mzd(plan.bl, (w1 - w0) * 64, buf=bufs["oper_b"], rowstride=plan.cwn, offset=jl * plan.bl * plan.cwn + w0, windowed=True)
         p = oracle.mul(None, a.copy(), b.copy(), 0)
         p0 = jl * plan.bm * plan.cwn + row0 * plan.cwn
-        bufs["prod"][p0:p0 + rows * plan.cwn] = p.masked().reshape(-1)
+        bufs["prod"][p0:p0 + rows * plan.cwn].reshape(rows, plan.cwn)[:, w0:w1] = p.masked()
 
     def do_up():
         if sa:
@@ -83,7 +84,7 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
             out["C"] = np.zeros((0, plan.N // 64), dtype=np.uint64)
 
     def copy_local(dst, src):
-        dst[:] = src
+        dst[...] = src
 
     sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local, chunks=chunks)
     return out["C"], sharding.local_rows(plan, rank, 0)

@@ -146,7 +146,7 @@ def test_bench_starts_its_own_ranks():
     assert "all_gather" in out["config"]["collective"] and stdout.count("-> OK") == 2
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--variant", "strassen", "--overlap", "2"])
-    assert out["n_gpus"] == 2 and out["config"]["overlap_chunks"] == 2 and stdout.count("-> OK") == 2
+    assert out["n_gpus"] == 2 and out["config"]["overlap_chunks"] == [2, 1] and stdout.count("-> OK") == 2
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--size", "8192", "--no-cpu-baseline"], capture_output=True, text=True,
                        env=env, timeout=300, cwd=ROOT)
@@ -155,12 +155,12 @@ def test_bench_starts_its_own_ranks():
 
 def test_bench_overlapped_strassen_schedule_at_8_ranks():
     """BASELINE.json configs[3]'s execution path at 8 ranks with the transport overlapped (two row chunks per sub-product:
-    operands of chunk 1 and the products of chunk 0 travel under the multiplications): every rank's slabs of C against the
+    2 row x 2 column units per sub-product: the operand chunks of later units and the results of earlier ones travel under the multiplications): every rank's slabs of C against the
     product it recomputes alone.  (gloo on one GPU completes every batch when it is posted: the bits and the batch order are
     what is tested here, the overlap itself needs links.)"""
     out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--overlap", "2"], timeout=1500)
-    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == 2
+                          "--overlap", "2x2"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2]
     assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
 
 

@@ -55,7 +55,7 @@ def test_plan_arithmetic():
             assert (cover == 1).all()
 
 
-@pytest.mark.parametrize("chunks", [1, 2, 3])   # row chunks of the overlapped schedule: same batches on every rank, same bits
+@pytest.mark.parametrize("chunks", [1, 2, 3, (2, 2), "3x2"])   # row (x column) chunks of the overlapped schedule: same batches on every rank, same bits
 @pytest.mark.parametrize("world,levels,m,l,n", [(2, 1, 64, 128, 128), (2, 2, 100, 256, 256), (3, 1, 77, 130, 65),
                                                 (4, 2, 203, 300, 257), (8, 1, 130, 129, 200), (8, 2, 64, 512, 256),
                                                 (5, 2, 7, 64, 64)])   # more ranks than rows per block: empty slabs
@@ -124,7 +124,8 @@ def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("levels,m,l,n,chunks", [(1, 200, 256, 320, 1), (2, 131, 257, 129, 1), (1, 200, 256, 320, 2), (2, 131, 257, 129, 2)])
+@pytest.mark.parametrize("levels,m,l,n,chunks", [(1, 200, 256, 320, 1), (2, 131, 257, 129, 1), (1, 200, 256, 320, 2), (2, 131, 257, 129, 2),
+                                                 (1, 200, 256, 320, "2x2"), (2, 131, 257, 513, "2x3")])
 def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n, chunks):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path), chunks), nprocs=world, join=True)
@@ -146,3 +147,6 @@ def test_chunk_bounds_cover_the_rows_once():
         assert b[0][0] == 0 and b[-1][1] == world and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     plan = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
     assert [x[2:] for x in sharding.chunk_bounds(plan, 2)] == [(0, 16384), (16384, 16384)]   # halves of a 32768-row sub-product
+    assert sharding.column_bounds(plan, 2) == [(0, 256), (256, 512)] and sharding.column_bounds(plan, 1) == [(0, 512)]
+    assert sharding.column_bounds(m4ri_amd.shard_plan(2, 64, 64, 64), 4) == [(0, 1)]        # one word per row: nothing to cut
+    assert sharding.parse_chunks("2x2") == (2, 2) and sharding.parse_chunks(3) == (3, 1) and sharding.parse_chunks("2") == (2, 1)

@@ -17,7 +17,8 @@ n = 65536
 SHAPES = {"N=1 (1,1,1)": (n, n, n), "slabs N=2": (n // 2, n, n), "slabs N=4": (n // 4, n, n), "slabs N=8": (n // 8, n, n),
           "strassen sub-product (n/2)^3 [N=8: x1]": (n // 2, n // 2, n // 2),
           "  its row half  (overlap chunks = 2: x2)": (n // 4, n // 2, n // 2),
-          "  its row quarter (overlap chunks = 4: x4)": (n // 8, n // 2, n // 2), "strassen sub-product (n/4)^3 [N=4: x13, N=2: x25]": (n // 4, n // 4, n // 4),
+          "  its row quarter (overlap chunks = 4: x4)": (n // 8, n // 2, n // 2),
+          "  its row half x column half (overlap 2x2: x4)": (n // 4, n // 2, n // 4), "strassen sub-product (n/4)^3 [N=4: x13, N=2: x25]": (n // 4, n // 4, n // 4),
           "blocks N=4 (2,2,1)": (n // 2, n, n // 2), "blocks N=8 (4,2,1)": (n // 4, n, n // 2)}
 m4ri_amd.init(0)
 out = {}
