@@ -374,6 +374,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise the process group anyway and run the N > 1 code path (its collectives, "
                          "batches and fences) at world size 1 -- how a one-GPU box puts the RCCL path through its paces")
+    ap.add_argument("--slab-overlap", type=int, default=-1,
+                    help="slabs variant: multiply with the rank's own slab of B while the all-gather of the others runs "
+                         "(1 / 0; default: on up to 4 ranks)")
     ap.add_argument("--dims", default="", help="m,l,n of a general product (overrides --size; ragged sizes exercise the uneven slabs)")
     ap.add_argument("--overlap", default="",
                     help="strassen variant: R or RxC -- row (x column) chunks per sub-product whose transport overlaps the products "
@@ -493,6 +496,10 @@ def main():
             Bs = None
             if rank == 0:
                 Cfull = torch.empty((M, w), dtype=torch.int64, device="cuda")
+        # the all-gather of B under the first product: needs every slab boundary of B on a word of A's rows, and pays when a rank's
+        # own slab is a large part of the inner dimension (few ranks); --slab-overlap 0/1 overrides
+        aligned = all(c % 64 == 0 for c in bc[:-1]) and lr > 0
+        slab_overlap = args.layout == "distributed" and aligned and (world <= 4 if args.slab_overlap < 0 else bool(args.slab_overlap))
 
         def step():
             if args.layout == "owner":             # rank 0 scatters the slabs of A and broadcasts B; C is gathered
@@ -506,9 +513,26 @@ def main():
                     As.copy_(A[:mr])
                     Bfull[:L].copy_(B)
                 exchange([x for x in sends if x[1].numel()], [x for x in recvs if x[1].numel()])
+            elif slab_overlap:
+                # the ONE collective of the variant runs under the product with the rank's own slab of B: C_r = A_r[:, own] * B_own
+                # first (nothing to wait for), then += A_r[:, before] * B[before] and A_r[:, after] * B[after] from the gathered B
+                pending = sharding.all_gather_rows(dist, Bfull, Bs, staged=staged, async_op=True)
+                first = True
+                for k0, k1, own in sharding.slab_product_pieces(bc, rank):
+                    if not own and pending is not None:
+                        pending.wait()
+                        pending = None
+                    if mr:
+                        bsrc = Bs.data_ptr() if own else Bfull.data_ptr() + 8 * k0 * w
+                        m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr() + 8 * (k0 // 64), wl, bsrc, w, mr, k1 - k0, N, not first, args.cutoff, stream)
+                        first = False
+                if pending is not None:
+                    pending.wait()
             else:
                 sharding.all_gather_rows(dist, Bfull, Bs, staged=staged)   # the ONE collective of the variant
-            if mr:
+                if mr:
+                    m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr(), wl, Bfull.data_ptr(), w, mr, L, N, False, args.cutoff, stream)
+            if mr and args.layout == "owner":
                 m4ri_amd.mul_dev(Cs.data_ptr(), w, As.data_ptr(), wl, Bfull.data_ptr(), w, mr, L, N, False, args.cutoff, stream)
             if args.layout == "owner":
                 sends, recvs = [], []
@@ -524,7 +548,7 @@ def main():
                 exchange(sends, recvs)
         per_rank_product = [ka, L, N]
         config_extra.update({"parallelism": f"row slabs x{world} + all-gather of B", "variant": "slabs", "layout": args.layout,
-                             "slab_rows": [ka, kb],
+                             "slab_rows": [ka, kb], "all_gather_under_first_product": bool(slab_overlap),
                              "bytes_over_links_per_step": 8 * kb * w * (world - 1) * (1 if args.layout == "distributed" else 0),
                              "collective": "all_gather_into_tensor(B)" if args.layout == "distributed" else "batched send/recv scatter + gather"})
 

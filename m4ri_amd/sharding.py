@@ -372,20 +372,32 @@ def slab_cuts(rows: int, world: int):
     return [min(r * k, rows) for r in range(world + 1)]
 
 
-def all_gather_rows(dist, full, mine, staged=False):
+def all_gather_rows(dist, full, mine, staged=False, async_op=False):
     """full (W * k rows) <- the ranks' `mine` (k rows each, the short last slab padded) in rank order:
     dist.all_gather_into_tensor, or its host-staged equivalent for backends that cannot move device tensors (gloo
-    in the one-GPU tests)."""
+    in the one-GPU tests).  async_op: return a handle at once -- under RCCL the collective runs on the communicator's
+    stream and handle.wait() orders the current stream behind it (the host does not block), so a product that needs only
+    the rank's OWN slab of B can be multiplied meanwhile (bench.py, slabs variant); staged / gloo: complete on return."""
     assert full.shape[0] == dist.get_world_size() * mine.shape[0], (tuple(full.shape), tuple(mine.shape))
     import torch
     if not staged:
-        dist.all_gather_into_tensor(full.view(-1), mine.contiguous().view(-1))
-        return
+        work = dist.all_gather_into_tensor(full.view(-1), mine.contiguous().view(-1), async_op=async_op)
+        return work if async_op else None
     parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, mine.cpu() if mine.is_cuda else mine.contiguous())
     k = mine.shape[0]
     for r, t in enumerate(parts):
         full[r * k:(r + 1) * k].copy_(t)
+    return _Done() if async_op else None
+
+
+def slab_product_pieces(cuts, rank):
+    """Inner-dimension pieces of C_r = A_r * B for the overlapped row-slab product, in the order they are multiplied: the
+    rank's OWN row slab of B first (resident: needs nothing from the links), then what lies before and after it in the
+    gathered B.  Returns [(k0, k1, own)] with empty pieces dropped."""
+    k0, k1 = cuts[rank], cuts[rank + 1]
+    out = [(k0, k1, True), (0, k0, False), (k1, cuts[-1], False)]
+    return [p for p in out if p[1] > p[0]]
 
 
 # the single-GPU engine's own rule for one more Strassen-Winograd level (engine.hip: default depth): a leaf keeps at

@@ -91,7 +91,7 @@ def test_large_product_matches_single_device(oracle):
 
 @pytest.mark.parametrize("world,variant,layout", [(2, "strassen", "distributed"), (2, "strassen", "owner"), (2, "blocks", "owner"),
                                                   (4, "strassen", "distributed"), (2, "slabs", "distributed"), (4, "slabs", "owner"),
-                                                  (2, "auto", "distributed")])
+                                                  (2, "auto", "distributed"), (4, "slabs", "distributed"), (3, "slabs", "distributed")])
 def test_bench_ranks_on_one_gpu(world, variant, layout):
     """bench.py's N > 1 path, ranks as processes sharing GPU 0, transport = gloo staged through the host
     (RCCL refuses two ranks on one device); --check compares every rank's part of C with the product the rank

@@ -159,3 +159,18 @@ def test_slab_cuts_and_default_variant():
     assert sharding.default_variant(8, 131072, 8192, 131072) == "slabs"
     assert sharding.default_variant(8, 4096, 65536, 65536) == "slabs" and sharding.default_variant(8, 65536, 65536, 4096) == "slabs"
     assert sharding.default_variant(4, 65536, 65536, 65536) == "slabs"
+
+
+def test_slab_product_pieces_cover_the_inner_dimension_own_slab_first():
+    """The overlapped row-slab product: C_r = A_r[:, own] * B_own first (nothing to wait for), then the pieces before and after the
+    rank's own slab from the gathered B -- together the whole inner dimension, once."""
+    for rows, world in ((65536, 2), (65536, 4), (8192, 8), (100, 3), (4, 3)):
+        cuts = sharding.slab_cuts(rows, world)
+        for rank in range(world):
+            pieces = sharding.slab_product_pieces(cuts, rank)
+            if cuts[rank + 1] > cuts[rank]:
+                assert pieces[0] == (cuts[rank], cuts[rank + 1], True)
+            assert all(not own for _, _, own in pieces[1:]) and sum(b - a for a, b, _ in pieces) == rows
+            cover = sorted((a, b) for a, b, _ in pieces)
+            assert cover[0][0] == 0 and cover[-1][1] == rows and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+    assert sharding.slab_product_pieces([0, 16384, 32768, 49152, 65536], 1) == [(16384, 32768, True), (0, 16384, False), (32768, 65536, False)]

@@ -15,6 +15,10 @@ import m4ri_amd
 
 n = 65536
 SHAPES = {"N=1 (1,1,1)": (n, n, n), "slabs N=2": (n // 2, n, n), "slabs N=4": (n // 4, n, n), "slabs N=8": (n // 8, n, n),
+          "  slabs N=2, inner half (own slab of B first, then the gathered half: x2)": (n // 2, n // 2, n),
+          "  slabs N=4, inner quarter (own slab / a 1-slab piece)": (n // 4, n // 4, n),
+          "  slabs N=4, inner half (a 2-slab piece)": (n // 4, n // 2, n),
+          "  slabs N=4, inner three quarters (a 3-slab piece)": (n // 4, 3 * n // 4, n),
           "strassen sub-product (n/2)^3 [N=8: x1]": (n // 2, n // 2, n // 2),
           "  its row half  (overlap chunks = 2: x2)": (n // 4, n // 2, n // 2),
           "  its row quarter (overlap chunks = 4: x4)": (n // 8, n // 2, n // 2),
