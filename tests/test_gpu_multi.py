@@ -164,6 +164,18 @@ def test_bench_overlapped_strassen_schedule_at_8_ranks():
     assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
 
 
+def test_bench_config4_at_8_ranks_full_size_matches_the_reference():
+    """BASELINE.json configs[3] exactly as the driver's 8-GPU command runs it -- 65536^3, `--variant auto` = the 7 sub-products of the
+    top Strassen-Winograd level over 8 ranks, slab-cyclic layout, two row chunks per sub-product in flight -- minus the links (8
+    processes on this one GPU, gloo): the C gathered from the 8 ranks against the real reference's SHA-256, and every rank's slabs
+    against the product it recomputes alone."""
+    out, stdout = _bench(["--gpus", "8", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1"], timeout=2400)
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["variant"] == "strassen" and cfg["sub_products"] == 7 and cfg["overlap_chunks"] == [2, 1]
+    assert cfg["per_rank_product"] == [32768, 32768, 32768] and cfg["bytes_over_links_per_step"] == 3 * 7 * 7 * (16 << 20)
+    assert out["verified"]["matches_reference"] is True and stdout.count("-> OK") == 8
+
+
 def test_bench_config5_at_8_ranks_takes_row_slabs_and_matches_the_reference():
     """BASELINE.json configs[4] (131072 x 8192 x 131072) at 8 ranks: `auto` = row slabs of A and C + ONE all-gather of B
     (the reference's row parallelism, m4ri/brilliantrussian.c:1121-1123), never the Strassen split; the gathered
