@@ -29,6 +29,10 @@ N > 1 (one process per GPU, torch.distributed.run, RCCL); --variant auto (defaul
       optionally the inner dimension split with ONE pairwise XOR exchange (--grid 2,2,2); blocks of A and B
       are scattered from rank 0 and the reduced blocks of C gathered there (owner layout only).
 
+At N > 1 (distributed layout) the timed loop keeps TWO products in flight (--inflight 2, sharding.run_products: the transport of the
+neighbouring products runs under the multiplications of the current one) -- `value` / `ms_per_step` are the throughput of that stream of
+products; `latency_ms` in the same line is the wall clock of ONE isolated product (fence, product, fence; max over ranks).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "roofline"     the dominant kernel (the M4RM leaf launch) against the HBM roofline: duration = mean over ALL
                  timed steps of HIP events around that launch on its stream; "traffic" = HBM bytes per launch
@@ -374,6 +378,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise the process group anyway and run the N > 1 code path (its collectives, "
                          "batches and fences) at world size 1 -- how a one-GPU box puts the RCCL path through its paces")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="N > 1, distributed layout: products in flight in the timed loop -- 2: the transport of product k+1 (operands) and of "
+                         "product k-1 (results) runs under the multiplications of product k (throughput of a stream of products; the latency of "
+                         "ONE product is measured beside it and reported as latency_ms); 1: one product at a time.  Default: 2")
     ap.add_argument("--slab-overlap", type=int, default=-1,
                     help="slabs variant: multiply with the rank's own slab of B while the all-gather of the others runs "
                          "(1 / 0; default: on up to 4 ranks)")
@@ -454,6 +462,9 @@ def main():
         exchange = sharding.torch_exchange(dist, staged_device=("cuda" if args.backend == "gloo" else None))
     A = B = Cfull = None
     config_extra = {}
+    phase_steps = None            # per buffer slot: an object with start() / multiply() / finish() (sharding.run_products)
+    last = {"slot": 0}            # the slot that holds the C of the last product
+    inflight = (args.inflight or 2) if (multi and args.layout == "distributed" and args.variant in ("slabs", "strassen")) else 1
     if args.variant == "blocks" and args.layout == "distributed" and multi:
         args.layout = "owner"  # the blocks variant scatters from rank 0 by construction
     need_full_inputs = not multi or args.layout == "owner" or args.variant == "blocks"
@@ -483,8 +494,9 @@ def main():
         ka, kb = sharding.slab_rows(M, world), sharding.slab_rows(L, world)
         mr, lr = rc[rank + 1] - rc[rank], bc[rank + 1] - bc[rank]   # rows of this rank's slab of A / C, and of B
         staged = args.backend == "gloo"
-        Bfull = torch.empty((world * kb, w), dtype=torch.int64, device="cuda")
-        Cs = torch.empty((max(mr, 1), w), dtype=torch.int64, device="cuda")[:mr]
+        Bfull_slots = [torch.empty((world * kb, w), dtype=torch.int64, device="cuda") for _ in range(inflight)]
+        Cs_slots = [torch.empty((max(mr, 1), w), dtype=torch.int64, device="cuda")[:mr] for _ in range(inflight)]
+        Bfull, Cs = Bfull_slots[0], Cs_slots[0]
         As = torch.empty((max(mr, 1), wl), dtype=torch.int64, device="cuda")[:mr]
         if args.layout == "distributed":           # the slabs are where the inputs live
             Bs = torch.zeros((kb, w), dtype=torch.int64, device="cuda")
@@ -501,7 +513,8 @@ def main():
         aligned = all(c % 64 == 0 for c in bc[:-1]) and lr > 0
         slab_overlap = args.layout == "distributed" and aligned and (world <= 4 if args.slab_overlap < 0 else bool(args.slab_overlap))
 
-        def step():
+        def step():   # one product at a time, always on slot 0
+            Cs, Bfull = Cs_slots[0], Bfull_slots[0]
             if args.layout == "owner":             # rank 0 scatters the slabs of A and broadcasts B; C is gathered
                 sends, recvs = [], []
                 for r in range(1, world):
@@ -546,6 +559,23 @@ def main():
                 if rank == 0:
                     Cfull[:mr].copy_(Cs)
                 exchange(sends, recvs)
+        class SlabStep:   # the throughput form: the whole product against the gathered B, the all-gather of the NEXT product's B under it
+            def __init__(self, slot):
+                self.slot, self.pending = slot, None
+
+            def start(self):
+                self.pending = sharding.all_gather_rows(dist, Bfull_slots[self.slot], Bs, staged=staged, async_op=True)
+
+            def multiply(self):
+                self.pending.wait()
+                if mr:
+                    m4ri_amd.mul_dev(Cs_slots[self.slot].data_ptr(), w, As.data_ptr(), wl, Bfull_slots[self.slot].data_ptr(), w, mr, L, N, False,
+                                     args.cutoff, stream)
+
+            def finish(self):
+                pass
+        if inflight > 1:
+            phase_steps = [SlabStep(slot) for slot in range(inflight)]
         per_rank_product = [ka, L, N]
         config_extra.update({"parallelism": f"row slabs x{world} + all-gather of B", "variant": "slabs", "layout": args.layout,
                              "slab_rows": [ka, kb], "all_gather_under_first_product": bool(slab_overlap),
@@ -558,6 +588,9 @@ def main():
                  "child_a": m4ri_amd.BUF_CHILD_A, "child_b": m4ri_amd.BUF_CHILD_B, "slabs_p": m4ri_amd.BUF_SLABS_P,
                  "oper_a": m4ri_amd.BUF_OPER_A, "oper_b": m4ri_amd.BUF_OPER_B, "prod": m4ri_amd.BUF_PROD}
         bufs = {k: words(m4ri_amd.shard_buffer_words(plan, rank, wh)) for k, wh in names.items()}
+        # a second product in flight has its own children / operands / products / slabs / result; the inputs are shared
+        slot_bufs = [bufs] + [{k: (bufs[k] if k in ("local_a", "local_b") else words(m4ri_amd.shard_buffer_words(plan, rank, wh)))
+                               for k, wh in names.items()} for _ in range(inflight - 1)]
         runs_a, runs_b = sharding.local_rows(plan, rank, 0), sharding.local_rows(plan, rank, 1)
         sa, sb = runs_a[0][1], runs_b[0][1]
         # units per sub-product whose transport runs under the products (sharding.run_strassen_sharded).  Default: two ROW chunks when
@@ -609,25 +642,32 @@ def main():
                         sends.append((0, bufs["local_c"][b * s * w:(b * s + rows) * w]))
             exchange(sends, recvs)
 
-        def do_down():
-            m4ri_amd.shard_down_dev(plan, rank, bufs["local_a"].data_ptr(), wl, bufs["local_b"].data_ptr(), w,
-                                    bufs["child_a"].data_ptr(), bufs["child_b"].data_ptr(), stream)
+        def sharded_step(sb_):   # the three phases of one product on one slot's buffers
+            def do_down():
+                m4ri_amd.shard_down_dev(plan, rank, sb_["local_a"].data_ptr(), wl, sb_["local_b"].data_ptr(), w,
+                                        sb_["child_a"].data_ptr(), sb_["child_b"].data_ptr(), stream)
 
-        def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
-            rows = plan.bm if rows is None else rows
-            w1 = plan.cwn if w1 is None else w1
-            m4ri_amd.mul_dev(bufs["prod"].data_ptr() + 8 * ((jl * plan.bm + row0) * plan.cwn + w0), plan.cwn,
-                             bufs["oper_a"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwl, plan.cwl,
-                             bufs["oper_b"].data_ptr() + 8 * (jl * plan.bl * plan.cwn + w0), plan.cwn,
-                             rows, plan.bl, (w1 - w0) * 64, False, args.cutoff, stream)
+            def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
+                rows = plan.bm if rows is None else rows
+                w1 = plan.cwn if w1 is None else w1
+                m4ri_amd.mul_dev(sb_["prod"].data_ptr() + 8 * ((jl * plan.bm + row0) * plan.cwn + w0), plan.cwn,
+                                 sb_["oper_a"].data_ptr() + 8 * (jl * plan.bm + row0) * plan.cwl, plan.cwl,
+                                 sb_["oper_b"].data_ptr() + 8 * (jl * plan.bl * plan.cwn + w0), plan.cwn,
+                                 rows, plan.bl, (w1 - w0) * 64, False, args.cutoff, stream)
 
-        def do_up():
-            m4ri_amd.shard_up_dev(plan, rank, bufs["slabs_p"].data_ptr(), bufs["local_c"].data_ptr(), w, False, stream)
+            def do_up():
+                m4ri_amd.shard_up_dev(plan, rank, sb_["slabs_p"].data_ptr(), sb_["local_c"].data_ptr(), w, False, stream)
+            return sharding.StrassenShardedStep(plan, rank, sb_, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks)
+        slot_steps = [sharded_step(sb_) for sb_ in slot_bufs]
+        if inflight > 1:
+            phase_steps = slot_steps
 
         def step():
             if args.layout == "owner":
                 scatter_from_owner()
-            sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks)
+            slot_steps[0].start()
+            slot_steps[0].multiply()
+            slot_steps[0].finish()
             if args.layout == "owner":
                 gather_to_owner()
         per_rank_product = [plan.bm, plan.bl, plan.cwn * 64]
@@ -728,15 +768,25 @@ def main():
         return
 
     # ---------------------------------------------------------------- timing ------------------------
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n, marks=None):
+        """n products back to back: one at a time through step(), or -- inflight 2 -- software-pipelined over two buffer slots."""
+        before = (lambda k: marks[k].record()) if marks is not None else None
+        if phase_steps is None or inflight == 1:
+            for k in range(n):
+                if before is not None:
+                    before(k)
+                step()
+            last["slot"] = 0
+        else:
+            sharding.run_products(lambda k: phase_steps[k % inflight], n, inflight, before)
+            last["slot"] = (n - 1) % inflight
+
+    run_steps(args.warmup)
     fence()
     m4ri_amd.set_profiling(2)  # leaf launches bracketed by HIP events on their stream, accumulated over all steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        marks[k].record()
-        step()
+    run_steps(args.steps, marks)
     marks[args.steps].record()
     fence()
     t1 = time.perf_counter()
@@ -753,6 +803,32 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     ops = float(M) * L * N  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
     value = ops * args.steps / elapsed
+    if multi and args.variant == "slabs":
+        Cs, Bfull = Cs_slots[last["slot"]], Bfull_slots[last["slot"]]
+    if multi and args.variant == "strassen":
+        bufs = slot_bufs[last["slot"]]
+    latency_ms = None
+    if phase_steps is not None and inflight > 1:
+        # the other half of the metric, wall clock of ONE mzd_mul: isolated products (fence, one product through step(), fence), max over
+        # ranks, best of 3 -- the pipelined loop above is the throughput of a stream of products
+        lat = []
+        for _ in range(3):
+            fence()
+            ta = time.perf_counter()
+            step()
+            fence()
+            lat.append(time.perf_counter() - ta)
+        tl = torch.tensor([min(lat)], dtype=torch.float64, device="cuda")
+        if args.backend == "gloo":
+            tl = tl.cpu()
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        latency_ms = 1e3 * float(tl.item())
+        if last["slot"] != 0:   # step() left its result in slot 0: the same product, point the checks there
+            last["slot"] = 0
+            if args.variant == "slabs":
+                Cs, Bfull = Cs_slots[0], Bfull_slots[0]
+            else:
+                bufs = slot_bufs[0]
 
     # ---------------------------------------------------------------- correctness of what was timed --
     verified = None
@@ -895,6 +971,12 @@ def main():
             lds["frac_in_cycles"] = need / traffic_detail["gui_active_cycles"]
             lds["effective_clock_hz"] = traffic_detail["effective_clock_hz"]
         out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
+        if multi:
+            out["config"]["inflight"] = inflight
+            if latency_ms is not None:
+                out["latency_ms"] = latency_ms
+                out["latency_note"] = ("one isolated product (fence, product, fence; max over ranks, best of 3); `value` and `ms_per_step` are the "
+                                       "timed loop with 2 products in flight: transport of the neighbouring products under the multiplications")
         if verified is not None:
             out["verified"] = verified
         if args.workload != "leaf16384":

@@ -203,6 +203,84 @@ def _cols(view, row_words, w0, w1):
     return view.reshape(-1, row_words)[:, w0:w1]
 
 
+class StrassenShardedStep:
+    """One sharded product as three phases, so that a caller with several products to multiply can keep more than one in flight
+    (bench.py --inflight 2: start(k+1), multiply(k), finish(k-1) -- the operands of product k+1 and the results of product k-1
+    cross the links while product k is multiplied).  start(); multiply(); finish() in a row is run_strassen_sharded.
+    Arguments and schedule: run_strassen_sharded."""
+
+    def __init__(self, plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1):
+        self.plan, self.rank, self.bufs = plan, rank, bufs
+        self.down, self.product, self.up, self.exchange, self.copy_local = down, product, up, exchange, copy_local
+        self.W = plan.world
+        self.rounds = -(-plan.nprod // self.W)
+        rchunks, cchunks = parse_chunks(chunks)
+        self.bounds = chunk_bounds(plan, rchunks)
+        self.cbounds = column_bounds(plan, cchunks)
+        self.table = {}
+        for side, j, r, pc in strassen_pieces(plan, (0, 1, 2)):
+            self.table.setdefault((side, j // self.W), []).append((r, pc))
+        self.inbound, self.returns = {}, []
+
+    def _batch(self, side, q, r_lo, r_hi, w0=0, w1=None):
+        plan, rank, bufs = self.plan, self.rank, self.bufs
+        child = {0: bufs["child_a"], 1: bufs["child_b"]}
+        oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
+        row_words = plan.cwl if side == 0 else plan.cwn
+        w1 = row_words if w1 is None else w1
+        sends, recvs = [], []
+        for r, pc in self.table.get((side, q), ()):
+            if not (r_lo <= r < r_hi):
+                continue
+            if side < 2:   # operand slab: holder -> owner
+                src = _cols(child[side][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
+                dst = _cols(oper[side][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
+                frm, to = pc.holder, pc.owner
+            else:          # product slab: owner -> holder
+                src = _cols(bufs["prod"][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
+                dst = _cols(bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
+                frm, to = pc.owner, pc.holder
+            if frm == rank and to == rank:
+                self.copy_local(dst, src)
+            elif frm == rank:
+                sends.append((to, src))
+            elif to == rank:
+                recvs.append((frm, dst))
+        return _post(self.exchange, sends, recvs)
+
+    def start(self):
+        """Local down pass, then every outbound operand chunk posted, in the order the units will want them."""
+        self.down()
+        self.inbound = {}
+        for q in range(self.rounds):
+            for c, (lo, hi, _, _) in enumerate(self.bounds):
+                for h, (w0, w1) in enumerate(self.cbounds):
+                    if (1, q, h) not in self.inbound:
+                        self.inbound[(1, q, h)] = self._batch(1, q, 0, self.W, w0, w1)
+                    if (0, q, c) not in self.inbound:
+                        self.inbound[(0, q, c)] = self._batch(0, q, lo, hi)
+
+    def multiply(self):
+        """Every unit: wait for its operand chunks, multiply, post its part of the result."""
+        owned = owned_products(self.plan, self.rank)
+        self.returns = []
+        for q in range(self.rounds):
+            for c, (lo, hi, row0, rows) in enumerate(self.bounds):
+                for h, (w0, w1) in enumerate(self.cbounds):
+                    self.inbound[(1, q, h)].wait()
+                    self.inbound[(0, q, c)].wait()
+                    if q < len(owned) and rows:
+                        self.product(q, owned[q], row0, rows, w0, w1)
+                    self.returns.append(self._batch(2, q, lo, hi, w0, w1))
+
+    def finish(self):
+        """Wait for the slabs of every product, then the local up pass."""
+        for hnd in self.returns:
+            hnd.wait()
+        self.returns = []
+        self.up()
+
+
 def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1):
     """One product C = A*B over plan.world ranks; this is rank `rank`'s part.
 
@@ -234,62 +312,48 @@ def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_loc
     synchronous transport is the plain three-phase walk (same bits in every case).  Column chunks are strided views of the
     row-slab pieces; the transport packs what it cannot move as it is (torch_exchange: a contiguous temporary).
     """
-    child = {0: bufs["child_a"], 1: bufs["child_b"]}
-    oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
-    W = plan.world
-    rounds = -(-plan.nprod // W)
-    rchunks, cchunks = parse_chunks(chunks)
-    bounds = chunk_bounds(plan, rchunks)
-    cbounds = column_bounds(plan, cchunks)
-    table = {}
-    for side, j, r, pc in strassen_pieces(plan, (0, 1, 2)):
-        table.setdefault((side, j // W), []).append((r, pc))
+    step = StrassenShardedStep(plan, rank, bufs, down, product, up, exchange, copy_local, chunks)
+    step.start()
+    step.multiply()
+    step.finish()
 
-    def batch(side, q, r_lo, r_hi, w0=0, w1=None):
-        row_words = plan.cwl if side == 0 else plan.cwn
-        w1 = row_words if w1 is None else w1
-        sends, recvs = [], []
-        for r, pc in table.get((side, q), ()):
-            if not (r_lo <= r < r_hi):
-                continue
-            if side < 2:   # operand slab: holder -> owner
-                src = _cols(child[side][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
-                dst = _cols(oper[side][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
-                frm, to = pc.holder, pc.owner
-            else:          # product slab: owner -> holder
-                src = _cols(bufs["prod"][pc.owner_off:pc.owner_off + pc.words], row_words, w0, w1) if pc.owner == rank else None
-                dst = _cols(bufs["slabs_p"][pc.holder_off:pc.holder_off + pc.words], row_words, w0, w1) if pc.holder == rank else None
-                frm, to = pc.owner, pc.holder
-            if frm == rank and to == rank:
-                copy_local(dst, src)
-            elif frm == rank:
-                sends.append((to, src))
-            elif to == rank:
-                recvs.append((frm, dst))
-        return _post(exchange, sends, recvs)
 
-    down()
-    inbound = {}
-    for q in range(rounds):
-        for c, (lo, hi, _, _) in enumerate(bounds):
-            for h, (w0, w1) in enumerate(cbounds):
-                if (1, q, h) not in inbound:
-                    inbound[(1, q, h)] = batch(1, q, 0, W, w0, w1)
-                if (0, q, c) not in inbound:
-                    inbound[(0, q, c)] = batch(0, q, lo, hi)
-    owned = owned_products(plan, rank)
-    returns = []
-    for q in range(rounds):
-        for c, (lo, hi, row0, rows) in enumerate(bounds):
-            for h, (w0, w1) in enumerate(cbounds):
-                inbound[(1, q, h)].wait()
-                inbound[(0, q, c)].wait()
-                if q < len(owned) and rows:
-                    product(q, owned[q], row0, rows, w0, w1)
-                returns.append(batch(2, q, lo, hi, w0, w1))
-    for hnd in returns:
-        hnd.wait()
-    up()
+def run_products(make_step, n, inflight=1, before=None):
+    """n products, each an object with start() / multiply() / finish() (StrassenShardedStep, or anything shaped like it), made by
+    make_step(k).  inflight = 1: one after the other.  inflight = 2: software-pipelined --
+
+        start(0);   for k:  start(k+1);  multiply(k);  finish(k-1);      finish(n-1)
+
+    so the transport a start() and a multiply() post (operands of product k+1, results of product k) runs under the multiplications of
+    the neighbouring product.  Product k may reuse the buffers of product k-2 (two slots): start(k+1) touches the slot's child /
+    operand buffers, which multiply(k-1) has finished with, and finish(k-1) the slot's slab / result buffers, which nothing writes
+    before multiply(k+1).  before(k) is called ahead of product k's first action inside the loop (timing marks)."""
+    if n <= 0:
+        return
+    if inflight <= 1:
+        for k in range(n):
+            if before is not None:
+                before(k)
+            st = make_step(k)
+            st.start()
+            st.multiply()
+            st.finish()
+        return
+    assert inflight == 2, "one or two products in flight"
+    cur, prev = make_step(0), None
+    cur.start()
+    for k in range(n):
+        if before is not None:
+            before(k)
+        nxt = None
+        if k + 1 < n:
+            nxt = make_step(k + 1)
+            nxt.start()
+        cur.multiply()
+        if prev is not None:
+            prev.finish()
+        prev, cur = cur, nxt
+    prev.finish()
 
 
 def local_rows(plan, rank, which):

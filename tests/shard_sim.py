@@ -90,6 +90,51 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
     return out["C"], sharding.local_rows(plan, rank, 0)
 
 
+def rank_products(plan, rank, pairs, oracle, exchange, inflight=2, chunks=1):
+    """Several products [(A_k, B_k)] through sharding.run_products on `inflight` buffer slots (product k on slot k % inflight):
+    rank `rank`'s local parents of every C_k.  What is under test is that a slot's buffers are not reused before their product
+    is through with them."""
+    names = {"child_a": m4ri_amd.BUF_CHILD_A, "child_b": m4ri_amd.BUF_CHILD_B, "slabs_p": m4ri_amd.BUF_SLABS_P,
+             "oper_a": m4ri_amd.BUF_OPER_A, "oper_b": m4ri_amd.BUF_OPER_B, "prod": m4ri_amd.BUF_PROD}
+    slots = [{k: np.zeros(max(1, m4ri_amd.shard_buffer_words(plan, rank, w)), dtype=np.uint64) for k, w in names.items()} for _ in range(max(1, inflight))]
+    sa, sb = m4ri_amd.shard_slab_rows(plan, rank, 0), m4ri_amd.shard_slab_rows(plan, rank, 1)
+    out = {}
+
+    def make_step(k):
+        bufs = slots[k % len(slots)]
+        A, B = pairs[k]
+        LA = local_parent(plan, rank, 0, A, plan.L // 64)
+        LB = local_parent(plan, rank, 1, B, plan.N // 64)
+
+        def do_down():
+            for key, X, bside, s_, cw in (("child_a", LA, False, sa, plan.cwl), ("child_b", LB, True, sb, plan.cwn)):
+                if s_:
+                    bufs[key][:plan.nprod * s_ * cw] = np.concatenate([c.reshape(-1) for c in down(X, bside, plan.levels)])
+
+        def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
+            rows = plan.bm if rows is None else rows
+            w1 = plan.cwn if w1 is None else w1
+            a0 = jl * plan.bm * plan.cwl + row0 * plan.cwl
+            a = Mzd(rows, plan.cwl * 64, buf=bufs["oper_a"][a0:a0 + rows * plan.cwl], rowstride=plan.cwl)
+            b = Mzd(plan.bl, (w1 - w0) * 64, buf=bufs["oper_b"], rowstride=plan.cwn, offset=jl * plan.bl * plan.cwn + w0, windowed=True)
+            p0 = jl * plan.bm * plan.cwn + row0 * plan.cwn
+            bufs["prod"][p0:p0 + rows * plan.cwn].reshape(rows, plan.cwn)[:, w0:w1] = oracle.mul(None, a.copy(), b.copy(), 0).masked()
+
+        def do_up():
+            if sa:
+                P = [bufs["slabs_p"][j * sa * plan.cwn:(j + 1) * sa * plan.cwn].reshape(sa, plan.cwn) for j in range(plan.nprod)]
+                out[k] = up(P, plan.levels)
+            else:
+                out[k] = np.zeros((0, plan.N // 64), dtype=np.uint64)
+
+        def copy_local(dst, src):
+            dst[...] = src
+        return sharding.StrassenShardedStep(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local, chunks)
+
+    sharding.run_products(make_step, len(pairs), inflight)
+    return [out[k] for k in range(len(pairs))], sharding.local_rows(plan, rank, 0)
+
+
 def assemble(plan, parts, m, n):
     """parts: {rank: (C_local, runs)} -> the m x n result as masked words."""
     wn = (n + 63) // 64

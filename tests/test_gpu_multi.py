@@ -144,6 +144,10 @@ def test_bench_starts_its_own_ranks():
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["variant"] == "slabs"
     assert "all_gather" in out["config"]["collective"] and stdout.count("-> OK") == 2
+    assert out["config"]["inflight"] == 2 and out["latency_ms"] > 0      # the loop keeps two products in flight; one product's latency beside it
+    out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                          "--inflight", "1"])
+    assert out["config"]["inflight"] == 1 and "latency_ms" not in out and stdout.count("-> OK") == 2
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--variant", "strassen", "--overlap", "2"])
     assert out["n_gpus"] == 2 and out["config"]["overlap_chunks"] == [2, 1] and stdout.count("-> OK") == 2
@@ -158,9 +162,9 @@ def test_bench_overlapped_strassen_schedule_at_8_ranks():
     2 row x 2 column units per sub-product: the operand chunks of later units and the results of earlier ones travel under the multiplications): every rank's slabs of C against the
     product it recomputes alone.  (gloo on one GPU completes every batch when it is posted: the bits and the batch order are
     what is tested here, the overlap itself needs links.)"""
-    out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                           "--overlap", "2x2"], timeout=1500)
-    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2]
+    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2] and out["config"]["inflight"] == 2
     assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
 
 

@@ -150,3 +150,43 @@ def test_chunk_bounds_cover_the_rows_once():
     assert sharding.column_bounds(plan, 2) == [(0, 256), (256, 512)] and sharding.column_bounds(plan, 1) == [(0, 512)]
     assert sharding.column_bounds(m4ri_amd.shard_plan(2, 64, 64, 64), 4) == [(0, 1)]        # one word per row: nothing to cut
     assert sharding.parse_chunks("2x2") == (2, 2) and sharding.parse_chunks(3) == (3, 1) and sharding.parse_chunks("2") == (2, 1)
+
+
+@pytest.mark.parametrize("world,levels,chunks,inflight", [(8, 1, 2, 2), (4, 2, 1, 2), (3, 1, "2x2", 2), (2, 2, 1, 1)])
+def test_products_in_flight_on_two_buffer_slots(oracle, world, levels, chunks, inflight):
+    """sharding.run_products: start(k+1), multiply(k), finish(k-1) over two buffer slots, five DIFFERENT products in a row -- every
+    C_k must be its own product (a slot reused too early would mix neighbours)."""
+    m, l, n = 130, 257, 200
+    pairs = [(Mzd.random(m, l, 100 + k), Mzd.random(l, n, 200 + k)) for k in range(5)]
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    mail, lock, barrier = {}, threading.Lock(), threading.Barrier(world)
+    parts, errors = {}, []
+
+    def make_exchange(rank):
+        def exchange(sends, recvs):
+            with lock:
+                for dst, v in sends:
+                    mail.setdefault((rank, dst), []).append(np.array(v, copy=True))
+            barrier.wait()
+            for src, v in recvs:
+                with lock:
+                    v[...] = mail[(src, rank)].pop(0)
+            barrier.wait()
+        return exchange
+
+    def work(rank):
+        try:
+            parts[rank] = shard_sim.rank_products(plan, rank, pairs, oracle, make_exchange(rank), inflight, chunks)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k, (A, B) in enumerate(pairs):
+        got = shard_sim.assemble(plan, {r: (parts[r][0][k], parts[r][1]) for r in range(world)}, m, n)
+        assert np.array_equal(got, oracle.mul(None, A, B, 0).masked()), k
