@@ -642,7 +642,7 @@ def main():
                         sends.append((0, bufs["local_c"][b * s * w:(b * s + rows) * w]))
             exchange(sends, recvs)
 
-        def sharded_step(sb_):   # the three phases of one product on one slot's buffers
+        def sharded_step(sb_, chunks_):   # the three phases of one product on one slot's buffers
             def do_down():
                 m4ri_amd.shard_down_dev(plan, rank, sb_["local_a"].data_ptr(), wl, sb_["local_b"].data_ptr(), w,
                                         sb_["child_a"].data_ptr(), sb_["child_b"].data_ptr(), stream)
@@ -657,17 +657,20 @@ def main():
 
             def do_up():
                 m4ri_amd.shard_up_dev(plan, rank, sb_["slabs_p"].data_ptr(), sb_["local_c"].data_ptr(), w, False, stream)
-            return sharding.StrassenShardedStep(plan, rank, sb_, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks)
-        slot_steps = [sharded_step(sb_) for sb_ in slot_bufs]
+            return sharding.StrassenShardedStep(plan, rank, sb_, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks_)
+        # one product at a time (step(), `latency_ms`): row chunks hide part of its own transport.  Two products in flight: the neighbours'
+        # multiplications hide all of it, so the sub-products stay whole (their halves cost up to 3 % more than the whole)
+        single_step = sharded_step(slot_bufs[0], chunks)
+        chunks_loop = chunks if (args.overlap or inflight == 1) else (1, 1)
         if inflight > 1:
-            phase_steps = slot_steps
+            phase_steps = [sharded_step(sb_, chunks_loop) for sb_ in slot_bufs]
 
         def step():
             if args.layout == "owner":
                 scatter_from_owner()
-            slot_steps[0].start()
-            slot_steps[0].multiply()
-            slot_steps[0].finish()
+            single_step.start()
+            single_step.multiply()
+            single_step.finish()
             if args.layout == "owner":
                 gather_to_owner()
         per_rank_product = [plan.bm, plan.bl, plan.cwn * 64]
@@ -675,6 +678,7 @@ def main():
         config_extra.update({"parallelism": f"strassen-sharded x{world}", "variant": "strassen", "layout": args.layout, "sharded_levels": plan.levels,
                              "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
                              "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": list(chunks),
+                             "overlap_chunks_in_the_timed_loop": list(chunks_loop),
                              "collective": f"batched isend/irecv (one group per batch: operands out per round and row / column chunk, products back "
                                            f"per unit; {len(sharding.chunk_bounds(plan, chunks[0]))} x {len(sharding.column_bounds(plan, chunks[1]))} unit(s) "
                                            f"x {-(-plan.nprod // world)} round(s))",
