@@ -190,3 +190,39 @@ def test_products_in_flight_on_two_buffer_slots(oracle, world, levels, chunks, i
     for k, (A, B) in enumerate(pairs):
         got = shard_sim.assemble(plan, {r: (parts[r][0][k], parts[r][1]) for r in range(world)}, m, n)
         assert np.array_equal(got, oracle.mul(None, A, B, 0).masked()), k
+
+
+def _pipeline_worker(rank, world, port, levels, m, l, n, out_dir, chunks):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_libs
+    orc = cpu_libs.oracle()
+    pairs = [(Mzd.random(m, l, 300 + k), Mzd.random(l, n, 400 + k)) for k in range(4)]
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    torch_x = sharding.torch_exchange(dist)   # CPU tensors under gloo: isend / irecv really run in the background until wait()
+
+    def as_t(v):
+        return torch.from_numpy(v.view(np.int64))
+
+    def exchange(sends, recvs):
+        torch_x([(d, as_t(v)) for d, v in sends], [(s_, as_t(v)) for s_, v in recvs])
+    exchange.post = lambda sends, recvs: torch_x.post([(d, as_t(v)) for d, v in sends], [(s_, as_t(v)) for s_, v in recvs])
+    Cs, runs = shard_sim.rank_products(plan, rank, pairs, orc, exchange, 2, chunks)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), runs=np.array(runs), **{f"C{k}": c for k, c in enumerate(Cs)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("levels,chunks", [(1, 2), (2, 1)])
+def test_two_products_in_flight_two_ranks_gloo(tmp_path, oracle, levels, chunks):
+    """run_products over the asynchronous transport (torch_exchange.post: batches posted, waited for later) with two ranks under gloo:
+    four different products through two buffer slots, each against the oracle."""
+    world, (m, l, n) = 2, (200, 256, 320)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path), chunks), nprocs=world, join=True)
+    plan = m4ri_amd.shard_plan(world, m, l, n, levels)
+    z = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for k in range(4):
+        parts = {r: (z[r][f"C{k}"], [tuple(int(x) for x in row) for row in z[r]["runs"]]) for r in range(world)}
+        got = shard_sim.assemble(plan, parts, m, n)
+        assert np.array_equal(got, oracle.mul(None, Mzd.random(m, l, 300 + k), Mzd.random(l, n, 400 + k), 0).masked()), k
