@@ -1,22 +1,23 @@
-"""Multi-GPU decomposition of one product C = A*B: one process per GPU, block products sharded with
-no data-path collective except ONE pairwise XOR exchange when the inner dimension is split.
+"""One product C = A*B over several GPUs, one process per GPU (bench.py drives it).
 
-The template is the reference's own multi-core path, _mzd_mul_mp4 (reference m4ri/mp.c:158-275): C is
-split into blocks and every rank computes its block(s) C_ij = A_i* x B_*j.  The default grids split
-only the rows and columns of C, so no rank ever needs another rank's data:
+Three ways to hand the work out, all bit-identical to the single-GPU product:
 
-    world 1: (1,1,1)   world 2: (2,1,1) rows of C   world 4: (2,2,1)   world 8: (4,2,1) blocks of C
+  * Strassen sub-products (the design for 5+ ranks; StrassenShardedStep, run_strassen_sharded, run_products): the 7 or 49
+    sub-products of the top Strassen-Winograd level(s) (reference m4ri/strassen.c:111-150) go to the ranks, the matrices are
+    distributed slab-cyclically, so the level's additions are local passes and only slabs of operands / products cross the
+    xGMI mesh -- every rank to every rank, one send/recv pair per piece, posted in batches laid out so that transport runs under
+    the multiplications (row / column chunks inside one product, and -- for a stream of products -- two products in flight).
+    The plan and the piece table come from libm4ri_amd.so (pure host arithmetic, include/m4ri_amd.h part 4).
+  * Row slabs (2 and 4 ranks, and any product a Strassen level cannot help: default_variant): rank r holds rows of A, B and C;
+    ONE collective, the all-gather of B (all_gather_rows), which runs under the product with the rank's own slab
+    (slab_product_pieces) or under the previous product.  The reference's own row parallelism, m4ri/brilliantrussian.c:1121-1123.
+  * Blocks of C (ShardPlan, run_sharded; kept for comparison): the reference's own multi-core template, _mzd_mul_mp4
+    (m4ri/mp.c:158-275) -- every rank computes C_ij = A_i* x B_*j; a grid may also split the inner dimension (gh > 1), the gh
+    partial products then meet by ONE pairwise exchange + a local XOR kernel (RCCL has no XOR reduction and none is needed).
 
-(the engine gives the resulting rectangular blocks, e.g. 16384 x 65536 x 32768 at 8 GPUs, the same
-Strassen depth per leaf size as a cube).  A grid may also split the inner dimension (gh > 1, e.g.
-(2,2,2)): the gh partial products of a block then sit on different GPUs and are combined by a
-pairwise exchange over xGMI; RCCL has no XOR reduction, so the reduce is "send/recv half of the
-partial product + local XOR kernel" -- each pair talks over its own point-to-point link, nothing is
-ring-shaped.  That costs 64 MiB per rank and product at n = 65536, which is why it is not the default.
-
-Everything here is device-agnostic (views are (row0, rows, col0_bits, cols_bits) tuples; the multiply,
-XOR and transport are injected), so the same code runs under gloo on CPU tensors in the tests and
-under RCCL on HBM tensors in bench.py.
+Everything here is device-agnostic: the multiply, the local passes and the transport are injected, so the same walks run under
+gloo on CPU arrays in the tests (tests/shard_sim.py), under gloo with several ranks sharing one GPU, and under RCCL on HBM
+tensors in bench.py.  torch_exchange is the transport over torch.distributed.
 """
 from __future__ import annotations
 
