@@ -406,7 +406,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             if args.variant == "auto":

@@ -97,8 +97,13 @@ def test_bench_ranks_on_one_gpu(world, variant, layout):
     (RCCL refuses two ranks on one device); --check compares every rank's part of C with the product the rank
     recomputes alone."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
            "--size", "8192", "--backend", "gloo", "--check", "--variant", variant, "--layout", layout, "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -230,7 +235,12 @@ def test_rccl_backend_at_world_size_1():
     """The transport code of the N > 1 path (sharding.torch_exchange incl. its asynchronous post/wait, all_gather_rows, the
     barrier and the max-reduce of bench.py) through the real nccl (= RCCL) backend, the only way a one-GPU box can: world
     size 1, self-addressed batches.  API misuse shows up here, not in the driver's 8-GPU run."""
-    r = subprocess.run([sys.executable, "-c", _NCCL_PROBE, ROOT, "29541"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    r = subprocess.run([sys.executable, "-c", _NCCL_PROBE, ROOT, str(port)], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "probe OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
