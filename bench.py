@@ -979,6 +979,9 @@ def main():
             need = lds["bound_ms"] * 1e-3 * PEAK_CLOCK_HZ
             lds["frac_in_cycles"] = need / traffic_detail["gui_active_cycles"]
             lds["effective_clock_hz"] = traffic_detail["effective_clock_hz"]
+            lds["note"] = ("frac prices the launch at the 2.4 GHz peak clock, frac_in_cycles at the clock it really ran at (GRBM_GUI_ACTIVE / duration): "
+                           "the kernel sits on the chip's power limit.  Of the cycles with the LDS idle ~10 % are bubbles of the gather pipeline itself "
+                           "(gathers alone: 90 % busy) and ~4.5 % the stage barrier (profiles/r03_leaf_decomposition/README.md)")
         out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
         if multi:
             out["config"]["inflight"] = inflight
