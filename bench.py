@@ -29,9 +29,16 @@ N > 1 (one process per GPU, torch.distributed.run, RCCL); --variant auto (defaul
       optionally the inner dimension split with ONE pairwise XOR exchange (--grid 2,2,2); blocks of A and B
       are scattered from rank 0 and the reduced blocks of C gathered there (owner layout only).
 
-At N > 1 (distributed layout) the timed loop keeps TWO products in flight (--inflight 2, sharding.run_products: the transport of the
-neighbouring products runs under the multiplications of the current one) -- `value` / `ms_per_step` are the throughput of that stream of
-products; `latency_ms` in the same line is the wall clock of ONE isolated product (fence, product, fence; max over ranks).
+`value` / `ms_per_step` are always ONE product at a time (the metric is the wall clock of one n x n mzd_mul).  --inflight 2 adds a second,
+separately named measurement: `pipelined_value` / `pipelined_ms_per_step`, the throughput of a stream of independent products with two
+in flight (sharding.run_products: the transport of the neighbouring products runs under the multiplications of the current one).
+
+N > 1 transports (--transport): `rccl` = one process per GPU, torch.distributed (backend nccl == RCCL) send/recv + all-gather, as above;
+`peer` = ONE process driving all GPUs through libm4ri_amd.so's distributed matrices (m4ri_amd_dmat_mul, m4ri_amd/csrc/multi.hip: the same
+two schedules behind the C boundary, pieces pulled by hipMemcpyPeerAsync on copy streams, one host thread per GPU).  The command that
+receives `--gpus N` is a CONTROLLER: it starts the ranks itself, watches them (--watchdog seconds) and walks down a ladder
+rccl -> peer -> a JSON error line, so that an N-GPU run always ends with exactly one line (`config.transport`, `config.transport_fallback`).
+Under `torch.distributed.run` rank 0 is the controller and the other launcher ranks step aside.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "roofline"     the dominant kernel (the M4RM leaf launch) against the HBM roofline: duration = mean over ALL
@@ -332,20 +339,81 @@ def sha_of_device_rows(t, chunk_rows=8192):
     return h.hexdigest()
 
 
-def self_launch(n_ranks: int) -> int:
-    """Re-run this very command line under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free
-    port) and return its exit code; the ranks' stdout is ours, so rank 0's JSON line is the command's output."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+LAUNCHER_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                "MASTER_ADDR", "MASTER_PORT", "NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+
+
+def run_rung(transport: str, n_ranks: int, argv: list, watchdog_s: float):
+    """One rung of the N > 1 ladder in processes of its own (own session: on a timeout the whole group we started is killed, nothing
+    else).  rccl: `torch.distributed.run --standalone` (it picks its own rendezvous port on 127.0.0.1) with one rank per GPU; peer: one
+    process driving all GPUs.  Returns (the rung's JSON line or None, why it failed or None, its other stdout lines)."""
+    import signal
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC_")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    return subprocess.run(cmd, env=env).returncode
+    args, skip = [], False
+    for a in argv:  # the rung gets this command's own arguments, minus what the controller decides
+        if skip:
+            skip = False
+        elif a in ("--transport", "--watchdog"):
+            skip = True
+        elif not (a.startswith("--transport=") or a.startswith("--watchdog=") or a == "--inner"):
+            args.append(a)
+    me = os.path.abspath(__file__)
+    if transport == "rccl":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+               me, *args, "--inner", "--transport", "rccl"]
+    else:
+        cmd = [sys.executable, me, *args, "--inner", "--transport", "peer"]
+    with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:
+        proc = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True)
+        why = None
+        try:
+            rc = proc.wait(timeout=watchdog_s)
+            if rc != 0:
+                why = f"exit code {rc}"
+        except subprocess.TimeoutExpired:
+            why = f"no result within the {watchdog_s:.0f} s watchdog: ranks killed"
+        finally:
+            try:  # the session we started (torchrun and its ranks), nothing else; a finished group is simply gone
+                os.killpg(proc.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            proc.wait()
+        fo.seek(0)
+        fe.seek(0)
+        out_lines, err_tail = fo.read().splitlines(), fe.read()[-1500:]
+    lines = [ln for ln in out_lines if ln.startswith("{") and '"metric"' in ln]
+    rest = [ln for ln in out_lines if not (ln.startswith("{") and '"metric"' in ln)]
+    if why is None and len(lines) != 1:
+        why = f"{len(lines)} result lines"
+    if why is not None:
+        errs = [ln for ln in out_lines if ln.startswith("{") and '"error"' in ln]
+        detail = errs[-1] if errs else " | ".join(err_tail.strip().splitlines()[-3:])
+        return None, f"{why}: {detail}"[:700], rest
+    return lines[0], None, rest
+
+
+def controller(args) -> int:
+    """`bench.py --gpus N` as a command: start the ranks, watch them, fall back down the ladder rccl -> peer, and end with exactly
+    one JSON line either way (the reference switches to its multi-core path inside the same command, bench/bench_multiplication.c:94-103)."""
+    ladder = {"auto": ["rccl", "peer"], "rccl": ["rccl"], "peer": ["peer"]}[args.transport]
+    if args.variant == "blocks" or args.layout == "owner":
+        ladder = [t for t in ladder if t == "rccl"] or ["rccl"]  # scatter / gather layouts exist over torch.distributed only
+    failed = []
+    for transport in ladder:
+        line, why, rest = run_rung(transport, args.gpus, sys.argv[1:], args.watchdog)
+        for ln in rest:
+            print(ln, flush=True)
+        if line is not None:
+            out = json.loads(line)
+            out["config"]["transport"] = transport
+            out["config"]["transport_fallback"] = failed
+            print(json.dumps(out), flush=True)
+            return 0
+        failed.append({"transport": transport, "reason": why})
+    print(json.dumps({"error": f"no transport completed the {args.gpus}-GPU run", "gpus_requested": args.gpus, "transport_fallback": failed}), flush=True)
+    return 1
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -378,10 +446,17 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise the process group anyway and run the N > 1 code path (its collectives, "
                          "batches and fences) at world size 1 -- how a one-GPU box puts the RCCL path through its paces")
-    ap.add_argument("--inflight", type=int, default=0,
-                    help="N > 1, distributed layout: products in flight in the timed loop -- 2: the transport of product k+1 (operands) and of "
-                         "product k-1 (results) runs under the multiplications of product k (throughput of a stream of products; the latency of "
-                         "ONE product is measured beside it and reported as latency_ms); 1: one product at a time.  Default: 2")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2],
+                    help="N > 1, distributed layout, rccl transport: 2 = after the timed loop (always one product at a time: `value`) also time a "
+                         "software-pipelined stream of products, two in flight -- the transport of product k+1 (operands) and of product k-1 (results) "
+                         "under the multiplications of product k -- reported as pipelined_value / pipelined_ms_per_step")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"],
+                    help="N > 1: rccl = one process per GPU over torch.distributed; peer = one process, all GPUs, m4ri_amd_dmat_mul (peer copies); "
+                         "auto = rccl, falling back to peer when the ranks fail or do not finish within --watchdog seconds")
+    ap.add_argument("--watchdog", type=float, default=420.0, help="N > 1: seconds one rung of the transport ladder may take before its processes are killed")
+    ap.add_argument("--virtual-ranks", action="store_true",
+                    help="peer transport: allow more ranks than visible GPUs (ranks share devices round robin: how a one-GPU box tests the path)")
+    ap.add_argument("--inner", action="store_true", help="internal: this process is a rank / the single process of a rung the controller started")
     ap.add_argument("--slab-overlap", type=int, default=-1,
                     help="slabs variant: multiply with the rank's own slab of B while the all-gather of the others runs "
                          "(1 / 0; default: on up to 4 ranks)")
@@ -393,35 +468,50 @@ def main():
 
     # `python bench.py --gpus N` with no launcher around it (the reference switches to its multi-core path inside the
     # same command, bench/bench_multiplication.c:94-103): start the N ranks ourselves, one per GPU, and let rank 0 print
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.probe:
-        raise SystemExit(self_launch(args.gpus))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and not args.inner and not args.probe:
+        # this command is the controller of an N-GPU run.  Under a launcher that already started N copies of it, copy 0 takes the
+        # role and the others step aside: the ranks that do the work are the controller's own, watched and replaceable
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        raise SystemExit(controller(args))
+    peer = args.transport == "peer" and args.gpus > 1
+    world = args.gpus if peer else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if peer else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if peer else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:  # never print an n_gpus the command did not ask for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     multi = world > 1 or args.force_dist   # the distributed code path (normally N > 1)
-    if multi:
+    if peer:
+        ndev = m4ri_amd.lib().m4ri_amd_device_count()
+        if ndev < world and not args.virtual_ranks:
+            print(json.dumps({"error": f"--transport peer --gpus {world}: only {ndev} device(s) visible (--virtual-ranks lets ranks share devices: a test aid)"}), flush=True)
+            raise SystemExit(2)
+        m4ri_amd.set_devices([i % max(1, ndev) for i in range(world)])
+        torch.cuda.set_device(0)
+    elif multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        solo = world == 1 and "MASTER_PORT" not in os.environ   # --force-dist typed by hand: a store on a port of its own choosing
         if world == 1:
-            if "MASTER_PORT" not in os.environ:
-                import socket
-                sk = socket.socket()
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-                sk.close()
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             if args.variant == "auto":
                 args.variant = "strassen"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=max(60.0, min(args.watchdog, 600.0)))   # a rank that never arrives is an error, not a hang
+        rdzv = {"init_method": "tcp://127.0.0.1:0", "rank": 0, "world_size": 1} if solo else {}
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout, **rdzv)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout, **rdzv)
+        inject = os.environ.get("M4RI_AMD_BENCH_INJECT", "") if args.inner else ""   # test hook: the first rung fails / never finishes
+        if inject == "crash":
+            raise SystemExit(9)
+        if inject == "hang":
+            time.sleep(1e6)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -447,7 +537,7 @@ def main():
     plan = None
     if args.variant == "strassen" and multi:
         plan = m4ri_amd.shard_plan(world, M, L, N, args.shard_levels)
-        if (plan.M, plan.L, plan.N) != (M, L, N):  # the slab-cyclic layout of this script holds unpadded slabs only
+        if (plan.M, plan.L, plan.N) != (M, L, N) and not peer:  # the slab-cyclic layout of this script holds unpadded slabs only (the library pads its own)
             if not auto:
                 raise SystemExit(f"--variant strassen: {M}x{L}x{N} needs padding to {plan.M}x{plan.L}x{plan.N} in the slab-cyclic layout; "
                                  "bench.py runs such sizes as row slabs (mzd_mul_mp pads them itself)")
@@ -458,6 +548,8 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
+        if peer:
+            m4ri_amd.multi_sync()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -469,10 +561,10 @@ def main():
     config_extra = {}
     phase_steps = None            # per buffer slot: an object with start() / multiply() / finish() (sharding.run_products)
     last = {"slot": 0}            # the slot that holds the C of the last product
-    inflight = (args.inflight or 2) if (multi and args.layout == "distributed" and args.variant in ("slabs", "strassen")) else 1
+    inflight = args.inflight if (multi and not peer and args.layout == "distributed" and args.variant in ("slabs", "strassen")) else 1
     if args.variant == "blocks" and args.layout == "distributed" and multi:
         args.layout = "owner"  # the blocks variant scatters from rank 0 by construction
-    need_full_inputs = not multi or args.layout == "owner" or args.variant == "blocks"
+    need_full_inputs = not multi or ((args.layout == "owner" or args.variant == "blocks") and not peer)
     if need_full_inputs and (not multi or rank == 0):
         A = torch.empty((M, wl), dtype=torch.int64, device="cuda")
         B = torch.empty((L, w), dtype=torch.int64, device="cuda")
@@ -490,6 +582,31 @@ def main():
                 m4ri_amd.mul_dev(Cfull.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, M, L, N, False, args.cutoff, stream)
         per_rank_product = [M, L, N]
         config_extra["parallelism"] = "1 GPU"
+
+    # ---------------------------------------------------------------- N > 1, one process, all GPUs: the schedules behind the C boundary
+    elif peer:
+        if args.variant not in ("slabs", "strassen"):
+            raise SystemExit("--transport peer runs the slabs and the strassen schedule (m4ri_amd_dmat_mul)")
+        v = m4ri_amd.VARIANT_SLABS if args.variant == "slabs" else m4ri_amd.VARIANT_STRASSEN
+        if v == m4ri_amd.VARIANT_STRASSEN:
+            lay = m4ri_amd.LAYOUT_CYCLIC2 if plan.levels == 2 else m4ri_amd.LAYOUT_CYCLIC1
+        else:
+            lay = m4ri_amd.LAYOUT_ROWS
+        dA, dB, dC = m4ri_amd.Dmat(M, L, lay).fill(seeds[0]), m4ri_amd.Dmat(L, N, lay).fill(seeds[1]), m4ri_amd.Dmat(M, N, lay)
+        issue_s = [0.0]
+
+        def step():   # asynchronous: returns when every rank's host thread has issued its part (the devices work on)
+            ta = time.perf_counter()
+            m4ri_amd.dmat_mul(dC, dA, dB, False, args.cutoff, v)
+            issue_s[0] += time.perf_counter() - ta
+        if v == m4ri_amd.VARIANT_STRASSEN:
+            per_rank_product = [plan.bm, plan.bl, plan.cwn * 64]
+        else:
+            per_rank_product = [sharding.slab_rows(M, world), L, N]
+        config_extra.update({"parallelism": (f"strassen-sharded x{world}" if v == m4ri_amd.VARIANT_STRASSEN else f"row slabs x{world} + gather of B")
+                                            + ", one process, peer copies", "variant": args.variant, "layout": "distributed",
+                             "devices": m4ri_amd.get_devices(), "virtual_ranks_sharing_devices": len(set(m4ri_amd.get_devices())) < world,
+                             "collective": "hipMemcpyPeerAsync pulls on per-device copy streams, HIP events between ranks; one host thread per rank (multi.hip)"})
 
     # ---------------------------------------------------------------- N > 1, row slabs + all-gather of B
     elif args.variant == "slabs":
@@ -777,10 +894,10 @@ def main():
         return
 
     # ---------------------------------------------------------------- timing ------------------------
-    def run_steps(n, marks=None):
-        """n products back to back: one at a time through step(), or -- inflight 2 -- software-pipelined over two buffer slots."""
+    def run_steps(n, marks=None, pipelined=False):
+        """n products back to back: one at a time through step(), or -- pipelined -- two in flight over two buffer slots."""
         before = (lambda k: marks[k].record()) if marks is not None else None
-        if phase_steps is None or inflight == 1:
+        if not pipelined:
             for k in range(n):
                 if before is not None:
                     before(k)
@@ -790,54 +907,51 @@ def main():
             sharding.run_products(lambda k: phase_steps[k % inflight], n, inflight, before)
             last["slot"] = (n - 1) % inflight
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if args.backend == "gloo":
+            tt = tt.cpu()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     run_steps(args.warmup)
     fence()
     m4ri_amd.set_profiling(2)  # leaf launches bracketed by HIP events on their stream, accumulated over all steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if peer:
+        issue_s[0] = 0.0
     t0 = time.perf_counter()
     run_steps(args.steps, marks)
     marks[args.steps].record()
+    t_posted = time.perf_counter()   # every step is posted; the devices may still be working
     fence()
     t1 = time.perf_counter()
-    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)) if not peer else None
     stats = m4ri_amd.get_stats()  # last product's schedule + the leaf launch durations of ALL timed steps
     m4ri_amd.set_profiling(0)
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        if args.backend == "gloo":
-            tt = tt.cpu()
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(t1 - t0)
+    # how long the HOST needs to post one step, no fence inside: must stay well below the step for the devices never to wait for it
+    host_issue_ms = 1e3 * max_over_ranks((issue_s[0] if peer else (t_posted - t0)) / args.steps)
     ms_per_step = 1e3 * elapsed / args.steps
     ops = float(M) * L * N  # classical bit multiply-accumulates of the WHOLE product (AND+XOR = 1 op)
     value = ops * args.steps / elapsed
-    if multi and args.variant == "slabs":
-        Cs, Bfull = Cs_slots[last["slot"]], Bfull_slots[last["slot"]]
-    if multi and args.variant == "strassen":
-        bufs = slot_bufs[last["slot"]]
-    latency_ms = None
+    pipelined = None
     if phase_steps is not None and inflight > 1:
-        # the other half of the metric, wall clock of ONE mzd_mul: isolated products (fence, one product through step(), fence), max over
-        # ranks, best of 3 -- the pipelined loop above is the throughput of a stream of products
-        lat = []
-        for _ in range(3):
-            fence()
-            ta = time.perf_counter()
-            step()
-            fence()
-            lat.append(time.perf_counter() - ta)
-        tl = torch.tensor([min(lat)], dtype=torch.float64, device="cuda")
-        if args.backend == "gloo":
-            tl = tl.cpu()
-        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-        latency_ms = 1e3 * float(tl.item())
-        if last["slot"] != 0:   # step() left its result in slot 0: the same product, point the checks there
-            last["slot"] = 0
-            if args.variant == "slabs":
-                Cs, Bfull = Cs_slots[0], Bfull_slots[0]
-            else:
-                bufs = slot_bufs[0]
+        # a second, separately named measurement: the throughput of a STREAM of independent products, two in flight (the transport of
+        # the neighbouring products under the multiplications of the current one).  Never the headline: the metric is one mzd_mul
+        run_steps(2, None, True)
+        fence()
+        tp0 = time.perf_counter()
+        run_steps(args.steps, None, True)
+        fence()
+        tp = max_over_ranks(time.perf_counter() - tp0)
+        pipelined = {"pipelined_value": ops * args.steps / tp, "pipelined_ms_per_step": 1e3 * tp / args.steps}
+    if multi and not peer and args.variant == "slabs":
+        Cs, Bfull = Cs_slots[last["slot"]], Bfull_slots[last["slot"]]
+    if multi and not peer and args.variant == "strassen":
+        bufs = slot_bufs[last["slot"]]
 
     # ---------------------------------------------------------------- correctness of what was timed --
     verified = None
@@ -850,7 +964,19 @@ def main():
             if got != want:
                 print(json.dumps({"error": "C differs from the reference", "sha256": got, "expected": want}), flush=True)
                 raise SystemExit(4)
-    if multi and not args.no_verify and args.workload != "leaf16384":
+    Chost = None
+    if peer and not args.no_verify:
+        want = golden_sha("mul", M, L, N, seeds)
+        if want is not None:
+            Chost = dC.download()   # every device its own rows, outside the timed region
+            got = hashlib.sha256(Chost.masked().tobytes()).hexdigest()
+            verified = {"sha256": got, "matches_reference": got == want,
+                        "what": f"C of the last timed step, downloaded from the {world} ranks, vs the real reference's product of the same inputs "
+                                "(tests/golden/sha256.json)"}
+            if got != want:
+                print(json.dumps({"error": "C differs from the reference", "sha256": got, "expected": want}), flush=True)
+                raise SystemExit(4)
+    if multi and not peer and not args.no_verify and args.workload != "leaf16384":
         # the distributed result against the reference's: gather the ranks' rows of C on rank 0 (outside the timed region,
         # over the same transport) and compare its SHA-256 with the golden one, when tests/golden holds one for this product
         want = golden_sha("mul", M, L, N, seeds)
@@ -893,7 +1019,11 @@ def main():
         full = torch.empty((M, w), dtype=torch.int64, device="cuda")
         m4ri_amd.mul_dev(full.data_ptr(), w, fullA.data_ptr(), wl, fullB.data_ptr(), w, M, L, N, False, 0, stream)
         torch.cuda.synchronize()
-        if args.variant == "slabs":
+        if peer:
+            Chost = Chost if Chost is not None else dC.download()
+            ok = bool(np.array_equal(Chost.valid_words().view(np.int64), full.cpu().numpy()))
+            what = "the whole C, downloaded"
+        elif args.variant == "slabs":
             ok = bool(torch.equal(Cs, full[rc[rank]:rc[rank + 1]]))
             what = f"rows {rc[rank]}:{rc[rank + 1]} of C"
         elif args.variant == "strassen":
@@ -905,7 +1035,7 @@ def main():
             o0, o1 = bplan.owned_rows_after_reduce()
             ok = bool(torch.equal(P[o0 - r0:o1 - r0], full[o0:o1, c0 // 64:c1 // 64]))
             what = f"rows {o0}:{o1} cols {c0}:{c1}"
-        if rank == 0 and Cfull is not None:
+        if rank == 0 and Cfull is not None and not peer:
             ok = ok and bool(torch.equal(Cfull, full))
             what += " + the gathered C"
         print(f"[check] rank {rank} {config_extra.get('parallelism')} {what} -> {'OK' if ok else 'MISMATCH'}", flush=True)
@@ -952,12 +1082,14 @@ def main():
                 **config_extra,
             },
             "roofline": {
-                "bound": "hbm",
+                # the resource that binds the kernel is the LDS array (`lds` below); achieved / peak / frac are the HBM figures SURVEY.md 8(d) asks for
+                "bound": "lds",
                 "kernel": LEAF_KERNELS.get(int(stats.leaf_gen), "?") + " (the M4RM leaf; HIP events around every launch on its stream, mean over all timed steps)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "hbm_frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
                 "launch_ms": leaf_launch_ms,
@@ -982,13 +1114,24 @@ def main():
             lds["note"] = ("frac prices the launch at the 2.4 GHz peak clock, frac_in_cycles at the clock it really ran at (GRBM_GUI_ACTIVE / duration): "
                            "the kernel sits on the chip's power limit.  Of the cycles with the LDS idle ~10 % are bubbles of the gather pipeline itself "
                            "(gathers alone: 90 % busy) and ~4.5 % the stage barrier (profiles/r03_leaf_decomposition/README.md)")
-        out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
+        if step_ms:
+            out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
+        out["host_issue_ms_per_step"] = host_issue_ms
         if multi:
-            out["config"]["inflight"] = inflight
-            if latency_ms is not None:
-                out["latency_ms"] = latency_ms
-                out["latency_note"] = ("one isolated product (fence, product, fence; max over ranks, best of 3); `value` and `ms_per_step` are the "
-                                       "timed loop with 2 products in flight: transport of the neighbouring products under the multiplications")
+            out["config"]["inflight"] = 1
+            out["config"]["transport"] = "peer" if peer else "rccl"
+            if pipelined is not None:
+                out.update(pipelined)
+                out["pipelined_note"] = ("a stream of independent products, two in flight (transport of the neighbouring products under the multiplications): "
+                                         "throughput of that stream; `value` / `ms_per_step` are one product at a time")
+            if peer:
+                ms = m4ri_amd.multi_stats()
+                out["config"].update({"schedule_stats": {"variant": m4ri_amd.VARIANT_NAMES.get(ms.variant), "sharded_levels": ms.levels, "sub_products": ms.sub_products,
+                                                         "row_chunks": ms.chunks, "gather_under_first_product": bool(ms.overlap),
+                                                         "operands_converted": ms.converted, "bytes_over_links_per_step": ms.link_bytes},
+                                      "timeline_ms_last_step": {str(r): m4ri_amd.multi_timeline(r) for r in range(world)},
+                                      "timeline_marks": ("strassen: down pass done; per row chunk: operands in, product done; result slabs in; up pass done"
+                                                         if ms.variant == m4ri_amd.VARIANT_STRASSEN else "slabs: gather done; first product done; all done")})
         if verified is not None:
             out["verified"] = verified
         if args.workload != "leaf16384":
@@ -997,6 +1140,8 @@ def main():
             # this rank's products / step time); the compulsory bytes beside it
             pm, pl, pn = per_rank_product
             nprod_rank = 1 if (not multi or args.variant != "strassen") else len(sharding.owned_products(plan, 0))
+            if peer and args.variant == "strassen":   # the library's own padding (every dimension to 256 bits) and row chunks
+                pm, pl, pn = plan.bm, plan.bl, plan.cwn * 64
             bs = float(bytes_sched(pm, pl, pn, int(stats.levels))) * nprod_rank
             out["roofline_schedule"] = {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

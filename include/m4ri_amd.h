@@ -412,11 +412,68 @@ int m4ri_amd_shard_up_dev(const m4ri_amd_shard_plan *p, int rank, const word *sl
 /* Rows [row0, row0 + rows) of the matrix m4ri_amd_fill_dev(seed) would fill, written to M (for filling
  * local parents of a distributed matrix without materialising the whole). */
 int m4ri_amd_fill_rows_dev(word *M, int64_t stride, int64_t row0, int64_t rows, int64_t ncols, uint64_t seed, void *stream);
-/* One process, several devices, host matrices: C (+)= A*B with every device uploading / downloading its
- * own slabs and pieces moving by peer copies.  levels as above.  Returns 0 or a hipError_t value. */
+/* ---- one process, all devices: distributed device-resident matrices ----------------------------------
+ * The reference's multi-core entry is a C function (mzd_mul_mp, m4ri/mp.c:158-297), so the multi-GPU schedules sit
+ * behind this boundary.  A m4ri_amd_dmat is a matrix spread over the configured devices (m4ri_amd_set_devices) and
+ * resident in HBM; products leave their result distributed, so they chain without PCIe traffic.  Layouts (every
+ * dimension zero-padded to 256 bits in the local buffers, one row stride for all layouts of a matrix):
+ *   ROWS        rank r holds rows [r k, (r+1) k), k = ceil(rows / W)            -- the row-slab schedule
+ *   CYCLIC1/2   slab-cyclic over the 2 / 4 row blocks of 1 / 2 Strassen-Winograd levels (above)
+ *   REPLICATED  every rank holds the whole matrix (a B that needs no gather)
+ * Schedules (m4ri_amd_dmat_mul, `variant`): M4RI_AMD_VARIANT_SLABS -- C_r = A_r * B, B's row slabs gathered by peer
+ * copies under the product with the rank's own slab (no reduction; SURVEY.md 8e "rectangular"); M4RI_AMD_VARIANT_STRASSEN
+ * -- the sub-products of the top Strassen level(s), operand and result slabs pulled by hipMemcpyPeerAsync on copy streams
+ * under the products (row chunks).  0 = by the operands' layout, else by shape and world size
+ * (m4ri_amd_multi_default_variant: slabs up to 4 ranks and for every product a Strassen level cannot help, e.g.
+ * 131072 x 8192 x 131072).  One host thread per rank issues the work; all calls but _mul are blocking, _mul is
+ * asynchronous (m4ri_amd_multi_sync).  Return 0 or a hipError_t value unless noted. */
+enum { M4RI_AMD_LAYOUT_ROWS = 0, M4RI_AMD_LAYOUT_CYCLIC1 = 1, M4RI_AMD_LAYOUT_CYCLIC2 = 2, M4RI_AMD_LAYOUT_REPLICATED = 3 };
+enum { M4RI_AMD_VARIANT_AUTO = 0, M4RI_AMD_VARIANT_SLABS = 1, M4RI_AMD_VARIANT_STRASSEN = 2 };
+typedef struct m4ri_amd_dmat m4ri_amd_dmat;
+typedef struct m4ri_amd_dmat_info_t {
+  int64_t rows, ncols, stride;  /* stride: words of a local row */
+  int32_t layout, world, alive; /* alive == 0: the device list changed since the matrix was made -- only _free is valid */
+} m4ri_amd_dmat_info_t;
+m4ri_amd_dmat *m4ri_amd_dmat_create(int64_t rows, int64_t ncols, int layout);  /* zero matrix; NULL on failure */
+void m4ri_amd_dmat_free(m4ri_amd_dmat *d);
+int m4ri_amd_dmat_info(const m4ri_amd_dmat *d, m4ri_amd_dmat_info_t *out);
+/* device pointer, rows (padding included) and HIP device of rank `rank`'s local buffer */
+int m4ri_amd_dmat_local(const m4ri_amd_dmat *d, int rank, word **data, int64_t *local_rows, int *device);
+int m4ri_amd_dmat_fill(m4ri_amd_dmat *d, uint64_t seed);                /* the matrix m4ri_amd_fill_dev(seed) fills, distributed */
+int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M);             /* every device its own rows over its own PCIe link */
+int m4ri_amd_dmat_download(const m4ri_amd_dmat *d, mzd_t *M);           /* a windowed M keeps the bits outside its columns */
+int m4ri_amd_dmat_convert(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src); /* dst <- src, any two layouts (ROWS -> REPLICATED = all-gather) */
+int m4ri_amd_dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant);
+int m4ri_amd_multi_sync(void);
+/* what the most recent m4ri_amd_dmat_mul / m4ri_amd_mul_multi / mzd_mul_mp did */
+typedef struct m4ri_amd_multi_stats {
+  int32_t world, variant, levels, sub_products; /* variant: M4RI_AMD_VARIANT_*; levels / sub_products: Strassen schedule   */
+  int32_t chunks, overlap, converted;           /* row chunks per sub-product; slabs: gather under the first product;       */
+  int32_t reserved;                             /* operands converted to the schedule's layout first (0 on the fast path)   */
+  int64_t m, l, n;
+  double link_bytes;                            /* bytes that crossed between ranks                                          */
+} m4ri_amd_multi_stats;
+int m4ri_amd_multi_get_stats(m4ri_amd_multi_stats *out);
+/* Marks of rank `rank`'s part of the most recent m4ri_amd_dmat_mul, ms after its compute stream entered the operation
+ * (synchronises first).  Strassen: down pass done; per unit (round, row chunk): operands in, product done; result slabs
+ * in; up pass done.  Slabs: gather done; first product done; all done.  Returns the number of marks, < 0 on error. */
+int m4ri_amd_multi_timeline(int rank, double *ms, int cap);
+/* Pure host arithmetic (no GPU needed): the schedule a product takes, the layout that schedule wants, and the geometry
+ * of a layout -- rows of rank `rank`'s local buffer; its runs of valid global rows (global first row, rows, local first
+ * row; returns their number, at most 4). */
+int m4ri_amd_multi_default_variant(int world, int64_t m, int64_t l, int64_t n);
+int m4ri_amd_multi_layout_for(int variant, int world, int64_t m, int64_t l, int64_t n);
+int64_t m4ri_amd_layout_local_rows(int layout, int world, int rank, int64_t rows);
+int m4ri_amd_layout_runs(int layout, int world, int rank, int64_t rows, int64_t *g0, int64_t *nrows, int64_t *l0, int cap);
+/* Force a schedule for m4ri_amd_mul_multi / mzd_mul_mp and for m4ri_amd_dmat_mul on operands whose layouts fit none
+ * (0 automatic, M4RI_AMD_VARIANT_SLABS, M4RI_AMD_VARIANT_STRASSEN); returns the previous value, others only query. */
+int m4ri_amd_set_multi_variant(int variant);
+/* One process, several devices, HOST matrices: C (+)= A*B = upload into distributed temporaries (kept between calls) +
+ * m4ri_amd_dmat_mul + download.  levels: 0 = automatic schedule (above), 1 / 2 = the Strassen schedule with that many
+ * sharded levels.  What mzd_mul_mp / mzd_addmul_mp run for large products.  Returns 0 or a hipError_t value. */
 int m4ri_amd_mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int add, int cutoff, int levels);
-/* The devices mzd_mul_mp / m4ri_amd_mul_multi spread a product over.  Default: the comma-separated list in
- * the environment variable M4RI_AMD_DEVICES, else every visible device.  An id may repeat (several ranks
+/* The devices mzd_mul_mp / m4ri_amd_mul_multi / the distributed matrices are spread over.  Default: the comma-separated
+ * list in the environment variable M4RI_AMD_DEVICES, else every visible device.  An id may repeat (several ranks
  * on one GPU: how the tests exercise the path on a one-GPU box).  n == 0 restores the default. */
 int m4ri_amd_set_devices(int n, const int *ids);
 int m4ri_amd_get_device_list(int *ids, int cap);

@@ -65,6 +65,25 @@ class Stats(ctypes.Structure):
     ]
 
 
+class DmatInfo(ctypes.Structure):
+    """m4ri_amd_dmat_info_t."""
+
+    _fields_ = [("rows", ctypes.c_int64), ("ncols", ctypes.c_int64), ("stride", ctypes.c_int64),
+                ("layout", ctypes.c_int32), ("world", ctypes.c_int32), ("alive", ctypes.c_int32)]
+
+
+class MultiStats(ctypes.Structure):
+    """m4ri_amd_multi_stats."""
+
+    _fields_ = [("world", ctypes.c_int32), ("variant", ctypes.c_int32), ("levels", ctypes.c_int32), ("sub_products", ctypes.c_int32),
+                ("chunks", ctypes.c_int32), ("overlap", ctypes.c_int32), ("converted", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("m", ctypes.c_int64), ("l", ctypes.c_int64), ("n", ctypes.c_int64), ("link_bytes", ctypes.c_double)]
+
+
+(LAYOUT_ROWS, LAYOUT_CYCLIC1, LAYOUT_CYCLIC2, LAYOUT_REPLICATED) = range(4)
+(VARIANT_AUTO, VARIANT_SLABS, VARIANT_STRASSEN) = range(3)
+VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_SLABS: "slabs", VARIANT_STRASSEN: "strassen"}
+
 # every symbol include/m4ri_amd.h declares, with its ctypes signature
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -187,6 +206,23 @@ SYMBOLS = {
     "m4ri_amd_get_device_list": (_I, [ctypes.POINTER(_I), _I]),
     "m4ri_amd_set_multi_threshold": (_I64, [_I64]),
     "m4ri_amd_release_workspace": (None, []),
+    "m4ri_amd_dmat_create": (_P, [_I64, _I64, _I]),
+    "m4ri_amd_dmat_free": (None, [_P]),
+    "m4ri_amd_dmat_info": (_I, [_P, ctypes.POINTER(DmatInfo)]),
+    "m4ri_amd_dmat_local": (_I, [_P, _I, ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I)]),
+    "m4ri_amd_dmat_fill": (_I, [_P, ctypes.c_uint64]),
+    "m4ri_amd_dmat_upload": (_I, [_P, MzdPtr]),
+    "m4ri_amd_dmat_download": (_I, [_P, MzdPtr]),
+    "m4ri_amd_dmat_convert": (_I, [_P, _P]),
+    "m4ri_amd_dmat_mul": (_I, [_P, _P, _P, _I, _I, _I]),
+    "m4ri_amd_multi_sync": (_I, []),
+    "m4ri_amd_multi_get_stats": (_I, [ctypes.POINTER(MultiStats)]),
+    "m4ri_amd_multi_timeline": (_I, [_I, ctypes.POINTER(ctypes.c_double), _I]),
+    "m4ri_amd_multi_default_variant": (_I, [_I, _I64, _I64, _I64]),
+    "m4ri_amd_multi_layout_for": (_I, [_I, _I, _I64, _I64, _I64]),
+    "m4ri_amd_layout_local_rows": (_I64, [_I, _I, _I, _I64]),
+    "m4ri_amd_layout_runs": (_I, [_I, _I, _I, _I64, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), _I]),
+    "m4ri_amd_set_multi_variant": (_I, [_I]),
 }
 
 
@@ -482,6 +518,100 @@ def set_multi_threshold(min_dim: int) -> int:
 
 
 # ---- residency (include/m4ri_amd.h part 3) --------------------------------------------------------
+class Dmat:
+    """A matrix distributed over the configured devices and resident in HBM (m4ri_amd_dmat, include/m4ri_amd.h part 4)."""
+
+    def __init__(self, rows: int, ncols: int, layout: int = LAYOUT_ROWS):
+        self.h = lib().m4ri_amd_dmat_create(rows, ncols, layout)
+        if not self.h:
+            raise RuntimeError(f"m4ri_amd_dmat_create({rows}, {ncols}, {layout}) failed")
+        self.rows, self.ncols, self.layout = rows, ncols, layout
+
+    def free(self):
+        if self.h:
+            lib().m4ri_amd_dmat_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def info(self) -> DmatInfo:
+        out = DmatInfo()
+        _check(lib().m4ri_amd_dmat_info(self.h, ctypes.byref(out)), "m4ri_amd_dmat_info")
+        return out
+
+    def local(self, rank: int):
+        """(device pointer, rows incl. padding, HIP device) of rank `rank`'s local buffer."""
+        ptr, rows, dev = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int()
+        _check(lib().m4ri_amd_dmat_local(self.h, rank, ctypes.byref(ptr), ctypes.byref(rows), ctypes.byref(dev)), "m4ri_amd_dmat_local")
+        return ptr.value, rows.value, dev.value
+
+    def fill(self, seed: int) -> "Dmat":
+        _check(lib().m4ri_amd_dmat_fill(self.h, seed), "m4ri_amd_dmat_fill")
+        return self
+
+    def upload(self, M: Mzd) -> "Dmat":
+        _check(lib().m4ri_amd_dmat_upload(self.h, M.ptr), "m4ri_amd_dmat_upload")
+        return self
+
+    def download(self, M: Mzd = None) -> Mzd:
+        M = M if M is not None else Mzd(self.rows, self.ncols)
+        _check(lib().m4ri_amd_dmat_download(self.h, M.ptr), "m4ri_amd_dmat_download")
+        return M
+
+    def convert_from(self, src: "Dmat") -> "Dmat":
+        _check(lib().m4ri_amd_dmat_convert(self.h, src.h), "m4ri_amd_dmat_convert")
+        return self
+
+
+def dmat_mul(C: Dmat, A: Dmat, B: Dmat, add: bool = False, cutoff: int = 0, variant: int = VARIANT_AUTO) -> Dmat:
+    """C (+)= A*B on distributed operands; asynchronous (multi_sync)."""
+    _check(lib().m4ri_amd_dmat_mul(C.h, A.h, B.h, int(add), cutoff, variant), "m4ri_amd_dmat_mul")
+    return C
+
+
+def multi_sync() -> None:
+    _check(lib().m4ri_amd_multi_sync(), "m4ri_amd_multi_sync")
+
+
+def multi_stats() -> MultiStats:
+    out = MultiStats()
+    _check(lib().m4ri_amd_multi_get_stats(ctypes.byref(out)), "m4ri_amd_multi_get_stats")
+    return out
+
+
+def multi_timeline(rank: int, cap: int = 256) -> list:
+    buf = (ctypes.c_double * cap)()
+    n = lib().m4ri_amd_multi_timeline(rank, buf, cap)
+    if n < 0:
+        raise RuntimeError("m4ri_amd_multi_timeline failed")
+    return [buf[i] for i in range(n)]
+
+
+def multi_default_variant(world: int, m: int, l: int, n: int) -> int:
+    return lib().m4ri_amd_multi_default_variant(world, m, l, n)
+
+
+def multi_layout_for(variant: int, world: int, m: int, l: int, n: int) -> int:
+    return lib().m4ri_amd_multi_layout_for(variant, world, m, l, n)
+
+
+def layout_runs(layout: int, world: int, rank: int, rows: int) -> list:
+    """[(global first row, rows, local first row)] of the valid rows rank `rank` holds."""
+    g0, nr, l0 = (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 4)()
+    n = lib().m4ri_amd_layout_runs(layout, world, rank, rows, g0, nr, l0, 4)
+    if n < 0:
+        raise ValueError("m4ri_amd_layout_runs: bad arguments")
+    return [(g0[i], nr[i], l0[i]) for i in range(n)]
+
+
+def set_multi_variant(variant: int) -> int:
+    return lib().m4ri_amd_set_multi_variant(variant)
+
+
 def pin(M: Mzd) -> None:
     """Keep a device copy of M (which must own its block); products then read it, and windows into it,
     in place and leave results there.  The host copy is stale after a product wrote into it until sync()."""

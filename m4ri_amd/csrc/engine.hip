@@ -111,22 +111,29 @@ struct Engine {
   hipStream_t last_stream = nullptr;  // stream of the previous product: the workspace is shared, so a product
   hipEvent_t last_done    = nullptr;  // on ANOTHER stream first waits for this event (recorded after every product)
   bool have_last          = false;
+  std::mutex mu;                      // one host thread at a time plans on this device's workspace; other devices do not wait
 };
 
-std::mutex g_mu;
+std::mutex g_cfg_mu;  // the process-wide knobs (workspace budget, fuse depth)
 Engine g_engines[NUM_DEVICES_MAX];
 
-Engine *engine_for_current_device() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NUM_DEVICES_MAX) return nullptr;
-  Engine *e = &g_engines[dev];
-  e->device = dev;
-  if (e->cus == 0) {
-    int n = 0;
-    e->cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+// the engine of the calling thread's device, locked: host threads issuing on DIFFERENT devices (the ranks of multi.hip) run
+// side by side, threads on one device take turns
+struct EngineLock {
+  Engine *e = nullptr;
+  std::unique_lock<std::mutex> lk;
+  EngineLock() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NUM_DEVICES_MAX) return;
+    e  = &g_engines[dev];
+    lk = std::unique_lock<std::mutex>(e->mu);
+    e->device = dev;
+    if (e->cus == 0) {
+      int n = 0;
+      e->cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
   }
-  return e;
-}
+};
 
 int ws_reserve(Engine *e, size_t words) {
   e->ws_used = 0;
@@ -694,16 +701,15 @@ int m4ri_amd_device_count(void) {
 }
 
 int m4ri_amd_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
   HIPTRY(hipSetDevice(device));
-  Engine *e = engine_for_current_device();
-  return e ? 0 : (int)hipErrorInvalidDevice;
+  EngineLock el;
+  return el.e ? 0 : (int)hipErrorInvalidDevice;
 }
 
 int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                      int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int cutoff, void *stream) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e || cutoff < 0 || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
   if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
@@ -715,8 +721,8 @@ int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride,
 
 int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                       int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit, void *stream) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e || m < 0 || l < 0 || n < 0) return (int)hipErrorInvalidValue;
   reset_stats(e);
   if (int rc = order_after_previous(e, (hipStream_t)stream)) return rc;
@@ -730,8 +736,8 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
 // trsm.hip), where one launch per product costs more than the product.
 int m4ri_amd_m4rm_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
                             int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, void *stream) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e || m < 0 || l < 0 || n < 0 || batch < 0) return (int)hipErrorInvalidValue;
   if (batch == 0 || m == 0 || n == 0) return 0;
   reset_stats(e);
@@ -764,22 +770,22 @@ int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {  // pure
 }
 
 int64_t m4ri_amd_set_workspace_budget(int64_t bytes) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_cfg_mu);
   const int64_t old = g_ws_budget;
   if (bytes >= 0) g_ws_budget = bytes;
   return old;
 }
 
 int m4ri_amd_set_max_fuse(int levels) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_cfg_mu);
   const int old = g_max_fuse;
   if (levels >= 1 && levels <= 3) g_max_fuse = levels;
   return old;
 }
 
 void m4ri_amd_set_profiling(int on) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e) return;
   for (auto &pr : e->pending) { e->event_pool.push_back(pr.e0); e->event_pool.push_back(pr.e1); }
   e->pending.clear();
@@ -788,8 +794,8 @@ void m4ri_amd_set_profiling(int on) {
 }
 
 int m4ri_amd_get_stats(m4ri_amd_stats *out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e || !out) return (int)hipErrorInvalidValue;
   if (!e->pending.empty()) {
     HIPTRY(hipEventSynchronize(e->pending.back().e1));
@@ -816,8 +822,8 @@ void gf2_release_multi(void);    // multi.hip: the per-rank arenas of the multi-
 void m4ri_amd_release_workspace(void) {
   gf2_release_staging();
   gf2_release_multi();
-  std::lock_guard<std::mutex> lk(g_mu);
-  Engine *e = engine_for_current_device();
+  EngineLock el;
+  Engine *e = el.e;
   if (!e || !e->ws) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(e->ws);

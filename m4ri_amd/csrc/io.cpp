@@ -155,7 +155,7 @@ mzd_t *mzd_from_jcf(const char *fn, int verbose) {
     if (verbose) printf("Expected p==2 but found p==%d\n", (int)modulus);
     return NULL;
   }
-  if (nrows < 0 || ncols < 0 || nrows > 0x7fffffffLL || ncols > 0x7fffffffLL) {
+  if (nrows < 0 || ncols < 0 || nrows > 0x7fffffffLL || ncols > 0x7fffffffLL || entries < 0) {
     if (verbose) printf("File '%s' does not seem to be in JCF format.", fn);
     return NULL;
   }
@@ -165,11 +165,10 @@ mzd_t *mzd_from_jcf(const char *fn, int verbose) {
   mzd_t *A      = new_matrix((rci_t)nrows, (rci_t)ncols);
   long long row = -1;  // no row is open until the first negative index
   for (long long token; in.next(token);) {
-    if (token < 0) {
-      ++row;
-      token = -token;
-    }
-    const long long col = token - 1;
+    if (token < 0) ++row;
+    // an index the matrix cannot hold (strtoll saturates on overflow: LLONG_MIN must not be negated) is out of range as it stands
+    const bool representable = token >= -0x7fffffffLL && token <= 0x7fffffffLL;
+    const long long col      = representable ? (token < 0 ? -token : token) - 1 : 0x7fffffffLL;
     if (row < 0 || row >= nrows || col < 0 || col >= ncols)
       die("trying to write to (%d,%d) in %d x %d matrix\n", (int)row, (int)col, (int)nrows, (int)ncols);
     write_bit(A, (rci_t)row, (rci_t)col, 1);

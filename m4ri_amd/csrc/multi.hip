@@ -24,13 +24,18 @@
 // Two front ends over one plan (m4ri_amd_shard_plan, pure host arithmetic, exported):
 //   * the per-rank device API (m4ri_amd_shard_down_dev / _up_dev + the piece table): one process per
 //     GPU moves the pieces itself -- bench.py does it with RCCL send/recv via torch.distributed;
-//   * m4ri_amd_mul_multi / mzd_mul_mp: one process, all devices, host mzd_t in and out; every device
-//     uploads and downloads its own slabs (W PCIe links in parallel) and pieces move by
-//     hipMemcpyPeerAsync.
+//   * ONE process, all devices (the second half of this file): distributed device-resident matrices
+//     (m4ri_amd_dmat), m4ri_amd_dmat_mul with the row-slab and the Strassen-sharded schedule, pieces
+//     pulled by hipMemcpyPeerAsync on per-device copy streams under the products; mzd_mul_mp /
+//     m4ri_amd_mul_multi on host mzd_t = upload + that + download.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -165,26 +170,144 @@ int m4ri_amd_shard_up_dev(const m4ri_amd_shard_plan *p, int rank, const word *sl
 
 }  // extern "C"
 
-// ================================ one process, all devices, host mzd_t ==============================
+// ================================ one process, all devices ==========================================
+// The reference's multi-core entry is a C function (mzd_mul_mp, m4ri/mp.c:158-297, mp.h:47,62), so the multi-GPU schedules
+// live here, behind the C boundary, on DISTRIBUTED, DEVICE-RESIDENT operands:
+//
+//   m4ri_amd_dmat      a matrix spread over the configured devices (m4ri_amd_set_devices) in one of three layouts --
+//                      ROWS (rank r holds rows [r k, (r+1) k), k = ceil(rows / W)), CYCLIC1 / CYCLIC2 (slab-cyclic over the 2 / 4
+//                      row blocks of 1 / 2 Strassen-Winograd levels, see the top of this file), REPLICATED (every rank holds it
+//                      all).  Every dimension is zero-padded to a multiple of 256 bits in the local buffers, so all layouts of
+//                      one matrix share ONE row stride and every piece that ever crosses a link is a contiguous run of rows.
+//   m4ri_amd_dmat_mul  C (+)= A*B on such operands, the result left distributed: products chain with no PCIe traffic.  Two
+//                      schedules, chosen by shape and world size like sharding.default_variant (m4ri_amd_multi_default_variant):
+//                        * row slabs: C_r = A_r * B with B's row slabs all-gathered by peer copies on a copy stream while the
+//                          product with the rank's OWN slab of B runs (no reduction; the reference's own row parallelism,
+//                          m4ri/brilliantrussian.c:1121-1123; BASELINE configs[4] takes this at every world size);
+//                        * Strassen sub-products: local down pass, slabs of the 7 / 49 sub-product operands pulled by their
+//                          owners (hipMemcpyPeerAsync on the owner's inbound stream), the sub-products in row chunks so that
+//                          a chunk's operands and the previous chunk's results travel under the multiplications, result slabs
+//                          pulled back by their holders on a third stream, local up pass.
+//                      One host thread per rank issues that rank's work (a persistent pool: the host posts a step in
+//                      parallel, nothing in Python); cross-rank dependencies are HIP events, made safe to wait on by host
+//                      flags that say "recorded".  Asynchronous: m4ri_amd_multi_sync() waits for the devices.
+//   mzd_mul_mp / m4ri_amd_mul_multi on host matrices = upload (every device its own rows over its own PCIe link) + that +
+//   download.
 namespace {
 
 constexpr uint8_t FLAG_WINDOW = 0x4;  // mzd.h:150
+constexpr int64_t PAD_BITS   = 256;   // every dimension of a distributed matrix is padded to this in the local buffers
+constexpr int MAX_RANKS      = 64;
+
+enum Buf { B_CHILD_A = 0, B_CHILD_B, B_SLABS_P, B_OPER_A, B_OPER_B, B_PROD, B_GATHER, B_COUNT };
 
 struct Rank {
   int device         = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_down = nullptr, ev_prod = nullptr;
-  word *arena        = nullptr;
-  size_t cap         = 0;  // words
-  word *buf[9]       = {};
-  int rc             = 0;
+  hipStream_t st = nullptr, ci = nullptr, co = nullptr;  // compute; inbound copies (operands); outbound copies (result slabs)
+  // All events carry timestamps: they double as the marks of the per-phase timeline (m4ri_amd_multi_timeline)
+  hipEvent_t ev_start = nullptr, ev_down = nullptr, ev_gather = nullptr, ev_first = nullptr, ev_back = nullptr, ev_done = nullptr;
+  std::vector<hipEvent_t> ev_in, ev_prod;  // per unit (round, row chunk) of the Strassen schedule
+  bool done_recorded = false;
+  word *arena = nullptr;
+  size_t cap  = 0;  // words
+  word *buf[B_COUNT] = {};
+  std::atomic<int64_t> flag_down{0}, flag_prod{0};  // host flags: "ev_down of operation seq is recorded", "ev_prod[u] ... (seq * 4096 + u + 1)"
+  // what the last operation recorded (for the timeline)
+  int tl_units = 0;
+  bool tl_strassen = false, tl_gathered = false, tl_valid = false;
 };
 
 std::mutex g_multi_mu;
 std::vector<int> g_devices;   // the devices products are spread over (an id may repeat: "virtual" ranks)
 bool g_devices_set = false;
-std::vector<Rank> g_ranks;
+std::vector<std::unique_ptr<Rank>> g_ranks;
+uint64_t g_config_gen = 1;    // bumped whenever the ranks are rebuilt: distributed matrices of an older configuration are dead
 int64_t g_threshold = 16384;  // smallest min(m, l, n) mzd_mul_mp spreads over several devices
+int g_variant = 0;            // 0 automatic, 1 row slabs, 2 Strassen sub-products (m4ri_amd_set_multi_variant)
+int64_t g_seq = 0;            // operations issued so far
+std::atomic<int> g_abort{0};  // a worker failed: the others stop waiting for its flags
+m4ri_amd_multi_stats g_mstats = {};
+
+// ---- worker pool: thread i issues the work of rank i -------------------------------------------------
+struct Pool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  const std::function<int(int)> *job = nullptr;
+  uint64_t gen = 0;
+  int pending  = 0;
+  bool stop    = false;
+  std::vector<int> rc;
+
+  void worker(int i) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen;
+      const std::function<int(int)> *f = job;
+      lk.unlock();
+      const int r = (*f)(i);
+      lk.lock();
+      rc[(size_t)i] = r;
+      if (--pending == 0) cv_done.notify_all();
+    }
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread &t : th)
+      if (t.joinable()) t.join();
+    th.clear();
+    stop = false;
+  }
+  int start(int n) {
+    shutdown();
+    rc.assign((size_t)n, 0);
+    try {
+      for (int i = 0; i < n; ++i) th.emplace_back([this, i] { worker(i); });
+    } catch (...) {
+      shutdown();
+      return (int)hipErrorOutOfMemory;
+    }
+    return 0;
+  }
+  // every worker i runs f(i); returns the first non-zero result
+  int run(const std::function<int(int)> &f) {
+    std::unique_lock<std::mutex> lk(mu);
+    g_abort.store(0);
+    job     = &f;
+    pending = (int)th.size();
+    ++gen;
+    cv.notify_all();
+    cv_done.wait(lk, [&] { return pending == 0; });
+    job = nullptr;
+    for (int r : rc)
+      if (r) return r;
+    return 0;
+  }
+  ~Pool() { shutdown(); }
+};
+Pool g_pool;
+
+// a failure on one rank must not leave the others spinning on its flags
+#define RTRY(expr)                                     \
+  do {                                                 \
+    const int e_ = (int)(expr);                        \
+    if (e_ != 0) { g_abort.store(1); return e_; }      \
+  } while (0)
+
+int wait_flag(const std::atomic<int64_t> &f, int64_t want) {
+  for (int spins = 0; f.load(std::memory_order_acquire) < want; ++spins) {
+    if (g_abort.load(std::memory_order_relaxed)) return (int)hipErrorLaunchFailure;
+    if (spins > 64) std::this_thread::yield();
+  }
+  return 0;
+}
 
 void default_devices() {
   if (g_devices_set) return;
@@ -198,46 +321,67 @@ void default_devices() {
       g_devices.push_back((int)v);
       q = (*end == ',') ? end + 1 : end;
     }
+    // the same range m4ri_amd_set_devices accepts; a list with any id outside it is ignored as a whole
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
+    bool ok = g_devices.size() <= (size_t)MAX_RANKS;
+    for (int id : g_devices) ok = ok && id >= 0 && id < have && id < 16;
+    if (!ok) {
+      fprintf(stderr, "m4ri_amd: M4RI_AMD_DEVICES=\"%s\" names a device outside 0..%d: ignored, using every visible device\n", env, (have < 16 ? have : 16) - 1);
+      g_devices.clear();
+    }
   }
   if (g_devices.empty()) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) n = 1;
+    if (n > 16) n = 16;
     for (int d = 0; d < n; ++d) g_devices.push_back(d);
   }
 }
 
+void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks empty
+  g_pool.shutdown();
+  for (auto &rp : g_ranks) {
+    Rank &r = *rp;
+    (void)hipSetDevice(r.device);
+    if (r.st) (void)hipStreamSynchronize(r.st);
+    if (r.ci) (void)hipStreamSynchronize(r.ci);
+    if (r.co) (void)hipStreamSynchronize(r.co);
+    if (r.arena) (void)hipFree(r.arena);
+    for (hipStream_t s : {r.st, r.ci, r.co})
+      if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {r.ev_start, r.ev_down, r.ev_gather, r.ev_first, r.ev_back, r.ev_done})
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_prod) (void)hipEventDestroy(e);
+  }
+  g_ranks.clear();
+  ++g_config_gen;
+}
+
 int ensure_ranks() {
   default_devices();
-  if (g_ranks.size() == g_devices.size()) {
+  if (g_ranks.size() == g_devices.size() && !g_ranks.empty()) {
     bool same = true;
-    for (size_t i = 0; i < g_ranks.size(); ++i) same = same && g_ranks[i].device == g_devices[i];
+    for (size_t i = 0; i < g_ranks.size(); ++i) same = same && g_ranks[i]->device == g_devices[i];
     if (same) return 0;
   }
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
-  auto drop_all = [&]() {  // streams, events and arenas of every rank that has them; leaves g_ranks empty
-    for (Rank &r : g_ranks) {
-      (void)hipSetDevice(r.device);
-      if (r.arena) (void)hipFree(r.arena);
-      if (r.stream) (void)hipStreamDestroy(r.stream);
-      if (r.ev_down) (void)hipEventDestroy(r.ev_down);
-      if (r.ev_prod) (void)hipEventDestroy(r.ev_prod);
-    }
-    g_ranks.clear();
-  };
-  drop_all();
-  // a failure half way must not leave ranks that LOOK configured (same size, same ids, null streams) nor another current
-  // device behind: on any error everything made so far is dropped and the caller's device restored
+  drop_ranks();
+  // a failure half way must not leave ranks that LOOK configured nor another current device behind: on any error
+  // everything made so far is dropped and the caller's device restored
   auto build = [&]() -> int {
-    g_ranks.assign(g_devices.size(), Rank{});
-    for (size_t i = 0; i < g_ranks.size(); ++i) {
-      Rank &r  = g_ranks[i];
+    for (size_t i = 0; i < g_devices.size(); ++i) {
+      g_ranks.emplace_back(new Rank());
+      Rank &r  = *g_ranks.back();
       r.device = g_devices[i];
       HIPTRY(m4ri_amd_init(r.device));  // binds the device + creates its engine
-      HIPTRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-      HIPTRY(hipEventCreateWithFlags(&r.ev_down, hipEventDisableTiming));
-      HIPTRY(hipEventCreateWithFlags(&r.ev_prod, hipEventDisableTiming));
-      for (size_t k = 0; k < g_ranks.size(); ++k) {  // direct xGMI copies between every pair
+      HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+      HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
+      HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
+      for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done}) HIPTRY(hipEventCreate(e));
+      for (size_t k = 0; k < g_devices.size(); ++k) {  // direct xGMI copies between every pair
         const int other = g_devices[k];
         int can         = 0;
         if (other != r.device && hipDeviceCanAccessPeer(&can, r.device, other) == hipSuccess && can) {
@@ -247,159 +391,577 @@ int ensure_ranks() {
         }
       }
     }
-    return 0;
+    return g_pool.start((int)g_ranks.size());
   };
   const int rc = build();
-  if (rc) drop_all();
+  if (rc) drop_ranks();
   (void)hipSetDevice(cur);
   return rc;
 }
 
-int carve(Rank &r, const m4ri_amd_shard_plan &p, int rank) {
+int unit_events(Rank &r, size_t n) {
+  while (r.ev_in.size() < n) { hipEvent_t e; HIPTRY(hipEventCreate(&e)); r.ev_in.push_back(e); }
+  while (r.ev_prod.size() < n) { hipEvent_t e; HIPTRY(hipEventCreate(&e)); r.ev_prod.push_back(e); }
+  return 0;
+}
+
+// device-to-device copy of `words` words, between ranks (peer copy over the link of the pair) or inside a device
+int copy_words(word *dst, int dst_dev, const word *src, int src_dev, int64_t words, hipStream_t s) {
+  if (words <= 0) return 0;
+  if (dst_dev == src_dev) return (int)hipMemcpyAsync(dst, src, (size_t)words * 8, hipMemcpyDeviceToDevice, s);
+  return (int)hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, (size_t)words * 8, s);
+}
+
+// ---- layouts ---------------------------------------------------------------------------------------
+struct Run { int64_t g0, rows, l0; };  // global first row, valid rows, local first row
+
+int64_t padded(int64_t x) { return roundup(x > 0 ? x : 1, PAD_BITS); }
+int layout_levels(int layout) { return layout == M4RI_AMD_LAYOUT_CYCLIC1 ? 1 : layout == M4RI_AMD_LAYOUT_CYCLIC2 ? 2 : 0; }
+
+// rows of rank `rank`'s local buffer (padding included)
+int64_t local_rows_of(int layout, int world, int rank, int64_t rows) {
+  if (layout == M4RI_AMD_LAYOUT_REPLICATED) return rows;
+  if (layout == M4RI_AMD_LAYOUT_ROWS) return (rows + world - 1) / world;
+  const int64_t S = 1ll << layout_levels(layout), brows = padded(rows) / S;
+  return S * (cut_of(brows, world, rank + 1) - cut_of(brows, world, rank));
+}
+
+// the runs of VALID global rows rank `rank` holds, in local order
+int runs_of(int layout, int world, int rank, int64_t rows, Run *out) {
+  int n = 0;
+  if (layout == M4RI_AMD_LAYOUT_REPLICATED) {
+    if (rows > 0) out[n++] = Run{0, rows, 0};
+  } else if (layout == M4RI_AMD_LAYOUT_ROWS) {
+    const int64_t k = (rows + world - 1) / world, g0 = k * rank;
+    if (g0 < rows) out[n++] = Run{g0, (rows - g0) < k ? (rows - g0) : k, 0};
+  } else {
+    const int64_t S = 1ll << layout_levels(layout), brows = padded(rows) / S;
+    const int64_t c0 = cut_of(brows, world, rank), s = cut_of(brows, world, rank + 1) - c0;
+    for (int64_t b = 0; b < S; ++b) {
+      const int64_t g0 = b * brows + c0;
+      int64_t valid    = rows - g0;
+      if (valid > s) valid = s;
+      if (valid > 0) out[n++] = Run{g0, valid, b * s};
+    }
+  }
+  return n;
+}
+
+}  // namespace
+
+struct m4ri_amd_dmat {
+  int64_t rows = 0, ncols = 0, stride = 0;  // stride: words of a local row = padded(ncols) / 64, the same in every layout
+  int layout = 0, world = 0;
+  uint64_t config_gen = 0;
+  std::vector<int> device;
+  std::vector<word *> local;
+  std::vector<int64_t> lrows;  // rows of the local buffers
+};
+
+namespace {
+
+bool alive(const m4ri_amd_dmat *d) { return d && d->config_gen == g_config_gen && d->world == (int)g_ranks.size(); }
+
+m4ri_amd_dmat *dmat_new(int64_t rows, int64_t ncols, int layout) {  // g_multi_mu held, ranks configured
+  if (rows < 0 || ncols < 0 || layout < 0 || layout > M4RI_AMD_LAYOUT_REPLICATED) return nullptr;
+  const int W = (int)g_ranks.size();
+  std::unique_ptr<m4ri_amd_dmat> d(new m4ri_amd_dmat());
+  d->rows = rows; d->ncols = ncols; d->layout = layout; d->world = W; d->config_gen = g_config_gen;
+  d->stride = padded(ncols) / 64;
+  d->device.resize((size_t)W); d->local.assign((size_t)W, nullptr); d->lrows.resize((size_t)W);
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  bool ok = true;
+  for (int r = 0; r < W && ok; ++r) {
+    d->device[(size_t)r] = g_ranks[(size_t)r]->device;
+    d->lrows[(size_t)r]  = local_rows_of(layout, W, r, rows);
+    const size_t bytes   = (size_t)(d->lrows[(size_t)r] > 0 ? d->lrows[(size_t)r] : 1) * (size_t)d->stride * 8;
+    ok = hipSetDevice(d->device[(size_t)r]) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d->local[(size_t)r]), bytes) == hipSuccess &&
+         hipMemset(d->local[(size_t)r], 0, bytes) == hipSuccess;  // the padding is zero from here on: every operation keeps it so
+  }
+  (void)hipSetDevice(cur);
+  if (!ok) {
+    for (int r = 0; r < W; ++r)
+      if (d->local[(size_t)r]) { (void)hipSetDevice(d->device[(size_t)r]); (void)hipFree(d->local[(size_t)r]); }
+    (void)hipSetDevice(cur);
+    return nullptr;
+  }
+  return d.release();
+}
+
+void dmat_delete(m4ri_amd_dmat *d) {
+  if (!d) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (size_t r = 0; r < d->local.size(); ++r)
+    if (d->local[r]) {
+      (void)hipSetDevice(d->device[r]);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(d->local[r]);
+    }
+  (void)hipSetDevice(cur);
+  delete d;
+}
+
+// every operation starts behind the previous operation of EVERY rank (their reads of what it will overwrite, their writes of
+// what it will read) and ends with ev_done on the compute stream; the copy streams start behind ev_start
+int op_begin(Rank &R) {
+  for (auto &other : g_ranks)
+    if (other->done_recorded) HIPTRY(hipStreamWaitEvent(R.st, other->ev_done, 0));
+  HIPTRY(hipEventRecord(R.ev_start, R.st));
+  HIPTRY(hipStreamWaitEvent(R.ci, R.ev_start, 0));
+  HIPTRY(hipStreamWaitEvent(R.co, R.ev_start, 0));
+  R.tl_valid = false;
+  return 0;
+}
+int op_end(Rank &R) {
+  HIPTRY(hipEventRecord(R.ev_done, R.st));
+  return 0;
+}
+// after the pool has joined: from now on ev_done of every rank is a recorded event
+void ops_joined() {
+  for (auto &r : g_ranks) r->done_recorded = true;
+}
+
+int carve(Rank &r, const int64_t *words) {
   size_t need = 0;
-  int64_t w[9];
-  for (int k = 0; k < 9; ++k) { w[k] = pad32(m4ri_amd_shard_buffer_words(&p, rank, k)); need += (size_t)w[k]; }
+  for (int k = 0; k < B_COUNT; ++k) need += (size_t)pad32(words[k] > 0 ? words[k] : 0);
   if (need > r.cap) {
-    HIPTRY(hipStreamSynchronize(r.stream));
+    HIPTRY(hipDeviceSynchronize());
     if (r.arena) HIPTRY(hipFree(r.arena));
     r.arena = nullptr; r.cap = 0;
-    HIPTRY(hipMalloc(reinterpret_cast<void **>(&r.arena), need * 8));
+    HIPTRY(hipMalloc(reinterpret_cast<void **>(&r.arena), (need > 0 ? need : 32) * 8));
     r.cap = need;
   }
   word *q = r.arena;
-  for (int k = 0; k < 9; ++k) { r.buf[k] = q; q += w[k]; }
+  for (int k = 0; k < B_COUNT; ++k) { r.buf[k] = q; q += pad32(words[k] > 0 ? words[k] : 0); }
   return 0;
 }
 
-// host rows of M (slab-cyclic selection for `rank`) -> the zero-padded local parent on the device
-int upload_local(Rank &r, const m4ri_amd_shard_plan &p, int rank, const mzd_t *M, word *local, int64_t brows, int64_t lwidth) {
-  const int64_t c0 = cut_of(brows, p.world, rank), s = cut_of(brows, p.world, rank + 1) - c0;
-  if (s == 0) return 0;
-  HIPTRY(hipMemsetAsync(local, 0, (size_t)(p.blocks * s * lwidth) * 8, r.stream));
-  for (int b = 0; b < p.blocks; ++b) {
-    const int64_t g0 = (int64_t)b * brows + c0;
-    int64_t rows     = (int64_t)M->nrows - g0;
-    if (rows > s) rows = s;
-    if (rows <= 0 || M->width == 0) continue;
-    HIPTRY(hipMemcpy2DAsync(local + (int64_t)b * s * lwidth, (size_t)lwidth * 8, M->data + g0 * M->rowstride, (size_t)M->rowstride * 8,
-                            (size_t)M->width * 8, (size_t)rows, hipMemcpyHostToDevice, r.stream));
+// ---- redistribution: dst <- src, any two layouts of one shape (also the all-gather: ROWS -> REPLICATED) --------------
+int redistribute_rank(const m4ri_amd_dmat *dst, const m4ri_amd_dmat *src, int me) {
+  Rank &R = *g_ranks[(size_t)me];
+  RTRY(hipSetDevice(R.device));
+  RTRY(op_begin(R));
+  const int W = dst->world;
+  Run dr[4], sr[4];
+  const int nd = runs_of(dst->layout, W, me, dst->rows, dr);
+  for (int i = 0; i < nd; ++i) {
+    // walk the source holders starting at this rank: a replicated source is read locally, slabs spread over the links
+    for (int k = 0; k < W; ++k) {
+      const int s  = (me + k) % W;
+      const int ns = runs_of(src->layout, W, s, src->rows, sr);
+      for (int j = 0; j < ns; ++j) {
+        const int64_t lo = dr[i].g0 > sr[j].g0 ? dr[i].g0 : sr[j].g0;
+        const int64_t hi = (dr[i].g0 + dr[i].rows) < (sr[j].g0 + sr[j].rows) ? (dr[i].g0 + dr[i].rows) : (sr[j].g0 + sr[j].rows);
+        if (hi <= lo) continue;
+        RTRY(copy_words(dst->local[(size_t)me] + (dr[i].l0 + lo - dr[i].g0) * dst->stride, R.device,
+                        src->local[(size_t)s] + (sr[j].l0 + lo - sr[j].g0) * src->stride, src->device[(size_t)s], (hi - lo) * dst->stride, R.st));
+      }
+      if (src->layout == M4RI_AMD_LAYOUT_REPLICATED) break;  // the first holder had everything
+    }
   }
-  // a window's last word carries its parent's neighbouring columns (mzd.h:117-123): zero them
-  HIPTRY(gf2_launch_mask_tail(r.stream, local, lwidth, p.blocks * s, M->ncols));
+  return op_end(R);
+}
+
+int redistribute(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src) {
+  if (!alive(dst) || !alive(src) || dst->rows != src->rows || dst->ncols != src->ncols) return (int)hipErrorInvalidValue;
+  if (dst == src) return 0;
+  const int rc = g_pool.run([&](int me) { return redistribute_rank(dst, src, me); });
+  ops_joined();
+  return rc;
+}
+
+// ---- schedule 1: row slabs -----------------------------------------------------------------------------
+// C_r (+)= A_r * B.  A and C in ROWS layout; B in ROWS layout (gathered here, the gather under the product with the own
+// slab) or REPLICATED (nothing to move).
+struct SlabOp {
+  m4ri_amd_dmat *C; const m4ri_amd_dmat *A, *B;
+  int add, cutoff;
+  bool overlap;
+};
+
+int slabs_rank(const SlabOp &op, int me) {
+  Rank &R = *g_ranks[(size_t)me];
+  RTRY(hipSetDevice(R.device));
+  const int W      = op.A->world;
+  const int64_t l  = op.A->ncols, n = op.B->ncols, m = op.A->rows;
+  const int64_t ka = (m + W - 1) / W, kb = (l + W - 1) / W;
+  const int64_t r0 = ka * me < m ? ka * me : m, mr = (m - r0) < ka ? (m - r0) : ka;  // my rows of A and C
+  const int64_t sa = op.A->stride, sbw = op.B->stride, sc = op.C->stride;
+  int64_t words[B_COUNT] = {};
+  const bool gathered = op.B->layout == M4RI_AMD_LAYOUT_ROWS;
+  if (gathered) words[B_GATHER] = (int64_t)W * kb * sbw;
+  RTRY(carve(R, words));
+  RTRY(op_begin(R));
+  word *Cme = op.C->local[(size_t)me];
+  const word *Ame = op.A->local[(size_t)me];
+  R.tl_strassen = false; R.tl_gathered = gathered; R.tl_units = 0;
+  if (!gathered) {
+    if (mr > 0) RTRY(m4ri_amd_mul_dev(Cme, sc, Ame, sa, op.B->local[(size_t)me], sbw, mr, l, n, op.add, op.cutoff, R.st));
+    RTRY(hipEventRecord(R.ev_first, R.st));
+    RTRY(hipEventRecord(R.ev_gather, R.ci));
+    R.tl_valid = true;
+    return op_end(R);
+  }
+  word *Bfull      = R.buf[B_GATHER];
+  const int64_t k0 = kb * me < l ? kb * me : l, k1 = (k0 + kb) < l ? (k0 + kb) : l;  // my rows of B
+  // the ONE exchange of the schedule: the other ranks' slabs of B, pulled over the link of each pair on the inbound stream,
+  // nearest neighbour first so that the W - 1 links of a rank are all in use
+  for (int k = op.overlap ? 1 : 0; k < W; ++k) {
+    const int s      = (me + k) % W;
+    const int64_t g0 = kb * s < l ? kb * s : l, g1 = (g0 + kb) < l ? (g0 + kb) : l;
+    if (g1 > g0) RTRY(copy_words(Bfull + g0 * sbw, R.device, op.B->local[(size_t)s], op.B->device[(size_t)s], (g1 - g0) * sbw, R.ci));
+  }
+  RTRY(hipEventRecord(R.ev_gather, R.ci));
+  if (op.overlap) {
+    // own slab first (resident: nothing to wait for), then what lies before and after it in the gathered B
+    bool first = true;
+    if (mr > 0 && k1 > k0) {
+      RTRY(m4ri_amd_mul_dev(Cme, sc, Ame + k0 / 64, sa, op.B->local[(size_t)me], sbw, mr, k1 - k0, n, op.add, op.cutoff, R.st));
+      first = false;
+    }
+    RTRY(hipEventRecord(R.ev_first, R.st));
+    RTRY(hipStreamWaitEvent(R.st, R.ev_gather, 0));
+    if (mr > 0 && k0 > 0) {
+      RTRY(m4ri_amd_mul_dev(Cme, sc, Ame, sa, Bfull, sbw, mr, k0, n, (op.add || !first) ? 1 : 0, op.cutoff, R.st));
+      first = false;
+    }
+    if (mr > 0 && l > k1) {
+      RTRY(m4ri_amd_mul_dev(Cme, sc, Ame + k1 / 64, sa, Bfull + k1 * sbw, sbw, mr, l - k1, n, (op.add || !first) ? 1 : 0, op.cutoff, R.st));
+      first = false;
+    }
+    if (mr > 0 && first && !op.add) RTRY(hipMemsetAsync(Cme, 0, (size_t)mr * (size_t)sc * 8, R.st));  // l == 0
+  } else {
+    RTRY(hipEventRecord(R.ev_first, R.st));
+    RTRY(hipStreamWaitEvent(R.st, R.ev_gather, 0));
+    if (mr > 0) RTRY(m4ri_amd_mul_dev(Cme, sc, Ame, sa, Bfull, sbw, mr, l, n, op.add, op.cutoff, R.st));
+  }
+  R.tl_valid = true;
+  return op_end(R);
+}
+
+// ---- schedule 2: the sub-products of the top Strassen-Winograd level(s) ------------------------------------------
+struct StrassenOp {
+  m4ri_amd_dmat *C; const m4ri_amd_dmat *A, *B;
+  m4ri_amd_shard_plan p;
+  int add, cutoff, chunks;
+  int64_t seq;
+};
+
+// row chunk c of a sub-product = the slabs of ranks [lo, hi): rows [cut(lo), cut(hi)) of its A operand and of its result
+void chunk_of(const StrassenOp &op, int c, int *lo, int *hi) {
+  *lo = op.p.world * c / op.chunks;
+  *hi = op.p.world * (c + 1) / op.chunks;
+}
+
+int strassen_rank(const StrassenOp &op, int me) {
+  Rank &R = *g_ranks[(size_t)me];
+  RTRY(hipSetDevice(R.device));
+  const m4ri_amd_shard_plan &p = op.p;
+  const int W = p.world, nch = op.chunks, rounds = (p.nprod + W - 1) / W;
+  int64_t words[B_COUNT] = {};
+  words[B_CHILD_A] = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_CHILD_A);
+  words[B_CHILD_B] = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_CHILD_B);
+  words[B_SLABS_P] = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_SLABS_P);
+  words[B_OPER_A]  = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_OPER_A);
+  words[B_OPER_B]  = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_OPER_B);
+  words[B_PROD]    = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_PROD);
+  RTRY(carve(R, words));
+  RTRY(unit_events(R, (size_t)rounds * (size_t)nch));
+  RTRY(op_begin(R));
+  R.tl_strassen = true; R.tl_gathered = false; R.tl_units = 0;
+  // 1. the level's operand additions on my slabs: no communication
+  RTRY(m4ri_amd_shard_down_dev(&p, me, op.A->local[(size_t)me], op.A->stride, op.B->local[(size_t)me], op.B->stride, R.buf[B_CHILD_A], R.buf[B_CHILD_B], R.st));
+  RTRY(hipEventRecord(R.ev_down, R.st));
+  R.flag_down.store(op.seq, std::memory_order_release);
+  // 2. my sub-products, round by round, row chunk by row chunk: the chunk's operand slabs are pulled on the inbound stream
+  //    (every holder's down pass is a HIP event; its host flag says the event is recorded), so chunk c + 1 travels while chunk
+  //    c is multiplied
+  bool waited[MAX_RANKS] = {};
+  auto pull_operand = [&](int side, int j, int r) -> int {
+    m4ri_amd_shard_piece pc;
+    m4ri_amd_shard_piece_of(&p, side, j, r, &pc);
+    if (pc.words == 0) return 0;
+    Rank &H = *g_ranks[(size_t)r];
+    if (!waited[r]) {
+      if (int e = wait_flag(H.flag_down, op.seq)) return e;
+      HIPTRY(hipStreamWaitEvent(R.ci, H.ev_down, 0));
+      waited[r] = true;
+    }
+    return copy_words(R.buf[side ? B_OPER_B : B_OPER_A] + pc.owner_off, R.device, H.buf[side ? B_CHILD_B : B_CHILD_A] + pc.holder_off, H.device, pc.words, R.ci);
+  };
+  int units = 0;
+  for (int q = 0; q < rounds; ++q) {
+    const int j = q * W + me;
+    if (j >= p.nprod) break;
+    for (int c = 0; c < nch; ++c, ++units) {
+      int lo, hi;
+      chunk_of(op, c, &lo, &hi);
+      if (c == 0)
+        for (int k = 0; k < W; ++k) RTRY(pull_operand(1, j, (me + k) % W));  // the whole B operand, own slab first
+      for (int r = lo; r < hi; ++r) RTRY(pull_operand(0, j, r));
+      RTRY(hipEventRecord(R.ev_in[(size_t)units], R.ci));
+      RTRY(hipStreamWaitEvent(R.st, R.ev_in[(size_t)units], 0));
+      const int64_t row0 = cut_of(p.bm, W, lo), rows = cut_of(p.bm, W, hi) - row0;
+      if (rows > 0)
+        RTRY(m4ri_amd_mul_dev(R.buf[B_PROD] + ((int64_t)q * p.bm + row0) * p.cwn, p.cwn, R.buf[B_OPER_A] + ((int64_t)q * p.bm + row0) * p.cwl, p.cwl,
+                              R.buf[B_OPER_B] + (int64_t)q * p.bl * p.cwn, p.cwn, rows, p.bl, p.cwn * 64, 0, op.cutoff, R.st));
+      RTRY(hipEventRecord(R.ev_prod[(size_t)units], R.st));
+      R.flag_prod.store(op.seq * 4096 + units + 1, std::memory_order_release);
+    }
+  }
+  R.tl_units = units;
+  // 3. my slab of every product, pulled from its owner on the outbound stream as soon as the chunk that holds it is done,
+  //    then the level's result additions on my slabs
+  int myc = 0;
+  for (int c = 0; c < nch; ++c) {
+    int lo, hi;
+    chunk_of(op, c, &lo, &hi);
+    if (me >= lo && me < hi) myc = c;
+  }
+  for (int j = 0; j < p.nprod; ++j) {
+    m4ri_amd_shard_piece pc;
+    m4ri_amd_shard_piece_of(&p, 2, j, me, &pc);
+    if (pc.words == 0) continue;
+    Rank &O     = *g_ranks[(size_t)pc.owner];
+    const int u = (j / W) * nch + myc;
+    RTRY(wait_flag(O.flag_prod, op.seq * 4096 + u + 1));
+    RTRY(hipStreamWaitEvent(R.co, O.ev_prod[(size_t)u], 0));
+    RTRY(copy_words(R.buf[B_SLABS_P] + pc.holder_off, R.device, O.buf[B_PROD] + pc.owner_off, O.device, pc.words, R.co));
+  }
+  RTRY(hipEventRecord(R.ev_back, R.co));
+  RTRY(hipStreamWaitEvent(R.st, R.ev_back, 0));
+  RTRY(m4ri_amd_shard_up_dev(&p, me, R.buf[B_SLABS_P], op.C->local[(size_t)me], op.C->stride, op.add, R.st));
+  R.tl_valid = true;
+  return op_end(R);
+}
+
+// the plan of a product on CYCLIC-v operands: every dimension padded to 256 bits (the layouts' own padding)
+void plan_for(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n, int levels) {
+  memset(p, 0, sizeof *p);
+  p->world = world; p->levels = levels; p->blocks = 1 << levels; p->nprod = levels == 2 ? 49 : 7;
+  p->m = m; p->l = l; p->n = n;
+  p->M = padded(m); p->L = padded(l); p->N = padded(n);
+  p->bm = p->M / p->blocks; p->bl = p->L / p->blocks;
+  p->cwl = p->L / p->blocks / 64; p->cwn = p->N / p->blocks / 64;
+}
+
+// sharding.default_variant: row slabs up to 4 ranks (2 ranks share ONE link, which the Strassen exchange would saturate) and
+// for every product the single-GPU engine would not split once more in all three dimensions (engine.hip: default depth --
+// m/2 >= 4096, l/2 >= 8192, n/2 >= 4096; BASELINE.json configs[4], 131072 x 8192 x 131072, has l/2 < 8192: row slabs of A
+// and C with B replicated, no reduction); the Strassen sub-products from 5 ranks on
+int default_variant(int world, int64_t m, int64_t l, int64_t n) {
+  if (world <= 4) return M4RI_AMD_VARIANT_SLABS;
+  if (m / 2 < 4096 || l / 2 < 8192 || n / 2 < 4096) return M4RI_AMD_VARIANT_SLABS;
+  return M4RI_AMD_VARIANT_STRASSEN;
+}
+
+int auto_levels(int world, int64_t m, int64_t l, int64_t n) {
+  m4ri_amd_shard_plan p;
+  return m4ri_amd_shard_plan_make(&p, world, m, l, n, 0) ? 1 : p.levels;
+}
+
+// C (+)= A*B on distributed operands (g_multi_mu held).  Operands in another layout than the schedule's are converted
+// through temporaries (correct, not fast: keep matrices in the layout m4ri_amd_multi_layout_for names).
+int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant) {
+  if (!alive(C) || !alive(A) || !alive(B) || A->ncols != B->rows || C->rows != A->rows || C->ncols != B->ncols || cutoff < 0 || C == A || C == B)
+    return (int)hipErrorInvalidValue;
+  const int W = (int)g_ranks.size();
+  const int64_t m = A->rows, l = A->ncols, n = B->ncols;
+  if (variant == 0) {
+    // the operands' own layout decides when it fits a schedule; otherwise the shape and the world size
+    const int v = layout_levels(A->layout);
+    if (v > 0 && B->layout == A->layout && C->layout == A->layout) variant = M4RI_AMD_VARIANT_STRASSEN;
+    else if (A->layout == M4RI_AMD_LAYOUT_ROWS && C->layout == M4RI_AMD_LAYOUT_ROWS && (B->layout == M4RI_AMD_LAYOUT_ROWS || B->layout == M4RI_AMD_LAYOUT_REPLICATED))
+      variant = M4RI_AMD_VARIANT_SLABS;
+    else variant = g_variant ? g_variant : default_variant(W, m, l, n);
+  }
+  int want = M4RI_AMD_LAYOUT_ROWS;
+  if (variant == M4RI_AMD_VARIANT_STRASSEN) {
+    const int v = layout_levels(A->layout) ? layout_levels(A->layout) : layout_levels(C->layout) ? layout_levels(C->layout) : auto_levels(W, m, l, n);
+    want        = v == 2 ? M4RI_AMD_LAYOUT_CYCLIC2 : M4RI_AMD_LAYOUT_CYCLIC1;
+  }
+  // conversions
+  std::unique_ptr<m4ri_amd_dmat, void (*)(m4ri_amd_dmat *)> tA(nullptr, dmat_delete), tB(nullptr, dmat_delete), tC(nullptr, dmat_delete);
+  const m4ri_amd_dmat *a = A, *b = B;
+  m4ri_amd_dmat *c = C;
+  if (A->layout != want) {
+    tA.reset(dmat_new(m, l, want));
+    if (!tA) return (int)hipErrorOutOfMemory;
+    if (int rc = redistribute(tA.get(), A)) return rc;
+    a = tA.get();
+  }
+  if (B->layout != want && !(want == M4RI_AMD_LAYOUT_ROWS && B->layout == M4RI_AMD_LAYOUT_REPLICATED)) {
+    tB.reset(dmat_new(l, n, want));
+    if (!tB) return (int)hipErrorOutOfMemory;
+    if (int rc = redistribute(tB.get(), B)) return rc;
+    b = tB.get();
+  }
+  if (C->layout != want) {
+    tC.reset(dmat_new(m, n, want));
+    if (!tC) return (int)hipErrorOutOfMemory;
+    if (add)
+      if (int rc = redistribute(tC.get(), C)) return rc;
+    c = tC.get();
+  }
+  g_mstats = m4ri_amd_multi_stats{};
+  g_mstats.world = W; g_mstats.variant = variant; g_mstats.m = m; g_mstats.l = l; g_mstats.n = n;
+  g_mstats.converted = (tA ? 1 : 0) + (tB ? 1 : 0) + (tC ? 1 : 0);
+  int rc = 0;
+  ++g_seq;
+  if (m == 0 || n == 0) {
+    rc = 0;
+  } else if (variant == M4RI_AMD_VARIANT_SLABS) {
+    SlabOp op{c, a, b, add, cutoff, false};
+    const int64_t kb = (l + W - 1) / W;
+    // the gather under the product with the own slab: needs every slab boundary of B on a word of A's rows, and pays when a rank's
+    // own slab is a large part of the inner dimension (few ranks)
+    op.overlap = b->layout == M4RI_AMD_LAYOUT_ROWS && kb % 64 == 0 && W <= 4 && W > 1 && l > 0;
+    g_mstats.overlap    = op.overlap ? 1 : 0;
+    g_mstats.link_bytes = b->layout == M4RI_AMD_LAYOUT_ROWS ? 8.0 * (double)b->stride * (double)l * (double)(W - 1) : 0.0;
+    rc = g_pool.run([&](int me) { return slabs_rank(op, me); });
+    ops_joined();
+  } else {
+    StrassenOp op{c, a, b, {}, add, cutoff, 1, g_seq};
+    plan_for(&op.p, W, m, l, n, layout_levels(want));
+    // two ROW chunks when one product per rank is all there is to hide transfers behind and its halves keep the engine's Strassen depth
+    // (measured: two 16384 x 32768 x 32768 halves cost 1.00 - 1.03 of the whole, profiles/r03_rank_shapes_timing.log)
+    op.chunks = (op.p.levels == 1 && op.p.bm >= 4 * 4096 && W >= 2) ? 2 : 1;
+    if (const char *env = getenv("M4RI_AMD_MULTI_CHUNKS")) { const int v = atoi(env); if (v >= 1 && v <= W && v <= 16) op.chunks = v; }
+    g_mstats.levels = op.p.levels; g_mstats.sub_products = op.p.nprod; g_mstats.chunks = op.chunks;
+    double moved = 0;
+    for (int side = 0; side < 3; ++side)
+      for (int j = 0; j < op.p.nprod; ++j)
+        for (int r = 0; r < W; ++r) {
+          m4ri_amd_shard_piece pc;
+          m4ri_amd_shard_piece_of(&op.p, side, j, r, &pc);
+          if (pc.holder != pc.owner) moved += 8.0 * (double)pc.words;
+        }
+    g_mstats.link_bytes = moved;
+    rc = g_pool.run([&](int me) { return strassen_rank(op, me); });
+    ops_joined();
+  }
+  if (rc) return rc;
+  if (tC) return redistribute(C, tC.get());  // (the temporaries are freed after a device synchronisation: dmat_delete)
   return 0;
 }
 
-// the local parent of C -> host C, touching only the words and bits the reference would (mzd.h:117-123)
-int download_local(Rank &r, const m4ri_amd_shard_plan &p, int rank, mzd_t *C, const word *local) {
-  const int64_t c0 = cut_of(p.bm, p.world, rank), s = cut_of(p.bm, p.world, rank + 1) - c0, lw = p.N / 64;
-  if (s == 0 || C->width == 0) return 0;
+int sync_all() {
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  int rc = 0;
+  for (auto &r : g_ranks) {
+    if (hipSetDevice(r->device) != hipSuccess) { rc = (int)hipErrorInvalidDevice; continue; }
+    for (hipStream_t s : {r->ci, r->co, r->st}) {
+      const hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess && !rc) rc = (int)e;
+    }
+  }
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
+// ---- host matrices in and out ----------------------------------------------------------------------------
+// host rows of M -> the zero-padded local buffers: every device its own rows over its own PCIe link
+int upload_rank(m4ri_amd_dmat *d, const mzd_t *M, int me) {
+  Rank &R = *g_ranks[(size_t)me];
+  RTRY(hipSetDevice(R.device));
+  RTRY(op_begin(R));
+  word *local = d->local[(size_t)me];
+  if (d->lrows[(size_t)me] > 0) RTRY(hipMemsetAsync(local, 0, (size_t)d->lrows[(size_t)me] * (size_t)d->stride * 8, R.st));
+  Run runs[4];
+  const int nr = runs_of(d->layout, d->world, me, d->rows, runs);
+  for (int i = 0; i < nr && M->width > 0; ++i) {
+    RTRY(hipMemcpy2DAsync(local + runs[i].l0 * d->stride, (size_t)d->stride * 8, M->data + runs[i].g0 * M->rowstride, (size_t)M->rowstride * 8,
+                          (size_t)M->width * 8, (size_t)runs[i].rows, hipMemcpyHostToDevice, R.st));
+    // a window's last word carries its parent's neighbouring columns (mzd.h:117-123): zero them
+    if (M->ncols % 64) RTRY(gf2_launch_mask_tail(R.st, local + runs[i].l0 * d->stride, d->stride, runs[i].rows, M->ncols));
+  }
+  RTRY(op_end(R));
+  RTRY(hipStreamSynchronize(R.st));  // the caller may free or change M as soon as this returns
+  return 0;
+}
+
+// the local buffers -> host C, touching only the words and bits the reference would (mzd.h:117-123)
+int download_rank(const m4ri_amd_dmat *d, mzd_t *C, int me, bool all_ranks) {
+  Rank &R = *g_ranks[(size_t)me];
+  RTRY(hipSetDevice(R.device));
+  RTRY(op_begin(R));
+  RTRY(op_end(R));
+  if (C->width == 0) return 0;
+  if (d->layout == M4RI_AMD_LAYOUT_REPLICATED && !all_ranks && me != 0) return 0;
   const bool dangerous = (C->flags & FLAG_WINDOW) && (C->ncols % 64 != 0);
   const int64_t wfull  = dangerous ? C->width - 1 : C->width;
   std::vector<word> last;
-  for (int b = 0; b < p.blocks; ++b) {
-    const int64_t g0 = (int64_t)b * p.bm + c0;
-    int64_t rows     = (int64_t)C->nrows - g0;
-    if (rows > s) rows = s;
-    if (rows <= 0) continue;
-    const word *src = local + (int64_t)b * s * lw;
+  Run runs[4];
+  int nr = runs_of(d->layout, d->world, me, d->rows, runs);
+  if (d->layout == M4RI_AMD_LAYOUT_REPLICATED && all_ranks) {  // every rank downloads a share of the rows
+    const int64_t k = (d->rows + d->world - 1) / d->world, g0 = k * me;
+    nr = g0 < d->rows ? 1 : 0;
+    runs[0] = Run{g0, (d->rows - g0) < k ? (d->rows - g0) : k, g0};
+  }
+  for (int i = 0; i < nr; ++i) {
+    const word *src = d->local[(size_t)me] + runs[i].l0 * d->stride;
     if (wfull > 0)
-      HIPTRY(hipMemcpy2DAsync(C->data + g0 * C->rowstride, (size_t)C->rowstride * 8, src, (size_t)lw * 8, (size_t)wfull * 8, (size_t)rows,
-                              hipMemcpyDeviceToHost, r.stream));
+      RTRY(hipMemcpy2DAsync(C->data + runs[i].g0 * C->rowstride, (size_t)C->rowstride * 8, src, (size_t)d->stride * 8, (size_t)wfull * 8, (size_t)runs[i].rows,
+                            hipMemcpyDeviceToHost, R.st));
     if (dangerous) {
-      last.resize((size_t)rows);
-      HIPTRY(hipMemcpy2DAsync(last.data(), 8, src + (C->width - 1), (size_t)lw * 8, 8, (size_t)rows, hipMemcpyDeviceToHost, r.stream));
-      HIPTRY(hipStreamSynchronize(r.stream));
+      last.resize((size_t)runs[i].rows);
+      RTRY(hipMemcpy2DAsync(last.data(), 8, src + (C->width - 1), (size_t)d->stride * 8, 8, (size_t)runs[i].rows, hipMemcpyDeviceToHost, R.st));
+      RTRY(hipStreamSynchronize(R.st));
       const word mask = C->high_bitmask;
-      for (int64_t i = 0; i < rows; ++i) {
-        word *w = C->data + (g0 + i) * C->rowstride + (C->width - 1);
-        *w      = (*w & ~mask) | (last[(size_t)i] & mask);
+      for (int64_t k = 0; k < runs[i].rows; ++k) {
+        word *w = C->data + (runs[i].g0 + k) * C->rowstride + (C->width - 1);
+        *w      = (*w & ~mask) | (last[(size_t)k] & mask);
       }
     }
   }
+  RTRY(hipStreamSynchronize(R.st));
   return 0;
 }
 
-template <typename F>
-int on_every_rank(F f) {
-  std::vector<std::thread> th;
-  for (size_t i = 0; i < g_ranks.size(); ++i)
-    th.emplace_back([&, i] {
-      Rank &r = g_ranks[i];
-      r.rc    = (int)hipSetDevice(r.device);
-      if (r.rc == 0) r.rc = f(r, (int)i);
-    });
-  for (auto &t : th) t.join();
-  for (Rank &r : g_ranks)
-    if (r.rc) return r.rc;
-  return 0;
+// the three distributed temporaries of the host entry point, kept between calls (grow-only in spirit: re-made when the
+// shape or the layout changes)
+m4ri_amd_dmat *g_tmp[3] = {nullptr, nullptr, nullptr};
+
+m4ri_amd_dmat *tmp_dmat(int slot, int64_t rows, int64_t ncols, int layout) {
+  m4ri_amd_dmat *&d = g_tmp[slot];
+  if (d && alive(d) && d->rows == rows && d->ncols == ncols && d->layout == layout) return d;
+  if (d) dmat_delete(d);
+  d = dmat_new(rows, ncols, layout);
+  return d;
+}
+
+void drop_tmp() {
+  for (m4ri_amd_dmat *&d : g_tmp) {
+    if (d) dmat_delete(d);
+    d = nullptr;
+  }
 }
 
 int mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int add, int cutoff, int levels) {
   if (int rc = ensure_ranks()) return rc;
   const int W = (int)g_ranks.size();
-  m4ri_amd_shard_plan p;
-  if (m4ri_amd_shard_plan_make(&p, W, A->nrows, A->ncols, B->ncols, levels)) return (int)hipErrorInvalidValue;
+  const int64_t m = A->nrows, l = A->ncols, n = B->ncols;
+  int variant = levels > 0 ? M4RI_AMD_VARIANT_STRASSEN : (g_variant ? g_variant : default_variant(W, m, l, n));
+  if (levels == 0 && variant == M4RI_AMD_VARIANT_STRASSEN) levels = auto_levels(W, m, l, n);
+  const int layout = variant == M4RI_AMD_VARIANT_STRASSEN ? (levels == 2 ? M4RI_AMD_LAYOUT_CYCLIC2 : M4RI_AMD_LAYOUT_CYCLIC1) : M4RI_AMD_LAYOUT_ROWS;
+  m4ri_amd_dmat *dA = tmp_dmat(0, m, l, layout), *dB = tmp_dmat(1, l, n, layout), *dC = tmp_dmat(2, m, n, layout);
+  if (!dA || !dB || !dC) return (int)hipErrorOutOfMemory;
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
-  // 1. every device: its slabs of A, B (and C when accumulating) over its own PCIe link, local down passes
-  int rc = on_every_rank([&](Rank &r, int i) -> int {
-    if (int e = carve(r, p, i)) return e;
-    if (int e = upload_local(r, p, i, A, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_A], p.bm, p.L / 64)) return e;
-    if (int e = upload_local(r, p, i, B, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_B], p.bl, p.N / 64)) return e;
-    if (add) { if (int e = upload_local(r, p, i, C, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_C], p.bm, p.N / 64)) return e; }
-    if (int e = m4ri_amd_shard_down_dev(&p, i, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_A], p.L / 64, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_B], p.N / 64,
-                                        r.buf[M4RI_AMD_SHARD_BUF_CHILD_A], r.buf[M4RI_AMD_SHARD_BUF_CHILD_B], r.stream)) return e;
-    return (int)hipEventRecord(r.ev_down, r.stream);
+  int rc = g_pool.run([&](int me) -> int {
+    if (int e = upload_rank(dA, A, me)) return e;
+    if (int e = upload_rank(dB, B, me)) return e;
+    return add ? upload_rank(dC, C, me) : 0;
   });
-  if (rc) { (void)hipSetDevice(cur); return rc; }
-  // 2. slab r of child j: r -> owner(j), pulled on the owner's stream (one peer copy per piece: on a real
-  //    node W*(W-1) directed xGMI links work at once); then the owner's sub-products
-  for (int o = 0; o < W; ++o) {
-    Rank &ro = g_ranks[o];
-    HIPTRY(hipSetDevice(ro.device));
-    bool any = false;
-    for (int j = o; j < p.nprod; j += W) {
-      any = true;
-      for (int side = 0; side < 2; ++side)
-        for (int r = 0; r < W; ++r) {
-          m4ri_amd_shard_piece pc;
-          m4ri_amd_shard_piece_of(&p, side, j, r, &pc);
-          if (pc.words == 0) continue;
-          Rank &rh = g_ranks[r];
-          if (j == o) HIPTRY(hipStreamWaitEvent(ro.stream, rh.ev_down, 0));
-          HIPTRY(hipMemcpyPeerAsync(ro.buf[side ? M4RI_AMD_SHARD_BUF_OPER_B : M4RI_AMD_SHARD_BUF_OPER_A] + pc.owner_off, ro.device,
-                                    rh.buf[side ? M4RI_AMD_SHARD_BUF_CHILD_B : M4RI_AMD_SHARD_BUF_CHILD_A] + pc.holder_off, rh.device,
-                                    (size_t)pc.words * 8, ro.stream));
-        }
-    }
-    if (any) {
-      for (int j = o, jl = 0; j < p.nprod; j += W, ++jl)
-        HIPTRY(m4ri_amd_mul_dev(ro.buf[M4RI_AMD_SHARD_BUF_PROD] + (int64_t)jl * p.bm * p.cwn, p.cwn,
-                                ro.buf[M4RI_AMD_SHARD_BUF_OPER_A] + (int64_t)jl * p.bm * p.cwl, p.cwl,
-                                ro.buf[M4RI_AMD_SHARD_BUF_OPER_B] + (int64_t)jl * p.bl * p.cwn, p.cwn, p.bm, p.bl, p.cwn * 64, 0, cutoff,
-                                ro.stream));
-    }
-    HIPTRY(hipEventRecord(ro.ev_prod, ro.stream));
+  ops_joined();
+  if (!rc) rc = dmat_mul(dC, dA, dB, add, cutoff, variant);
+  if (!rc) {
+    rc = g_pool.run([&](int me) { return download_rank(dC, C, me, true); });
+    ops_joined();
   }
-  // 3. slab r of product j: owner(j) -> r, pulled on r's stream; local up pass; 4. download
-  for (int r = 0; r < W; ++r) {
-    Rank &rh = g_ranks[r];
-    HIPTRY(hipSetDevice(rh.device));
-    for (int o = 0; o < W && o < p.nprod; ++o) HIPTRY(hipStreamWaitEvent(rh.stream, g_ranks[o].ev_prod, 0));
-    for (int j = 0; j < p.nprod; ++j) {
-      m4ri_amd_shard_piece pc;
-      m4ri_amd_shard_piece_of(&p, 2, j, r, &pc);
-      if (pc.words == 0) continue;
-      Rank &ro = g_ranks[pc.owner];
-      HIPTRY(hipMemcpyPeerAsync(rh.buf[M4RI_AMD_SHARD_BUF_SLABS_P] + pc.holder_off, rh.device, ro.buf[M4RI_AMD_SHARD_BUF_PROD] + pc.owner_off,
-                                ro.device, (size_t)pc.words * 8, rh.stream));
-    }
-    HIPTRY(m4ri_amd_shard_up_dev(&p, r, rh.buf[M4RI_AMD_SHARD_BUF_SLABS_P], rh.buf[M4RI_AMD_SHARD_BUF_LOCAL_C], p.N / 64, add, rh.stream));
-  }
-  rc = on_every_rank([&](Rank &r, int i) -> int {
-    if (int e = download_local(r, p, i, C, r.buf[M4RI_AMD_SHARD_BUF_LOCAL_C])) return e;
-    return (int)hipStreamSynchronize(r.stream);
-  });
   (void)hipSetDevice(cur);
   return rc;
 }
@@ -410,7 +972,7 @@ extern "C" {
 
 int m4ri_amd_set_devices(int n, const int *ids) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
-  if (n < 0 || (n > 0 && !ids) || n > 64) return -1;  // up to 64 RANKS (ids may repeat) ...
+  if (n < 0 || (n > 0 && !ids) || n > MAX_RANKS) return -1;  // up to 64 RANKS (ids may repeat) ...
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
   for (int i = 0; i < n; ++i)
@@ -423,7 +985,7 @@ int m4ri_amd_set_devices(int n, const int *ids) {
 int m4ri_amd_get_device_list(int *ids, int cap) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
   default_devices();
-  for (int i = 0; i < (int)g_devices.size() && i < cap; ++i) ids[i] = g_devices[i];
+  for (int i = 0; i < (int)g_devices.size() && i < cap; ++i) ids[i] = g_devices[(size_t)i];
   return (int)g_devices.size();
 }
 
@@ -434,6 +996,34 @@ int64_t m4ri_amd_set_multi_threshold(int64_t min_dim) {
   return old;
 }
 
+int m4ri_amd_set_multi_variant(int variant) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  const int old = g_variant;
+  if (variant >= 0 && variant <= M4RI_AMD_VARIANT_STRASSEN) g_variant = variant;
+  return old;
+}
+
+int m4ri_amd_multi_default_variant(int world, int64_t m, int64_t l, int64_t n) { return default_variant(world, m, l, n); }
+
+int m4ri_amd_multi_layout_for(int variant, int world, int64_t m, int64_t l, int64_t n) {
+  if (variant == 0) variant = default_variant(world, m, l, n);
+  if (variant != M4RI_AMD_VARIANT_STRASSEN) return M4RI_AMD_LAYOUT_ROWS;
+  return auto_levels(world, m, l, n) == 2 ? M4RI_AMD_LAYOUT_CYCLIC2 : M4RI_AMD_LAYOUT_CYCLIC1;
+}
+
+int64_t m4ri_amd_layout_local_rows(int layout, int world, int rank, int64_t rows) {
+  if (layout < 0 || layout > M4RI_AMD_LAYOUT_REPLICATED || world < 1 || rank < 0 || rank >= world || rows < 0) return -1;
+  return local_rows_of(layout, world, rank, rows);
+}
+
+int m4ri_amd_layout_runs(int layout, int world, int rank, int64_t rows, int64_t *g0, int64_t *nrows, int64_t *l0, int cap) {
+  if (layout < 0 || layout > M4RI_AMD_LAYOUT_REPLICATED || world < 1 || rank < 0 || rank >= world || rows < 0) return -1;
+  Run runs[4];
+  const int n = runs_of(layout, world, rank, rows, runs);
+  for (int i = 0; i < n && i < cap; ++i) { g0[i] = runs[i].g0; nrows[i] = runs[i].rows; l0[i] = runs[i].l0; }
+  return n;
+}
+
 // would mzd_mul_mp spread this product over several devices?  (gf2_multi_run's own test)
 int gf2_multi_wanted(int64_t m, int64_t l, int64_t n) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
@@ -442,8 +1032,133 @@ int gf2_multi_wanted(int64_t m, int64_t l, int64_t n) {
   return g_devices.size() > 1 && mn >= g_threshold && mn >= 1;
 }
 
+m4ri_amd_dmat *m4ri_amd_dmat_create(int64_t rows, int64_t ncols, int layout) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (ensure_ranks()) return nullptr;
+  return dmat_new(rows, ncols, layout);
+}
+
+void m4ri_amd_dmat_free(m4ri_amd_dmat *d) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  dmat_delete(d);
+}
+
+int m4ri_amd_dmat_info(const m4ri_amd_dmat *d, m4ri_amd_dmat_info_t *out) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!d || !out) return -1;
+  out->rows = d->rows; out->ncols = d->ncols; out->stride = d->stride; out->layout = d->layout; out->world = d->world;
+  out->alive = alive(d) ? 1 : 0;
+  return 0;
+}
+
+int m4ri_amd_dmat_local(const m4ri_amd_dmat *d, int rank, word **data, int64_t *local_rows, int *device) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!d || rank < 0 || rank >= d->world) return -1;
+  if (data) *data = d->local[(size_t)rank];
+  if (local_rows) *local_rows = d->lrows[(size_t)rank];
+  if (device) *device = d->device[(size_t)rank];
+  return 0;
+}
+
+int m4ri_amd_dmat_fill(m4ri_amd_dmat *d, uint64_t seed) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!alive(d)) return (int)hipErrorInvalidValue;
+  const int rc = g_pool.run([&](int me) -> int {
+    Rank &R = *g_ranks[(size_t)me];
+    RTRY(hipSetDevice(R.device));
+    RTRY(op_begin(R));
+    Run runs[4];
+    const int nr = runs_of(d->layout, d->world, me, d->rows, runs);
+    for (int i = 0; i < nr; ++i)
+      RTRY(m4ri_amd_fill_rows_dev(d->local[(size_t)me] + runs[i].l0 * d->stride, d->stride, runs[i].g0, runs[i].rows, d->ncols, seed, R.st));
+    return op_end(R);
+  });
+  ops_joined();
+  return rc;
+}
+
+int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!alive(d) || !M || M->nrows != d->rows || M->ncols != d->ncols) return (int)hipErrorInvalidValue;
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  const int rc = g_pool.run([&](int me) { return upload_rank(d, M, me); });
+  ops_joined();
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
+int m4ri_amd_dmat_download(const m4ri_amd_dmat *d, mzd_t *M) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!alive(d) || !M || M->nrows != d->rows || M->ncols != d->ncols) return (int)hipErrorInvalidValue;
+  const int rc = g_pool.run([&](int me) { return download_rank(d, M, me, true); });
+  ops_joined();
+  return rc;
+}
+
+int m4ri_amd_dmat_convert(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  return redistribute(dst, src);
+}
+
+int m4ri_amd_dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (variant < 0 || variant > M4RI_AMD_VARIANT_STRASSEN) return (int)hipErrorInvalidValue;
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  const int rc = dmat_mul(C, A, B, add, cutoff, variant);
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
+int m4ri_amd_multi_sync(void) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  return sync_all();
+}
+
+int m4ri_amd_multi_get_stats(m4ri_amd_multi_stats *out) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (!out) return -1;
+  *out = g_mstats;
+  return 0;
+}
+
+// The marks of rank `rank`'s part of the most recent m4ri_amd_dmat_mul, in ms after the rank's compute stream entered the
+// operation (the devices are synchronised first).  Order: Strassen schedule -- down pass done; then per unit (round, row
+// chunk) operands in, product done; result slabs in; up pass done.  Row slabs -- gather done; first product done (the one
+// with the own slab of B when the gather is overlapped); all done.  Returns the number of marks written, < 0 on error.
+int m4ri_amd_multi_timeline(int rank, double *ms, int cap) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (rank < 0 || rank >= (int)g_ranks.size() || !ms) return -1;
+  if (sync_all()) return -1;
+  Rank &R = *g_ranks[(size_t)rank];
+  if (!R.tl_valid) return 0;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(R.device);
+  std::vector<hipEvent_t> marks;
+  if (R.tl_strassen) {
+    marks.push_back(R.ev_down);
+    for (int u = 0; u < R.tl_units; ++u) { marks.push_back(R.ev_in[(size_t)u]); marks.push_back(R.ev_prod[(size_t)u]); }
+    marks.push_back(R.ev_back);
+  } else {
+    marks.push_back(R.ev_gather);
+    marks.push_back(R.ev_first);
+  }
+  marks.push_back(R.ev_done);
+  int n = 0;
+  for (hipEvent_t e : marks) {
+    float t = 0;
+    if (n >= cap) break;
+    if (hipEventElapsedTime(&t, R.ev_start, e) != hipSuccess) t = -1.0f;
+    ms[n++] = (double)t;
+  }
+  (void)hipSetDevice(cur);
+  return n;
+}
+
 int m4ri_amd_mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int add, int cutoff, int levels) {
-  if (!C || !A || !B || A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols || cutoff < 0) return (int)hipErrorInvalidValue;
+  if (!C || !A || !B || A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols || cutoff < 0 || levels < 0 || levels > 2) return (int)hipErrorInvalidValue;
   if (C->nrows == 0 || C->ncols == 0) return 0;
   if (A->ncols == 0) {  // empty inner dimension: C = 0 / C unchanged
     if (!add)
@@ -462,9 +1177,11 @@ void gf2_release_multi(void) {  // called by m4ri_amd_release_workspace
   std::lock_guard<std::mutex> lk(g_multi_mu);
   int cur = 0;
   if (hipGetDevice(&cur) != hipSuccess) return;
-  for (Rank &r : g_ranks) {
+  drop_tmp();
+  for (auto &rp : g_ranks) {
+    Rank &r = *rp;
     (void)hipSetDevice(r.device);
-    if (r.stream) (void)hipStreamSynchronize(r.stream);
+    (void)hipDeviceSynchronize();
     if (r.arena) (void)hipFree(r.arena);
     r.arena = nullptr; r.cap = 0;
   }

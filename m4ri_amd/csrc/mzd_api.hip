@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sys/mman.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -40,10 +41,12 @@ std::mutex g_api_mu;
 struct ApiStats {
   double seconds = 0, h2d = 0, d2h = 0;
   long calls = 0;
+  int populate_fallback = 0;  // a fresh result's pages were faulted by touching them: no MADV_POPULATE_WRITE here
   ~ApiStats() {
     if (calls && getenv("M4RI_AMD_STATS"))
       fprintf(stderr, "m4ri_amd: %ld products through the host entry points, %.3f s inside them, %.2f GiB up, %.2f GiB down\n",
               calls, seconds, h2d / 1073741824.0, d2h / 1073741824.0);
+    if (populate_fallback && getenv("M4RI_AMD_STATS")) fprintf(stderr, "m4ri_amd: MADV_POPULATE_WRITE unavailable, fresh results were pre-faulted by touching their pages\n");
   }
 } g_api_stats;
 
@@ -61,12 +64,86 @@ struct ApiStats {
     if (e_ != hipSuccess) die("m4ri_amd: HIP failure '%s' in %s (%s:%d)\n", hipGetErrorString(e_), #expr, __FILE__, __LINE__); \
   } while (0)
 
-mzd_t *result_init(rci_t r, rci_t c) {
+typedef mzd_t *(*mzd_init_fn)(rci_t, rci_t);
+mzd_init_fn host_mzd_init() {
   // the caller will mzd_free() the result, so it has to come from the host program's libm4ri
   // allocator when there is one
-  typedef mzd_t *(*init_fn)(rci_t, rci_t);
-  static init_fn host_init = reinterpret_cast<init_fn>(dlsym(RTLD_DEFAULT, "mzd_init"));
+  static mzd_init_fn fn = reinterpret_cast<mzd_init_fn>(dlsym(RTLD_DEFAULT, "mzd_init"));
+  return fn;
+}
+
+mzd_t *result_init(rci_t r, rci_t c) {
+  mzd_init_fn host_init = host_mzd_init();
   return host_init ? host_init(r, c) : m4ri_amd_mzd_init(r, c);
+}
+
+// Blocks of this size and more come straight from mmap in m4ri_amd_mzd_init: whole zero pages from the kernel, nothing to clear
+constexpr size_t BIG_BLOCK = (size_t)8 << 20;
+size_t big_len(size_t bytes) { return (bytes + 4095) & ~(size_t)4095; }
+
+// A result that is still on its way.  mzd_mul(NULL, A, B, cutoff) is the region the reference's own bench times
+// (bench/bench_multiplication.c:85-107), and a fresh 512 MiB matrix costs 33 ... 87 ms of page faults and clearing -- more than
+// the 65536^3 product it receives -- when that happens in front of the upload.  Nothing needs C before the first block of the
+// result is downloaded, so:
+//   * with the host program's allocator (its mzd_init: malloc + ONE memset, misc.h:614-634) the call runs on a thread of its own
+//     beside the upload and the first products; the first download waits for it (get());
+//   * with this library's allocator the block is mmap'ed (instant, zero pages on demand) and worker threads fault its pages in
+//     (MADV_POPULATE_WRITE: never changes a byte, so it may run beside the downloads) while the GPU works.
+struct LateC {
+  rci_t nrows = 0, ncols = 0;
+  mzd_t *C = nullptr;
+  std::thread maker;
+  std::vector<std::thread> populate;
+  std::once_flag once;
+  mzd_t *get() {
+    std::call_once(once, [this] { if (maker.joinable()) maker.join(); });
+    return C;
+  }
+  mzd_t *finish() {
+    get();
+    for (std::thread &t : populate) t.join();
+    populate.clear();
+    return C;
+  }
+};
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux 5.14
+#endif
+
+void late_begin(LateC &lc, rci_t r, rci_t c) {
+  lc.nrows = r; lc.ncols = c;
+  if (mzd_init_fn host_init = host_mzd_init()) {
+    try {
+      lc.maker = std::thread([&lc, host_init, r, c] { lc.C = host_init(r, c); });
+    } catch (...) {  // no thread to be had (RLIMIT_NPROC, a pids cgroup): allocate here and now
+      lc.C = host_init(r, c);
+    }
+    return;
+  }
+  lc.C = m4ri_amd_mzd_init(r, c);
+  const size_t bytes = (size_t)r * (size_t)lc.C->rowstride * 8;
+  if (bytes < BIG_BLOCK) return;
+  char *base = reinterpret_cast<char *>(lc.C->data);
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = hw >= 64 ? 16 : hw >= 16 ? 8 : 2, chunk = (size_t)16 << 20;
+  // the workers walk the block front to back in 16 MiB chunks, round robin: the rows the first download will write come first
+  try {
+    for (size_t k = 0; k < nt; ++k)
+      lc.populate.emplace_back([base, bytes, k, nt, chunk] {
+        bool advise = true;
+        for (size_t at = k * chunk; at < bytes; at += nt * chunk) {
+          const size_t len = bytes - at < chunk ? bytes - at : chunk;
+          if (advise && madvise(base + at, big_len(len), MADV_POPULATE_WRITE) == 0) continue;
+          // a kernel (or sandbox) without MADV_POPULATE_WRITE: fault every page with an atomic OR of zero -- a write access that cannot
+          // change a byte, so it too may run beside the download that fills the page
+          advise = false;
+          g_api_stats.populate_fallback = 1;
+          for (size_t off = 0; off < len; off += 4096) __atomic_fetch_or(reinterpret_cast<unsigned char *>(base + at + off), (unsigned char)0, __ATOMIC_RELAXED);
+        }
+      });
+  } catch (...) {  // fewer (or no) helpers: the downloads fault what is left
+  }
 }
 
 extern "C" hipError_t gf2_launch_copy_masked(hipStream_t s, word *C, int64_t cs, const word *A, int64_t as, int64_t rows, int64_t ncols);
@@ -207,9 +284,10 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 size_t g_pipeline_min_bytes = (size_t)64 << 20;  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
-bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff) {
+bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff, LateC *late) {
   const int64_t m = A->nrows, l = A->ncols, n = B->ncols;
-  const size_t bytes = ((size_t)m * A->width + (size_t)B->nrows * B->width + (size_t)m * C->width) * 8;
+  const size_t bytes = ((size_t)m * A->width + (size_t)B->nrows * B->width + (size_t)m * (size_t)words_of(n)) * 8;
+  auto Cget = [&]() -> mzd_t * { return late ? late->get() : C; };  // a result still being allocated: first needed by the first download
   if (g_pipeline_min_bytes == 0 || bytes < g_pipeline_min_bytes || m < 4 * 4096) return false;
   // cuts: rows of A / C on whole 4096-row tiles, columns and the inner dimension on whole words
   std::vector<int64_t> rcut, ccut, kcut;
@@ -285,12 +363,11 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     ev(e);
     HIPDIE(hipEventRecord(e, nullptr));
   };
-  auto c_block = [&](int i, int j) { return block_of(C, rcut[(size_t)i], rcut[(size_t)i + 1], ccut[(size_t)j], ccut[(size_t)j + 1]); };
+  auto c_block = [&](int i, int j) { return block_of(Cget(), rcut[(size_t)i], rcut[(size_t)i + 1], ccut[(size_t)j], ccut[(size_t)j + 1]); };
   auto prepare_c = [&](int t) {
     if (upC[(size_t)t]) return;
-    const mzd_t S = c_block(t / gj, t % gj);
-    if (add) upload(dC[(size_t)t], &S);
-    else dev_alloc(dC[(size_t)t], S.nrows, S.ncols);
+    if (add) { const mzd_t S = c_block(t / gj, t % gj); upload(dC[(size_t)t], &S); }
+    else dev_alloc(dC[(size_t)t], R(t / gj), Cc(t % gj));
     ev(upC[(size_t)t]);
     HIPDIE(hipEventRecord(upC[(size_t)t], nullptr));
   };
@@ -347,9 +424,11 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
 }
 
 // the whole product: strassen == true runs the Strassen-Winograd engine, false a single leaf
-mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff) {
+// `late`: C == nullptr and the result is still being allocated (LateC; never with add, never empty)
+mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff, LateC *late = nullptr) {
   std::lock_guard<std::mutex> lk(g_api_mu);
-  if (C->nrows == 0 || C->ncols == 0) return C;  // strassen.c:44
+  const rci_t cm = A->nrows, cn = B->ncols;
+  if (cm == 0 || cn == 0) return late ? late->get() : C;  // strassen.c:44
   struct Timer {
     timespec t0;
     Timer() { clock_gettime(CLOCK_MONOTONIC, &t0); }
@@ -359,20 +438,20 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
   const bool same = (A == B);
-  Pin *pinC = find_pin(C);
-  if (strassen && !same && !pinC && !find_pin(A) && !find_pin(B) && run_pipelined(C, A, B, add, cutoff)) return C;
+  Pin *pinC = late ? nullptr : find_pin(C);
+  if (strassen && !same && !pinC && !find_pin(A) && !find_pin(B) && run_pipelined(C, A, B, add, cutoff, late)) return late ? late->get() : C;
   // a pinned C whose last word is shared with other columns of its parent is computed in staging and
   // merged under the column mask; otherwise the engine writes straight into the parent
-  const bool c_staged = !pinC || (C->ncols % 64 != 0 && C->ncols != pinC->ncols);
+  const bool c_staged = !pinC || (cn % 64 != 0 && cn != pinC->ncols);
   arena_reserve((find_pin(A) ? 0 : dev_words(A->nrows, A->ncols)) + ((same || find_pin(B)) ? 0 : dev_words(B->nrows, B->ncols)) +
-                (c_staged ? dev_words(C->nrows, C->ncols) : 0));
+                (c_staged ? dev_words(cm, cn) : 0));
   const DevMat dA = operand(A, true);
   const DevMat dB = same ? dA : operand(B, true);
   DevMat dC;
   if (!c_staged) dC = operand(C, false);
-  else if (!pinC) { if (add) upload(dC, C); else dev_alloc(dC, C->nrows, C->ncols); }
+  else if (!pinC) { if (add) upload(dC, C); else dev_alloc(dC, cm, cn); }
   else {
-    dev_alloc(dC, C->nrows, C->ncols);
+    dev_alloc(dC, cm, cn);
     if (add) {
       const DevMat src = operand(C, false);
       HIPDIE(hipMemcpy2DAsync(dC.p, (size_t)dC.stride * 8, src.p, (size_t)src.stride * 8, (size_t)C->width * 8, (size_t)C->nrows,
@@ -388,7 +467,7 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   // land in C's excess columns: clear them before the result leaves the staging buffer
   // (an unstaged pinned C spans its parent's full width, so its excess bits must be zero anyway:
   // mzd.h:115-121 -- mask there as well, or sync/unpin would carry the neighbours' bits to the host)
-  if (c_staged || C->ncols % 64 != 0) HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, C->nrows, C->ncols, nullptr));
+  if (c_staged || cn % 64 != 0) HIPDIE(m4ri_amd_mask_tail_dev(dC.p, dC.stride, cm, cn, nullptr));
   if (pinC) {
     if (c_staged) {
       const DevMat dst = operand(C, false);
@@ -396,6 +475,7 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
     }
     pinC->dev_newer = true;  // the host copy is stale until m4ri_amd_sync / m4ri_amd_unpin
   } else {
+    if (late) C = late->get();
     download(dC, C);
   }
   HIPDIE(hipDeviceSynchronize());
@@ -510,24 +590,20 @@ mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c) {  // mzd.c:142-157
   if (r && c) {
     void *p = nullptr;
     const size_t bytes = (size_t)r * (size_t)A->rowstride * 8;
-    // large blocks: 2 MiB-aligned (whole transparent huge pages) and zeroed by a few threads -- a fresh 512 MiB result
-    // costs 87 ms of page faults under one memset, more than the 65536^3 product it receives (bench.py: api.c_null_ms)
-    const bool big = bytes >= ((size_t)8 << 20);
-    if (posix_memalign(&p, big ? ((size_t)2 << 20) : 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
-    if (big) {
-      // (no MADV_HUGEPAGE: with the usual defrag = madvise setting it makes every fault compact memory synchronously -- a first
-      // 512 MiB block took 0.7 ... 1.7 s in the build container; 2 MiB alignment lets THP = always serve huge pages when it has them)
-      unsigned hw = std::thread::hardware_concurrency();
-      const size_t nt = hw >= 256 ? 32 : hw >= 64 ? 16 : 8, per = ((bytes / nt) + 4095) & ~(size_t)4095;
-      std::vector<std::thread> th;
-      for (size_t k = 0; k < nt; ++k) {
-        const size_t at = k * per;
-        if (at >= bytes) break;
-        const size_t len = bytes - at < per ? bytes - at : per;
-        th.emplace_back([=] { memset(static_cast<char *>(p) + at, 0, len); });
-      }
-      for (std::thread &t : th) t.join();
+    if (bytes >= BIG_BLOCK) {
+      // large blocks: their own mapping, 2 MiB-aligned (whole transparent huge pages where the system serves them) -- the kernel hands
+      // out zero pages, so nothing is cleared here and no page is touched before somebody needs it: a fresh 512 MiB result used to cost
+      // 87 ms of page faults under one memset (33 ms under 32 threads), more than the 65536^3 product it receives.  (No MADV_HUGEPAGE:
+      // with the usual defrag = madvise setting it makes every fault compact memory synchronously.)
+      const size_t len = big_len(bytes), al = (size_t)2 << 20;
+      char *raw = static_cast<char *>(mmap(nullptr, len + al, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+      if (raw == MAP_FAILED) die("m4ri_amd_mzd_init: out of memory\n");
+      char *q = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + al - 1) & ~(uintptr_t)(al - 1));
+      if (q > raw) munmap(raw, (size_t)(q - raw));
+      if (raw + len + al > q + len) munmap(q + len, (size_t)((raw + len + al) - (q + len)));
+      p = q;
     } else {
+      if (posix_memalign(&p, 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
       memset(p, 0, bytes);
     }
     A->data = static_cast<word *>(p);
@@ -537,14 +613,33 @@ mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c) {  // mzd.c:142-157
 
 void m4ri_amd_mzd_free(mzd_t *A) {  // mzd.c:179-185
   if (!A) return;
-  if (!(A->flags & FLAG_WINDOW)) free(A->data);
+  if (!(A->flags & FLAG_WINDOW) && A->data) {
+    const size_t bytes = (size_t)A->nrows * (size_t)A->rowstride * 8;
+    if (bytes >= BIG_BLOCK) munmap(A->data, big_len(bytes));  // m4ri_amd_mzd_init: large blocks are mappings of their own
+    else free(A->data);
+  }
   free(A);
+}
+
+// C == NULL at a product entry point: the product into a fresh matrix -- allocated beside the upload and the first products
+// when it is large (LateC), in front of them when it is small or the product is empty (the zero matrix)
+static mzd_t *run_fresh(mzd_t const *A, mzd_t const *B, bool strassen, int cutoff) {
+  const rci_t r = A->nrows, c = B->ncols;
+  const size_t bytes = (size_t)r * (size_t)((c + 63) / 64) * 8;
+  if (bytes < BIG_BLOCK || A->ncols == 0) {
+    mzd_t *C = result_init(r, c);
+    return (r == 0 || c == 0 || A->ncols == 0) ? C : run(C, A, B, false, strassen, cutoff);
+  }
+  LateC late;
+  late_begin(late, r, c);
+  run(nullptr, A, B, false, strassen, cutoff, &late);
+  return late.finish();
 }
 
 mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {  // strassen.c:345-365
   if (A->ncols != B->nrows) die("mzd_mul: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
   cutoff = norm_cutoff(cutoff, "mzd_mul");
-  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  if (C == NULL) return run_fresh(A, B, true, cutoff);
   else if (C->nrows != A->nrows || C->ncols != B->ncols)
     die("mzd_mul: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", C->nrows, C->ncols, A->nrows, B->ncols);
   return run(C, A, B, false, true, cutoff);
@@ -553,7 +648,7 @@ mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {  // stras
 mzd_t *mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {  // strassen.c:675-700
   if (A->ncols != B->nrows) die("mzd_addmul: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
   cutoff = norm_cutoff(cutoff, "mzd_addmul");
-  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  if (C == NULL) return run_fresh(A, B, true, cutoff);  // 0 + A*B
   else if (C->nrows != A->nrows || C->ncols != B->ncols)
     die("mzd_addmul: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", C->nrows, C->ncols, A->nrows, B->ncols);
   if (A->nrows == 0 || A->ncols == 0 || B->ncols == 0) return C;
@@ -569,7 +664,7 @@ mzd_t *_mzd_addsqr_even(mzd_t *C, mzd_t const *A, int cutoff) { return run(C, A,
 mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // brilliantrussian.c:999-1012
   (void)k;
   if (A->ncols != B->nrows) die("mzd_mul_m4rm: A ncols (%d) need to match B nrows (%d).\n", A->ncols, B->nrows);
-  if (C == NULL) C = result_init(A->nrows, B->ncols);
+  if (C == NULL) return run_fresh(A, B, false, 0);
   else if (C->nrows != A->nrows || C->ncols != B->ncols)
     die("mzd_mul_m4rm: C (%d x %d) has wrong dimensions.\n", C->nrows, C->ncols);
   return run(C, A, B, false, false, 0);

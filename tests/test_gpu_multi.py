@@ -96,18 +96,15 @@ def test_bench_ranks_on_one_gpu(world, variant, layout):
     """bench.py's N > 1 path, ranks as processes sharing GPU 0, transport = gloo staged through the host
     (RCCL refuses two ranks on one device); --check compares every rank's part of C with the product the rank
     recomputes alone."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    import socket
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--size", "8192", "--backend", "gloo", "--check", "--variant", variant, "--layout", layout, "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # launched the way the driver launches it: a torch.distributed.run around the command (it picks its own rendezvous port).  Launcher
+    # rank 0 becomes the controller of the run, starts the ranks that do the work and prints their line; the other launcher ranks step aside
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={world}",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--size", "8192", "--backend", "gloo", "--check", "--variant", variant, "--layout", layout, "--no-cpu-baseline", "--transport", "rccl"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("-> OK") == world, r.stdout[-3000:]
+    assert r.stdout.count("-> OK") == world and r.stdout.count('"metric"') == 1, r.stdout[-3000:]
 
 
 @pytest.mark.parametrize("m,l,n,seeds,world", [(65536, 65536, 65536, (3, 4), 8),        # BASELINE.json configs[3]: the sharded execution path
@@ -126,6 +123,9 @@ def test_baseline_sizes_through_the_sharded_path_vs_reference_sha256(m, l, n, se
     C = Mzd.init(m, n)
     m4ri_amd.mul_multi(C, A, B, False, 0, 0)
     assert hashlib.sha256(C.masked().tobytes()).hexdigest() == want[0]
+    # the schedule is chosen behind the C boundary: configs[3] takes the Strassen sub-products, configs[4] (l = 8192) row slabs
+    st = m4ri_amd.multi_stats()
+    assert st.variant == (m4ri_amd.VARIANT_SLABS if l == 8192 else m4ri_amd.VARIANT_STRASSEN) and st.world == world and st.converted == 0
 
 
 # ---- bench.py as the driver runs it: the command itself starts the ranks ---------------------------------------------
@@ -149,17 +149,17 @@ def test_bench_starts_its_own_ranks():
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["variant"] == "slabs"
     assert "all_gather" in out["config"]["collective"] and stdout.count("-> OK") == 2
-    assert out["config"]["inflight"] == 2 and out["latency_ms"] > 0      # the loop keeps two products in flight; one product's latency beside it
+    assert out["config"]["transport"] == "rccl" and out["config"]["transport_fallback"] == [] and out["host_issue_ms_per_step"] > 0
+    assert out["config"]["inflight"] == 1 and "pipelined_value" not in out     # the headline is one product at a time
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-                          "--inflight", "1"])
-    assert out["config"]["inflight"] == 1 and "latency_ms" not in out and stdout.count("-> OK") == 2
+                          "--inflight", "2"])
+    assert out["pipelined_value"] > 0 and out["pipelined_ms_per_step"] > 0 and stdout.count("-> OK") == 2   # the stream of products: a named extra
     out, stdout = _bench(["--gpus", "2", "--size", "8192", "--backend", "gloo", "--check", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--variant", "strassen", "--overlap", "2"])
     assert out["n_gpus"] == 2 and out["config"]["overlap_chunks"] == [2, 1] and stdout.count("-> OK") == 2
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--size", "8192", "--no-cpu-baseline"], capture_output=True, text=True,
-                       env=env, timeout=300, cwd=ROOT)
-    assert r.returncode != 0 and '"n_gpus"' not in r.stdout   # a launcher that started one rank for --gpus 8: refuse, do not print n_gpus 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--size", "8192", "--no-cpu-baseline", "--inner"], capture_output=True,
+                       text=True, env=dict(os.environ, WORLD_SIZE="1", RANK="0"), timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout   # a rank started alone for --gpus 8: refuse, do not print n_gpus 1
 
 
 def test_bench_overlapped_strassen_schedule_at_8_ranks():
@@ -168,8 +168,8 @@ def test_bench_overlapped_strassen_schedule_at_8_ranks():
     product it recomputes alone.  (gloo on one GPU completes every batch when it is posted: the bits and the batch order are
     what is tested here, the overlap itself needs links.)"""
     out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                          "--overlap", "2x2"], timeout=1500)
-    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2] and out["config"]["inflight"] == 2
+                          "--overlap", "2x2", "--inflight", "2"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2] and out["config"]["inflight"] == 1
     assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
 
 
@@ -250,3 +250,41 @@ def test_bench_distributed_code_path_under_rccl_at_world_size_1(variant):
     nccl backend at world size 1 (--force-dist): what the driver's multi-GPU run executes, minus the links."""
     out, stdout = _bench(["--gpus", "1", "--force-dist", "--variant", variant, "--size", "16384", "--steps", "2", "--warmup", "1", "--check"])
     assert out["n_gpus"] == 1 and out["config"]["variant"] == variant and "RCCL" in out["config"]["backend"] and stdout.count("-> OK") == 1
+
+
+# ---- the transport ladder of the N > 1 command ---------------------------------------------------------------------------
+def test_bench_peer_transport_one_process_all_ranks():
+    """`bench.py --gpus 8 --transport peer`: ONE process drives all ranks through m4ri_amd_dmat_mul (the schedules behind the C
+    boundary; here 8 virtual ranks on this GPU), prints the same line -- schedule chosen in C, per-rank timeline, host issue time."""
+    out, stdout = _bench(["--gpus", "8", "--transport", "peer", "--virtual-ranks", "--size", "16384", "--check", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"])
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["transport"] == "peer" and cfg["variant"] == "strassen" and cfg["transport_fallback"] == []
+    assert cfg["schedule_stats"]["variant"] == "strassen" and cfg["schedule_stats"]["sub_products"] == 7 and cfg["schedule_stats"]["operands_converted"] == 0
+    assert len(cfg["timeline_ms_last_step"]) == 8 and out["host_issue_ms_per_step"] > 0 and stdout.count("-> OK") == 1
+    out, stdout = _bench(["--gpus", "4", "--transport", "peer", "--virtual-ranks", "--dims", "20000,8192,30016", "--check", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"])
+    assert out["n_gpus"] == 4 and out["config"]["schedule_stats"]["variant"] == "slabs" and stdout.count("-> OK") == 1
+
+
+@pytest.mark.parametrize("inject", ["crash", "hang"])
+def test_bench_falls_back_down_the_ladder_and_still_prints_one_line(inject):
+    """The first rung (one process per rank over torch.distributed) fails -- its ranks die, or never finish and the watchdog kills them
+    (M4RI_AMD_BENCH_INJECT, a test hook in the ranks) -- and the command still ends with exactly one result line, from the peer
+    transport, saying what happened; with no rung left it ends with one error line and a non-zero exit code."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", M4RI_AMD_BENCH_INJECT=inject)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "8192", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--watchdog", "90" if inject == "crash" else "45"]
+    r = subprocess.run(base + ["--virtual-ranks", "--check"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["transport"] == "peer" and out["config"]["transport_fallback"][0]["transport"] == "rccl"
+    assert ("watchdog" in out["config"]["transport_fallback"][0]["reason"]) == (inject == "hang")
+    if inject == "crash":   # nothing left to fall back to: one error line, non-zero exit code
+        r = subprocess.run(base + ["--transport", "rccl"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]) and '"metric"' not in r.stdout

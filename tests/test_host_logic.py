@@ -54,3 +54,37 @@ def test_per_rank_blocks_of_the_default_grids_keep_their_depth():
         p = sharding.make_plan(world, 0, n, n, n)
         (r0, r1), (c0, c1), (k0, k1) = p.row_range(), p.col_range(), p.inner_range()
         assert m4ri_amd.plan_levels(r1 - r0, k1 - k0, c1 - c0, 0) == L
+
+
+# ---- the multi-GPU schedules behind the C boundary: their host arithmetic (multi.hip, no GPU needed) -----------------------
+def test_schedule_choice_in_c_matches_the_python_rule():
+    """m4ri_amd_multi_default_variant is sharding.default_variant moved behind the C boundary: same answer for every world size
+    and shape class (BASELINE.json configs[3] -> Strassen sub-products at 8 ranks, configs[4] -> row slabs at every world size)."""
+    names = {m4ri_amd.VARIANT_SLABS: "slabs", m4ri_amd.VARIANT_STRASSEN: "strassen"}
+    for world in (1, 2, 3, 4, 5, 7, 8, 16):
+        for shape in [(65536, 65536, 65536), (131072, 8192, 131072), (16384, 16384, 16384), (8192, 65536, 65536), (65536, 16384, 8192),
+                      (100003, 50021, 70017), (8190, 16384, 8192)]:
+            assert names[m4ri_amd.multi_default_variant(world, *shape)] == sharding.default_variant(world, *shape), (world, shape)
+    assert m4ri_amd.multi_layout_for(0, 8, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC1
+    assert m4ri_amd.multi_layout_for(0, 8, 131072, 8192, 131072) == m4ri_amd.LAYOUT_ROWS
+    assert m4ri_amd.multi_layout_for(m4ri_amd.VARIANT_STRASSEN, 4, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC2   # 49 products over 4 ranks
+
+
+@pytest.mark.parametrize("layout", [m4ri_amd.LAYOUT_ROWS, m4ri_amd.LAYOUT_CYCLIC1, m4ri_amd.LAYOUT_CYCLIC2])
+@pytest.mark.parametrize("world", [1, 2, 3, 7, 8, 64])
+def test_layout_runs_partition_the_rows(layout, world):
+    """Every valid row of a distributed matrix lives on exactly one rank (ROWS, CYCLIC1, CYCLIC2), inside that rank's local buffer,
+    and the local buffers of the CYCLIC layouts are whole slabs of every row block."""
+    for rows in (1, 63, 256, 1000, 4097, 65536, 100003):
+        seen = [0] * rows if rows <= 5000 else None
+        total = 0
+        for r in range(world):
+            lrows = m4ri_amd.lib().m4ri_amd_layout_local_rows(layout, world, r, rows)
+            for g0, n, l0 in m4ri_amd.layout_runs(layout, world, r, rows):
+                assert n > 0 and 0 <= g0 and g0 + n <= rows and 0 <= l0 and l0 + n <= lrows
+                total += n
+                if seen is not None:
+                    for g in range(g0, g0 + n):
+                        seen[g] += 1
+        assert total == rows and (seen is None or set(seen) == {1}), (layout, world, rows)
+    assert m4ri_amd.layout_runs(m4ri_amd.LAYOUT_REPLICATED, world, world - 1, 77) == [(0, 77, 0)]

@@ -3,7 +3,6 @@ processes.  The block products are done by the CPU oracle here (tests may use it
 stand-in for the device multiply); the partitioning, the pairwise XOR exchange and the ownership of the
 reduced rows are exactly the code bench.py runs under RCCL."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -21,17 +20,15 @@ from m4ri_amd.mzd import Mzd  # noqa: E402
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A token for the rendezvous file name (the ranks meet through a file, not a TCP port)."""
+    _free_port.n = getattr(_free_port, "n", 0) + 1
+    return _free_port.n
 
 
 def _worker(rank, world, port, grid, m, l, n, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to pick, nothing to collide with when suites run side by side
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous_' + str(port))}", rank=rank, world_size=world)
     import cpu_libs
     orc = cpu_libs.oracle()
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)  # every rank regenerates the operands, as bench.py does
@@ -109,8 +106,8 @@ def test_plans_tile_the_product():
 
 def _slab_worker(rank, world, port, m, l, n, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to pick, nothing to collide with when suites run side by side
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous_' + str(port))}", rank=rank, world_size=world)
     import cpu_libs
     orc = cpu_libs.oracle()
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)

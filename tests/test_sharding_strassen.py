@@ -6,7 +6,6 @@ with the device steps replaced by numpy/oracle stand-ins (tests/shard_sim.py).
   * world_size 2 under torch.distributed with the gloo backend -- exactly the transport code bench.py
     runs under RCCL."""
 import os
-import socket
 import sys
 import threading
 
@@ -96,17 +95,15 @@ def test_all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks):
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A token for the rendezvous file name (the ranks meet through a file, not a TCP port)."""
+    _free_port.n = getattr(_free_port, "n", 0) + 1
+    return _free_port.n
 
 
 def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to pick, nothing to collide with when suites run side by side
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous_' + str(port))}", rank=rank, world_size=world)
     import cpu_libs
     orc = cpu_libs.oracle()
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
@@ -194,8 +191,8 @@ def test_products_in_flight_on_two_buffer_slots(oracle, world, levels, chunks, i
 
 def _pipeline_worker(rank, world, port, levels, m, l, n, out_dir, chunks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to pick, nothing to collide with when suites run side by side
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous_' + str(port))}", rank=rank, world_size=world)
     import cpu_libs
     orc = cpu_libs.oracle()
     pairs = [(Mzd.random(m, l, 300 + k), Mzd.random(l, n, 400 + k)) for k in range(4)]

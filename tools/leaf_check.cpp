@@ -167,8 +167,8 @@ int main(int argc, char **argv) {
     timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), 1, 32, 3, 1, atoi(argv[6]));
     return 0;
   }
-  if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch : profile a single variant
-    timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), 3, atoi(argv[3]), atoi(argv[4]));
+  if (argc > 5 && !strcmp(argv[1], "--one")) {  // --one rg ug pipe batch [reps] : profile a single variant (many reps: a power trace)
+    timeit(8192, 8192, 8192, atoi(argv[5]), 1, atoi(argv[2]), argc > 6 ? atoi(argv[6]) : 3, atoi(argv[3]), atoi(argv[4]));
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--v4")) {  // generation 4 alone (build with -DK8Q_BUILDER_HALF=1 for the control experiment)
