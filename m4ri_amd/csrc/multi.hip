@@ -206,6 +206,7 @@ struct Rank {
   hipStream_t st = nullptr, ci = nullptr, co = nullptr;  // compute; inbound copies (operands); outbound copies (result slabs)
   // All events carry timestamps: they double as the marks of the per-phase timeline (m4ri_amd_multi_timeline)
   hipEvent_t ev_start = nullptr, ev_down = nullptr, ev_gather = nullptr, ev_first = nullptr, ev_back = nullptr, ev_done = nullptr;
+  hipEvent_t ev_tl0 = nullptr, ev_tl1 = nullptr;  // first and last mark of the most recent PRODUCT (uploads, downloads, conversions leave them alone)
   std::vector<hipEvent_t> ev_in, ev_prod;  // per unit (round, row chunk) of the Strassen schedule
   bool done_recorded = false;
   word *arena = nullptr;
@@ -239,8 +240,7 @@ struct Pool {
   bool stop    = false;
   std::vector<int> rc;
 
-  void worker(int i) {
-    uint64_t seen = 0;
+  void worker(int i, uint64_t seen) {  // seen: the generation at the time the pool was (re)started -- jobs before it are not this worker's
     for (;;) {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return stop || gen != seen; });
@@ -269,7 +269,7 @@ struct Pool {
     shutdown();
     rc.assign((size_t)n, 0);
     try {
-      for (int i = 0; i < n; ++i) th.emplace_back([this, i] { worker(i); });
+      for (int i = 0; i < n; ++i) th.emplace_back([this, i, g = gen] { worker(i, g); });
     } catch (...) {
       shutdown();
       return (int)hipErrorOutOfMemory;
@@ -350,7 +350,7 @@ void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks
     if (r.arena) (void)hipFree(r.arena);
     for (hipStream_t s : {r.st, r.ci, r.co})
       if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {r.ev_start, r.ev_down, r.ev_gather, r.ev_first, r.ev_back, r.ev_done})
+    for (hipEvent_t e : {r.ev_start, r.ev_down, r.ev_gather, r.ev_first, r.ev_back, r.ev_done, r.ev_tl0, r.ev_tl1})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_prod) (void)hipEventDestroy(e);
@@ -380,7 +380,7 @@ int ensure_ranks() {
       HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
-      for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done}) HIPTRY(hipEventCreate(e));
+      for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done, &r.ev_tl0, &r.ev_tl1}) HIPTRY(hipEventCreate(e));
       for (size_t k = 0; k < g_devices.size(); ++k) {  // direct xGMI copies between every pair
         const int other = g_devices[k];
         int can         = 0;
@@ -511,7 +511,6 @@ int op_begin(Rank &R) {
   HIPTRY(hipEventRecord(R.ev_start, R.st));
   HIPTRY(hipStreamWaitEvent(R.ci, R.ev_start, 0));
   HIPTRY(hipStreamWaitEvent(R.co, R.ev_start, 0));
-  R.tl_valid = false;
   return 0;
 }
 int op_end(Rank &R) {
@@ -594,6 +593,8 @@ int slabs_rank(const SlabOp &op, int me) {
   if (gathered) words[B_GATHER] = (int64_t)W * kb * sbw;
   RTRY(carve(R, words));
   RTRY(op_begin(R));
+  RTRY(hipEventRecord(R.ev_tl0, R.st));
+  R.tl_valid = false;
   word *Cme = op.C->local[(size_t)me];
   const word *Ame = op.A->local[(size_t)me];
   R.tl_strassen = false; R.tl_gathered = gathered; R.tl_units = 0;
@@ -601,6 +602,7 @@ int slabs_rank(const SlabOp &op, int me) {
     if (mr > 0) RTRY(m4ri_amd_mul_dev(Cme, sc, Ame, sa, op.B->local[(size_t)me], sbw, mr, l, n, op.add, op.cutoff, R.st));
     RTRY(hipEventRecord(R.ev_first, R.st));
     RTRY(hipEventRecord(R.ev_gather, R.ci));
+    RTRY(hipEventRecord(R.ev_tl1, R.st));
     R.tl_valid = true;
     return op_end(R);
   }
@@ -637,6 +639,7 @@ int slabs_rank(const SlabOp &op, int me) {
     RTRY(hipStreamWaitEvent(R.st, R.ev_gather, 0));
     if (mr > 0) RTRY(m4ri_amd_mul_dev(Cme, sc, Ame, sa, Bfull, sbw, mr, l, n, op.add, op.cutoff, R.st));
   }
+  RTRY(hipEventRecord(R.ev_tl1, R.st));
   R.tl_valid = true;
   return op_end(R);
 }
@@ -670,6 +673,8 @@ int strassen_rank(const StrassenOp &op, int me) {
   RTRY(carve(R, words));
   RTRY(unit_events(R, (size_t)rounds * (size_t)nch));
   RTRY(op_begin(R));
+  RTRY(hipEventRecord(R.ev_tl0, R.st));
+  R.tl_valid = false;
   R.tl_strassen = true; R.tl_gathered = false; R.tl_units = 0;
   // 1. the level's operand additions on my slabs: no communication
   RTRY(m4ri_amd_shard_down_dev(&p, me, op.A->local[(size_t)me], op.A->stride, op.B->local[(size_t)me], op.B->stride, R.buf[B_CHILD_A], R.buf[B_CHILD_B], R.st));
@@ -733,6 +738,7 @@ int strassen_rank(const StrassenOp &op, int me) {
   RTRY(hipEventRecord(R.ev_back, R.co));
   RTRY(hipStreamWaitEvent(R.st, R.ev_back, 0));
   RTRY(m4ri_amd_shard_up_dev(&p, me, R.buf[B_SLABS_P], op.C->local[(size_t)me], op.C->stride, op.add, R.st));
+  RTRY(hipEventRecord(R.ev_tl1, R.st));
   R.tl_valid = true;
   return op_end(R);
 }
@@ -1145,12 +1151,12 @@ int m4ri_amd_multi_timeline(int rank, double *ms, int cap) {
     marks.push_back(R.ev_gather);
     marks.push_back(R.ev_first);
   }
-  marks.push_back(R.ev_done);
+  marks.push_back(R.ev_tl1);
   int n = 0;
   for (hipEvent_t e : marks) {
     float t = 0;
     if (n >= cap) break;
-    if (hipEventElapsedTime(&t, R.ev_start, e) != hipSuccess) t = -1.0f;
+    if (hipEventElapsedTime(&t, R.ev_tl0, e) != hipSuccess) t = -1.0f;
     ms[n++] = (double)t;
   }
   (void)hipSetDevice(cur);

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <ctime>
 #include <sys/mman.h>
+#include <sys/sysinfo.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -81,6 +82,76 @@ mzd_t *result_init(rci_t r, rci_t c) {
 constexpr size_t BIG_BLOCK = (size_t)8 << 20;
 size_t big_len(size_t bytes) { return (bytes + 4095) & ~(size_t)4095; }
 
+// The allocator's cache of large blocks (the counterpart of the reference's m4ri_mmc cache, mmc.c:44-116, which keeps the blocks
+// BELOW the L3 size; this one keeps the few huge ones): m4ri_amd_mzd_free parks up to two mappings, at most 4 GiB together, and the
+// next allocation of exactly that size takes one back -- its pages are already faulted in, which is the whole cost of a fresh
+// 512 MiB result (33 ... 87 ms).  m4ri_amd_release_workspace() returns them to the system.
+struct BigCache {
+  std::mutex mu;
+  struct Slot { void *p = nullptr; size_t len = 0; } slot[2];
+  void *take(size_t len) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (Slot &s : slot)
+      if (s.p && s.len == len) { void *p = s.p; s = Slot{}; return p; }
+    return nullptr;
+  }
+  bool park(void *p, size_t len) {
+    static const bool enabled = !(getenv("M4RI_AMD_RESULT_CACHE") && atoi(getenv("M4RI_AMD_RESULT_CACHE")) == 0);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t held = 0;
+    for (Slot &s : slot) held += s.len;
+    if (!enabled || held + len > ((size_t)4 << 30)) return false;
+    for (Slot &s : slot)
+      if (!s.p) { s.p = p; s.len = len; return true; }
+    return false;
+  }
+  void drop() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (Slot &s : slot) {
+      if (s.p) munmap(s.p, s.len);
+      s = Slot{};
+    }
+  }
+} g_big_cache;
+
+void *big_map(size_t len) {  // a fresh 2 MiB-aligned mapping: zero pages on demand
+  const size_t al = (size_t)2 << 20;
+  char *raw = static_cast<char *>(mmap(nullptr, len + al, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (raw == MAP_FAILED) return nullptr;
+  char *q = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + al - 1) & ~(uintptr_t)(al - 1));
+  if (q > raw) munmap(raw, (size_t)(q - raw));
+  if (raw + len + al > q + len) munmap(q + len, (size_t)((raw + len + al) - (q + len)));
+  return q;
+}
+
+void zero_with_threads(char *p, size_t bytes) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = hw >= 256 ? 32 : hw >= 64 ? 16 : 8, per = ((bytes / nt) + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  size_t at = 0;
+  try {
+    for (; at < bytes; at += per) {
+      const size_t len = bytes - at < per ? bytes - at : per;
+      th.emplace_back([=] { memset(p + at, 0, len); });
+    }
+  } catch (...) {  // no more threads to be had: the rest here
+    if (at < bytes) memset(p + at, 0, bytes - at);
+  }
+  for (std::thread &t : th) t.join();
+}
+
+mzd_t *descriptor(rci_t r, rci_t c) {  // mzd.c:142-150
+  mzd_t *A = static_cast<mzd_t *>(calloc(1, sizeof(mzd_t)));
+  if (!A) return nullptr;
+  A->nrows        = r;
+  A->ncols        = c;
+  A->width        = c > 0 ? (c - 1) / 64 + 1 : 0;
+  A->rowstride    = (A->width & 1) ? A->width + 1 : A->width;
+  A->high_bitmask = (~(word)0) >> ((64 - c % 64) % 64);
+  A->flags        = (A->high_bitmask != ~(word)0) ? 0x2 : 0;  // mzd.h:144: non-zero excess
+  return A;
+}
+
 // A result that is still on its way.  mzd_mul(NULL, A, B, cutoff) is the region the reference's own bench times
 // (bench/bench_multiplication.c:85-107), and a fresh 512 MiB matrix costs 33 ... 87 ms of page faults and clearing -- more than
 // the 65536^3 product it receives -- when that happens in front of the upload.  Nothing needs C before the first block of the
@@ -121,10 +192,38 @@ void late_begin(LateC &lc, rci_t r, rci_t c) {
     }
     return;
   }
-  lc.C = m4ri_amd_mzd_init(r, c);
-  const size_t bytes = (size_t)r * (size_t)lc.C->rowstride * 8;
-  if (bytes < BIG_BLOCK) return;
-  char *base = reinterpret_cast<char *>(lc.C->data);
+  // this library's allocator.  The product overwrites every valid word of the result, so a parked block of the same size is taken
+  // as it is (its padding words cleared when rows have one); a block the cache does not have is a fresh mapping
+  mzd_t *C = descriptor(r, c);
+  if (!C) die("m4ri_amd: out of memory\n");
+  lc.C = C;
+  const size_t bytes = (size_t)r * (size_t)C->rowstride * 8, len = big_len(bytes);
+  if (void *p = g_big_cache.take(len)) {
+    C->data = static_cast<word *>(p);
+    if (C->rowstride != C->width) zero_with_threads(static_cast<char *>(p), bytes);
+    return;
+  }
+  char *base = static_cast<char *>(big_map(len));
+  if (!base) die("m4ri_amd: out of memory\n");
+  C->data = reinterpret_cast<word *>(base);
+  // How the pages of a NEW block come into being (M4RI_AMD_FRESH, a developer switch; measured in profiles/r04_fresh_result/):
+  //   populate   worker threads fault them in beside the upload and the products (MADV_POPULATE_WRITE never changes a byte, so it
+  //              may run beside the downloads; where the kernel lacks it, an atomic OR of zero per page)
+  //   huge       the same after MADV_HUGEPAGE;  lazy: nothing, the downloads fault them;  zero: cleared by threads here and now
+  //   auto (default): huge when memory is plentiful, else populate
+  // Measured on the GPU box, 65536^3, every result a new block (profiles/r04_fresh_result.log; C given: 42.6 ms): huge 58 ... 61 ms,
+  // populate 75 ... 86, lazy 73 ... 78, zero 68 ... 82 -- and 43.8 ms when the cache above has the block.  Huge pages are asked for only
+  // when memory is plentiful (8 x the block available): on a host short of memory MADV_HUGEPAGE makes every fault compact memory
+  // synchronously (a first 512 MiB block took 0.7 ... 1.7 s in the 8 GiB build container).
+  static const char *mode_env = getenv("M4RI_AMD_FRESH");
+  char mode = mode_env ? mode_env[0] : 'a';
+  if (mode == 'a') {
+    struct sysinfo si;
+    mode = (sysinfo(&si) == 0 && (double)si.freeram * (double)si.mem_unit >= 8.0 * (double)bytes) ? 'h' : 'p';
+  }
+  if (mode == 'l') return;
+  if (mode == 'z') { zero_with_threads(base, bytes); return; }
+  if (mode == 'h') (void)madvise(base, len, 14 /* MADV_HUGEPAGE */);
   const unsigned hw = std::thread::hardware_concurrency();
   const size_t nt = hw >= 64 ? 16 : hw >= 16 ? 8 : 2, chunk = (size_t)16 << 20;
   // the workers walk the block front to back in 16 MiB chunks, round robin: the rows the first download will write come first
@@ -133,13 +232,11 @@ void late_begin(LateC &lc, rci_t r, rci_t c) {
       lc.populate.emplace_back([base, bytes, k, nt, chunk] {
         bool advise = true;
         for (size_t at = k * chunk; at < bytes; at += nt * chunk) {
-          const size_t len = bytes - at < chunk ? bytes - at : chunk;
-          if (advise && madvise(base + at, big_len(len), MADV_POPULATE_WRITE) == 0) continue;
-          // a kernel (or sandbox) without MADV_POPULATE_WRITE: fault every page with an atomic OR of zero -- a write access that cannot
-          // change a byte, so it too may run beside the download that fills the page
+          const size_t n = bytes - at < chunk ? bytes - at : chunk;
+          if (advise && madvise(base + at, big_len(n), MADV_POPULATE_WRITE) == 0) continue;
           advise = false;
           g_api_stats.populate_fallback = 1;
-          for (size_t off = 0; off < len; off += 4096) __atomic_fetch_or(reinterpret_cast<unsigned char *>(base + at + off), (unsigned char)0, __ATOMIC_RELAXED);
+          for (size_t off = 0; off < n; off += 4096) __atomic_fetch_or(reinterpret_cast<unsigned char *>(base + at + off), (unsigned char)0, __ATOMIC_RELAXED);
         }
       });
   } catch (...) {  // fewer (or no) helpers: the downloads fault what is left
@@ -579,29 +676,19 @@ void pin_upload(Pin &p) {
 extern "C" {
 
 mzd_t *m4ri_amd_mzd_init(rci_t r, rci_t c) {  // mzd.c:142-157
-  mzd_t *A = static_cast<mzd_t *>(calloc(1, sizeof(mzd_t)));
+  mzd_t *A = descriptor(r, c);
   if (!A) die("m4ri_amd_mzd_init: out of memory\n");
-  A->nrows        = r;
-  A->ncols        = c;
-  A->width        = c > 0 ? (c - 1) / 64 + 1 : 0;
-  A->rowstride    = (A->width & 1) ? A->width + 1 : A->width;
-  A->high_bitmask = (~(word)0) >> ((64 - c % 64) % 64);
-  A->flags        = (A->high_bitmask != ~(word)0) ? FLAG_EXCESS : 0;
   if (r && c) {
     void *p = nullptr;
     const size_t bytes = (size_t)r * (size_t)A->rowstride * 8;
     if (bytes >= BIG_BLOCK) {
-      // large blocks: their own mapping, 2 MiB-aligned (whole transparent huge pages where the system serves them) -- the kernel hands
-      // out zero pages, so nothing is cleared here and no page is touched before somebody needs it: a fresh 512 MiB result used to cost
-      // 87 ms of page faults under one memset (33 ms under 32 threads), more than the 65536^3 product it receives.  (No MADV_HUGEPAGE:
-      // with the usual defrag = madvise setting it makes every fault compact memory synchronously.)
-      const size_t len = big_len(bytes), al = (size_t)2 << 20;
-      char *raw = static_cast<char *>(mmap(nullptr, len + al, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
-      if (raw == MAP_FAILED) die("m4ri_amd_mzd_init: out of memory\n");
-      char *q = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + al - 1) & ~(uintptr_t)(al - 1));
-      if (q > raw) munmap(raw, (size_t)(q - raw));
-      if (raw + len + al > q + len) munmap(q + len, (size_t)((raw + len + al) - (q + len)));
-      p = q;
+      // large blocks: a mapping of their own, 2 MiB-aligned (whole transparent huge pages where the system serves them) -- the kernel
+      // hands out zero pages, so nothing is cleared and no page is touched before somebody needs it (a fresh 512 MiB block used to
+      // cost 87 ms of page faults under one memset, 33 ms under 32 threads); a parked block of that size is cleared and reused.
+      // (No MADV_HUGEPAGE: with the usual defrag = madvise setting it makes every fault compact memory synchronously.)
+      const size_t len = big_len(bytes);
+      if ((p = g_big_cache.take(len)) != nullptr) zero_with_threads(static_cast<char *>(p), bytes);
+      else if ((p = big_map(len)) == nullptr) die("m4ri_amd_mzd_init: out of memory\n");
     } else {
       if (posix_memalign(&p, 64, bytes)) die("m4ri_amd_mzd_init: out of memory\n");
       memset(p, 0, bytes);
@@ -615,8 +702,9 @@ void m4ri_amd_mzd_free(mzd_t *A) {  // mzd.c:179-185
   if (!A) return;
   if (!(A->flags & FLAG_WINDOW) && A->data) {
     const size_t bytes = (size_t)A->nrows * (size_t)A->rowstride * 8;
-    if (bytes >= BIG_BLOCK) munmap(A->data, big_len(bytes));  // m4ri_amd_mzd_init: large blocks are mappings of their own
-    else free(A->data);
+    if (bytes >= BIG_BLOCK) {  // m4ri_amd_mzd_init: large blocks are mappings of their own; the cache may keep this one
+      if (!g_big_cache.park(A->data, big_len(bytes))) munmap(A->data, big_len(bytes));
+    } else free(A->data);
   }
   free(A);
 }
@@ -1100,7 +1188,8 @@ void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L)
   HIPDIE(hipDeviceSynchronize());
 }
 
-void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena
+void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena, the parked result blocks
+  g_big_cache.drop();
   std::lock_guard<std::mutex> lk(g_api_mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) return;

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401 -- before libm4ri_amd.so: the process gets ONE HIP runtime, the one torch ships
 
 import m4ri_amd
 from m4ri_amd import Dmat
@@ -156,7 +157,6 @@ def test_row_chunks_and_the_timeline():
         units = 2 if r < 7 else 0
         assert len(marks) == 1 + 2 * units + 2 and all(t >= 0 for t in marks), (r, marks)
         assert marks[0] <= marks[-2] <= marks[-1] and all(marks[1 + 2 * u] <= marks[2 + 2 * u] for u in range(units)), (r, marks)
-    import torch
     A = torch.empty((n, n // 64), dtype=torch.int64, device="cuda")
     B, C = torch.empty_like(A), torch.empty_like(A)
     m4ri_amd.fill_dev(A.data_ptr(), n // 64, n, n, 3)

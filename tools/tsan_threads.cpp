@@ -1,0 +1,80 @@
+// tools/tsan_threads.cpp -- the threading contract of the host entry points under ThreadSanitizer (developer tool; the
+// bit-exactness of the same pattern is tests/test_gpu_threads.py).  Four host threads call mzd_mul / mzd_addmul / mzd_mul_m4rm on
+// their own matrices, pin / chain / unpin, two of them go through mzd_mul_mp on virtual ranks, all at once; every thread compares
+// with the product the main thread computed alone beforehand.  Built by tools/build_tsan.sh against a -fsanitize=thread build of
+// the library's HOST code (the device code is not instrumented; races between kernels are the determinism stress tests' business).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "../include/m4ri_amd.h"
+
+static uint64_t splitmix(uint64_t &s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static mzd_t *random_matrix(rci_t r, rci_t c, uint64_t seed) {
+  mzd_t *M = m4ri_amd_mzd_init(r, c);
+  for (rci_t i = 0; i < r; ++i) {
+    for (wi_t k = 0; k < M->width; ++k) M->data[(int64_t)i * M->rowstride + k] = splitmix(seed);
+    M->data[(int64_t)i * M->rowstride + M->width - 1] &= M->high_bitmask;
+  }
+  return M;
+}
+
+static bool same(const mzd_t *X, const mzd_t *Y) {
+  for (rci_t i = 0; i < X->nrows; ++i)
+    if (memcmp(X->data + (int64_t)i * X->rowstride, Y->data + (int64_t)i * Y->rowstride, (size_t)X->width * 8)) return false;
+  return true;
+}
+
+int main(int argc, char **argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 3;
+  const int shapes[4][3] = {{1100, 1290, 1411}, {2048, 2048, 4096}, {513, 700, 65}, {1536, 1536, 1536}};
+  if (m4ri_amd_init(0)) { fprintf(stderr, "no device\n"); return 2; }
+  const int ids[3] = {0, 0, 0};
+  m4ri_amd_set_devices(3, ids);
+  m4ri_amd_set_multi_threshold(512);
+  mzd_t *A[4], *B[4], *want[4];
+  for (int i = 0; i < 4; ++i) {
+    A[i] = random_matrix(shapes[i][0], shapes[i][1], 100 + i);
+    B[i] = random_matrix(shapes[i][1], shapes[i][2], 200 + i);
+    want[i] = mzd_mul(NULL, A[i], B[i], 0);
+  }
+  int bad[4] = {0, 0, 0, 0};
+  std::vector<std::thread> th;
+  for (int i = 0; i < 4; ++i)
+    th.emplace_back([&, i] {
+      if (m4ri_amd_init(0)) { bad[i] = 100; return; }
+      for (int r = 0; r < reps; ++r) {
+        mzd_t *C = mzd_mul(NULL, A[i], B[i], r % 2 ? 0 : 256);
+        bad[i] += !same(C, want[i]);
+        mzd_addmul(C, A[i], B[i], 0);  // C ^= A*B: zero
+        mzd_t *Z = m4ri_amd_mzd_init(C->nrows, C->ncols);
+        bad[i] += !same(C, Z);
+        mzd_t *D = mzd_mul_m4rm(NULL, A[i], B[i], 0);
+        bad[i] += !same(D, want[i]);
+        if (i < 2) {  // the multi-device entry point (virtual ranks), two threads at once
+          mzd_t *E = mzd_mul_mp(NULL, A[i], B[i], 0);
+          bad[i] += !same(E, want[i]);
+          m4ri_amd_result_free(E);
+        } else {      // residency: pin, chain on the device, unpin
+          m4ri_amd_pin(A[i]); m4ri_amd_pin(B[i]); m4ri_amd_pin(Z);
+          mzd_addmul(Z, A[i], B[i], 0);
+          m4ri_amd_unpin(Z); m4ri_amd_unpin(B[i]); m4ri_amd_unpin(A[i]);
+          bad[i] += !same(Z, want[i]);
+        }
+        m4ri_amd_result_free(C); m4ri_amd_result_free(D); m4ri_amd_mzd_free(Z);
+      }
+    });
+  for (auto &t : th) t.join();
+  int total = 0;
+  for (int i = 0; i < 4; ++i) { printf("thread %d: %d mismatches\n", i, bad[i]); total += bad[i]; }
+  m4ri_amd_release_workspace();
+  printf("%s\n", total ? "TSAN_THREADS FAILED" : "TSAN_THREADS results ok");
+  return total != 0;
+}
