@@ -341,7 +341,7 @@ int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
    recursion -- same bits.  Returns the previous value; negative arguments only query. */
 int64_t m4ri_amd_set_workspace_budget(int64_t bytes);
 
-/* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..3, default 3;
+/* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..4, default 3;
    a scheduling knob: results are bit-identical for every value).  Returns the previous value;
    out-of-range arguments only query. */
 int m4ri_amd_set_max_fuse(int levels);

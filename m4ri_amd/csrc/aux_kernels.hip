@@ -805,6 +805,298 @@ extern "C" hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *
   return hipGetLastError();
 }
 
+// ---- four levels at once ---------------------------------------------------------------------------
+// The three-level passes with ONE MORE level on top, formed on the fly: the ancestor is a 16 x 16 grid of blocks; workgroup
+// (position block, j0) builds block (a, b), a, b < 8, of top-level child j0 from the up to four grid blocks (a, b), (a, b + 8),
+// (a + 8, b), (a + 8, b + 8) while it loads, then runs the three-level expansion of that child in registers and writes its 343
+// outputs at index 343 * j0 + 49 * j1 + 7 * j2 + j3 -- exactly what a single-level pass followed by a three-level pass produces, without
+// the 7/4-size intermediate level ever being written or read.  The seven workgroups of one position block read overlapping
+// grid blocks (14 quadrant reads for 4 quadrants); they are numbered 8 apart, so they run on the SAME XCD (workgroup b -> XCD
+// b % 8) within a few dispatches of each other and meet in its L2: HBM sees every ancestor word about once.
+// Up: the three-level recombination of the 343 products of top-level product j0 gives its 8 x 8 blocks, which are scattered into the
+// quadrants that product belongs to (winograd_scatter) by no-return L2 atomic XOR into a zeroed (or, accumulating, the caller's) C.
+namespace {
+
+// blockIdx.x -> (position block, j0): b = (hi * 7 + j0) * 8 + lo, position block = hi * 8 + lo
+__device__ __forceinline__ void pass4_block(int64_t b, int64_t &pb, int &j0) {
+  const int64_t lo = b & 7, rest = b >> 3;
+  j0 = (int)(rest % 7);
+  pb = (rest / 7) * 8 + lo;
+}
+inline int64_t pass4_grid(int64_t nposblocks) { return ((nposblocks + 7) / 8) * 7 * 8; }
+
+// block (a, b) of top-level child j (wave-uniform) of the 2 x 2 split whose quadrants are `qr` rows / `qc` words apart: only the
+// quadrants the child needs are loaded
+template <bool BSIDE>
+__device__ __forceinline__ word load_top_child(const word *q11, int64_t qr, int64_t qc, int j) {
+  const word *q12 = q11 + qc, *q21 = q11 + qr, *q22 = q11 + qr + qc;
+  if (!BSIDE) {  // [A11, A12, S4, A22, S1, S2, S3]
+    switch (j) {
+      case 0: return *q11;
+      case 1: return *q12;
+      case 2: return *q12 ^ *q21 ^ *q22 ^ *q11;
+      case 3: return *q22;
+      case 4: return *q21 ^ *q22;
+      case 5: return *q21 ^ *q22 ^ *q11;
+      default: return *q11 ^ *q21;
+    }
+  } else {       // [B11, B21, B22, T4, T1, T2, T3]
+    switch (j) {
+      case 0: return *q11;
+      case 1: return *q21;
+      case 2: return *q22;
+      case 3: return *q22 ^ *q12 ^ *q11 ^ *q21;
+      case 4: return *q12 ^ *q11;
+      case 5: return *q22 ^ *q12 ^ *q11;
+      default: return *q22 ^ *q12;
+    }
+  }
+}
+
+// (Tried and measured, profiles/r04_depth4_fused/: ONE workgroup of seven waves per 64 positions, wave = j0, so that the siblings'
+// loads are issued at the same moment -- slower, down4 1.37 -> 1.46 ms, up4 1.34 -> 1.61 ms: one 448-thread workgroup per CU.)
+template <bool BSIDE, bool NT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down4_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,  // ancestor array: 16 * crows rows x 16 * cw words each
+    word *__restrict__ gchild, int64_t c_bs,                       // 2401 descendants per ancestor, stride == cw
+    int64_t crows, int64_t cw, int64_t nposblocks) {
+  int64_t pb;
+  int j0;
+  pass4_block(blockIdx.x, pb, j0);
+  const int64_t i = pb * AUX_THREADS + threadIdx.x, pi = blockIdx.y;
+  if (pb >= nposblocks || i >= crows * cw) return;
+  const int64_t r = i / cw, w = i - r * cw;
+  const word *p   = anc + pi * p_bs + r * p_stride + w;
+  word x[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) x[a][b] = load_top_child<BSIDE>(p + (int64_t)a * crows * p_stride + (int64_t)b * cw, 8 * crows * p_stride, 8 * cw, j0);
+  word *c = gchild + (pi * 2401 + 343 * j0) * c_bs + r * cw + w;
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c1[a][b] = winograd_child<word, BSIDE>(x[a][b], x[a][b + 4], x[a + 4][b], x[a + 4][b + 4], j1);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      word c2[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, BSIDE>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) {
+        const word v = winograd_child<word, BSIDE>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        if (NT) __builtin_nontemporal_store(v, &c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs]);
+        else c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs] = v;
+      }
+    }
+  }
+}
+
+// out[a][b] ^-> block (a, b) of the quadrants T11 ... T22 of the ancestor (no-return L2 atomics)
+template <bool T11, bool T12, bool T21, bool T22>
+__device__ __forceinline__ void up4_scatter(const word (&out)[8][8], char *ob, uint32_t lane_b, int64_t qr, int64_t qc, int64_t br, int64_t bc) {
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      char *bb = ob + a * br + b * bc;  // wave-uniform
+      const unsigned long long v = out[a][b];
+      if (T11) atomicXor(reinterpret_cast<unsigned long long *>(bb + lane_b), v);
+      if (T12) atomicXor(reinterpret_cast<unsigned long long *>(bb + qc + lane_b), v);
+      if (T21) atomicXor(reinterpret_cast<unsigned long long *>(bb + qr + lane_b), v);
+      if (T22) atomicXor(reinterpret_cast<unsigned long long *>(bb + qr + qc + lane_b), v);
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_up4_kernel(
+    const word *__restrict__ prod, int64_t p_bs,            // 2401 products per ancestor, stride == cw
+    word *__restrict__ anc, int64_t o_stride, int64_t o_bs, // ancestor array, zeroed (or holding the matrix to accumulate onto)
+    int64_t crows, int64_t cw, int64_t nposblocks) {
+  int64_t pb;
+  int j0;
+  pass4_block(blockIdx.x, pb, j0);
+  const int64_t i = pb * AUX_THREADS + threadIdx.x, pi = blockIdx.y;
+  if (pb >= nposblocks || i >= crows * cw) return;
+  const int64_t r = i / cw, w = i - r * cw;
+  const word *q   = prod + (pi * 2401 + 343 * j0) * p_bs + r * cw + w;
+  word out[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) out[a][b] = 0;
+  // The 343 products are consumed in 49 groups of 7 (one j2 each), software-pipelined by hand: group g + 1 is loaded, then group g
+  // folded.  The scheduling barriers keep the memory operations in this order -- left alone, the compiler issues all 343 loads up
+  // front and spills most of them (it does not in the three-level kernel, whose tail is plain stores)
+  word buf[2][7];
+  auto load_group = [&](int g, word (&dst)[7]) {
+#pragma unroll
+    for (int j3 = 0; j3 < 7; ++j3) dst[j3] = NT ? __builtin_nontemporal_load(&q[(int64_t)(7 * g + j3) * p_bs]) : q[(int64_t)(7 * g + j3) * p_bs];
+  };
+  load_group(0, buf[0]);
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c1[a][b] = 0;
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      const int g = 7 * j1 + j2;
+      if (g + 1 < 49) load_group(g + 1, buf[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // nothing crosses: the loads of group g + 1 are in flight while group g is folded
+      word c2[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) winograd_scatter<word>(buf[g & 1][j3], j3, c2[0][0], c2[0][1], c2[1][0], c2[1][1]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) winograd_scatter<word>(c2[a][b], j2, c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) winograd_scatter<word>(c1[a][b], j1, out[a][b], out[a][b + 4], out[a + 4][b], out[a + 4][b + 4]);
+  }
+  // (the folds stay HERE: without the pins the optimiser sinks the whole XOR tree into each of the seven cases below and keeps all 343
+  // loaded products alive across the branch)
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(out[a][b]));
+  // top level: product j0 belongs to the quadrants winograd_scatter names; seven workgroups add into every word.  Addresses are a
+  // wave-uniform base (block, quadrant) + ONE 32-bit per-lane byte offset, so the 64 x (1 ... 4) atomics need no address registers
+  const uint32_t lane_b = (uint32_t)((r * o_stride + w) * 8);  // the launcher keeps one quadrant row range below 2 GiB
+  char *ob              = reinterpret_cast<char *>(anc + pi * o_bs);
+  const int64_t qr = 8 * crows * o_stride * 8, qc = 8 * cw * 8, br = crows * o_stride * 8, bc = cw * 8;  // bytes
+  switch (j0) {
+    case 0: up4_scatter<true, true, true, true>(out, ob, lane_b, qr, qc, br, bc); break;
+    case 1: up4_scatter<true, false, false, false>(out, ob, lane_b, qr, qc, br, bc); break;
+    case 2: up4_scatter<false, true, false, false>(out, ob, lane_b, qr, qc, br, bc); break;
+    case 3: up4_scatter<false, false, true, false>(out, ob, lane_b, qr, qc, br, bc); break;
+    case 4: up4_scatter<false, true, false, true>(out, ob, lane_b, qr, qc, br, bc); break;
+    case 5: up4_scatter<false, true, true, true>(out, ob, lane_b, qr, qc, br, bc); break;
+    default: up4_scatter<false, false, true, true>(out, ob, lane_b, qr, qc, br, bc); break;
+  }
+}
+
+template <int ROT, bool NT>
+__global__ __launch_bounds__(DP3_THREADS) void winograd_down4_pack_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
+    uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed descendants, a4_bs dwords each
+    int64_t crows, int64_t cw, int64_t tiles_r, int64_t tiles_w) {
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][DP3_ROWS * DP3_PITCH];
+  int64_t tb_;
+  int j0;
+  pass4_block(blockIdx.x, tb_, j0);
+  if (tb_ >= tiles_r * tiles_w) return;   // (whole workgroups leave: no barrier is missed)
+  const int64_t wt = tb_ % tiles_w, rt = tb_ / tiles_w, pi = blockIdx.y;
+  const int t = threadIdx.x, r = t >> 4, v = t & 15;
+  const word *p = anc + pi * p_bs + (rt * DP3_ROWS + r) * p_stride + (wt * DP3_W + v);
+  word x[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) x[a][b] = load_top_child<false>(p + (int64_t)a * crows * p_stride + (int64_t)b * cw, 8 * crows * p_stride, 8 * cw, j0);
+  const int q = t >> 4, r2 = (t & 15) * 2;
+  const int64_t orow = rt * DP3_ROWS + r2;
+  const uint32_t rot = ROT == 1 ? (uint32_t)((orow >> 6) & 3) : ROT == 2 ? (uint32_t)((orow >> 7) & 3) : 0u;
+  const int64_t oq   = (wt * (DP3_W * 2) + q) ^ (ROT == 2 ? ((orow >> 5) & 1) : 0);
+  uint32_t *o = a4 + (pi * 2401 + 343 * j0) * a4_bs + oq * crows + orow;
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c1[a][b] = winograd_child<word, false>(x[a][b], x[a][b + 4], x[a + 4][b], x[a + 4][b + 4], j1);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      word c2[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, false>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) {
+        const int k  = 49 * j1 + 7 * j2 + j3;
+        uint32_t *tb = tile[k & 1];
+        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
+            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        __syncthreads();
+        const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);
+        uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + rs], w1 = tb[(r2 + 1) * DP3_PITCH + rs];
+        if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
+        if (NT) __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)w1 << 32), reinterpret_cast<unsigned long long *>(o + (int64_t)k * a4_bs));
+        else *reinterpret_cast<uint2 *>(o + (int64_t)k * a4_bs) = make_uint2(w0, w1);
+      }
+    }
+  }
+}
+}  // namespace
+
+// Descendant 343 * j0 + 49 * j1 + 7 * j2 + j3 of ancestor i is stored at index 2401 * i + that; descendants are crows x cw words,
+// contiguous; an ancestor is 16 * crows rows x 16 * cw words with row stride p_stride.
+extern "C" hipError_t gf2_launch_winograd_down4(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs,
+                                                word *gchild, int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t c_bs = crows * cw;
+  if (nparents * c_bs == 0) return hipSuccess;
+  const int64_t nposblocks = (c_bs + AUX_THREADS - 1) / AUX_THREADS, grid = pass4_grid(nposblocks);
+  if (grid > 0x7fffffffLL || nparents > 65535) return hipErrorInvalidValue;
+#define D4_LAUNCH(BS, NT)                                                                                                             \
+  hipLaunchKernelGGL((winograd_down4_kernel<BS, NT>), dim3((unsigned)grid, (unsigned)nparents), dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs, gchild, \
+                     c_bs, crows, cw, nposblocks)
+  if (pass_nt() & 1) { if (bside) D4_LAUNCH(true, true); else D4_LAUNCH(false, true); }
+  else { if (bside) D4_LAUNCH(true, false); else D4_LAUNCH(false, false); }
+#undef D4_LAUNCH
+  return hipGetLastError();
+}
+
+// anc (+)= the recombination of the 2401 products per ancestor.  acc == 0: the ancestor's 16 crows x 16 cw words are zeroed first (the
+// seven top-level products of a word meet in it by atomic XOR); acc != 0: they are added onto what is there.
+extern "C" hipError_t gf2_launch_winograd_up4(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs,
+                                              int64_t nparents, int64_t crows, int64_t cw) {
+  const int64_t p_bs = crows * cw;
+  if (nparents * p_bs == 0) return hipSuccess;
+  const int64_t nposblocks = (p_bs + AUX_THREADS - 1) / AUX_THREADS, grid = pass4_grid(nposblocks);
+  if (grid > 0x7fffffffLL || nparents > 65535 || (crows * o_stride + cw) * 8 >= (1ll << 31)) return hipErrorInvalidValue;
+  if (!acc)
+    for (int64_t i = 0; i < nparents; ++i) {
+      const hipError_t e = gf2_launch_rowwise(s, 2, anc + i * o_bs, o_stride, nullptr, 0, nullptr, 0, 16 * crows, 16 * cw);
+      if (e != hipSuccess) return e;
+    }
+  if (pass_nt() & 2)
+    hipLaunchKernelGGL((winograd_up4_kernel<true>), dim3((unsigned)grid, (unsigned)nparents), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows,
+                       cw, nposblocks);
+  else
+    hipLaunchKernelGGL((winograd_up4_kernel<false>), dim3((unsigned)grid, (unsigned)nparents), dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows,
+                       cw, nposblocks);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4,
+                                                     int64_t nparents, int64_t crows, int64_t cw, int rot) {
+  if (nparents * crows * cw == 0) return hipSuccess;
+  if (!gf2_winograd_down3_pack_ok(a4, crows, cw)) return hipErrorInvalidValue;
+  const int64_t tiles_r = crows / DP3_ROWS, tiles_w = cw / DP3_W;
+  const int64_t grid = pass4_grid(tiles_r * tiles_w);
+  if (grid > 0x7fffffffLL || nparents > 65535) return hipErrorInvalidValue;
+#define DP4_LAUNCH(R, NT)                                                                                                                     \
+  hipLaunchKernelGGL((winograd_down4_pack_kernel<R, NT>), dim3((unsigned)grid, (unsigned)nparents), dim3(DP3_THREADS), 0, s, anc, p_stride, p_bs, \
+                     reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, tiles_r, tiles_w)
+  if (pass_nt() & 4) { if (rot == 2) DP4_LAUNCH(2, true); else if (rot == 1) DP4_LAUNCH(1, true); else DP4_LAUNCH(0, true); }
+  else { if (rot == 2) DP4_LAUNCH(2, false); else if (rot == 1) DP4_LAUNCH(1, false); else DP4_LAUNCH(0, false); }
+#undef DP4_LAUNCH
+  return hipGetLastError();
+}
+
 // Two levels per pass.  Grandchildren are crows x cw words, contiguous; a grandparent is 4*crows rows
 // x 4*cw words with row stride p_stride; grandchild 7*j1 + j2 of grandparent i is stored at index
 // 49*i + 7*j1 + j2.

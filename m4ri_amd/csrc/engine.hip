@@ -38,6 +38,12 @@ hipError_t gf2_launch_winograd_down3_pack(hipStream_t s, const word *anc, int64_
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_winograd_down2_pack(hipStream_t s, const word *gparent, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
+hipError_t gf2_launch_winograd_down4(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *gchild,
+                                     int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_up4(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs,
+                                   int64_t nparents, int64_t crows, int64_t cw);
+hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4,
+                                          int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
 int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
@@ -76,7 +82,7 @@ constexpr int64_t PART_SLABS  = 768;  // slabs (256 KiB each) a split generation
 #ifndef LEAF_MIN_SPLIT_BITS_G4
 #define LEAF_MIN_SPLIT_BITS_G4 128  // the same for generation 4 (slabs + reduce pass)
 #endif
-int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..3); m4ri_amd_set_max_fuse
+int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..4); m4ri_amd_set_max_fuse
 constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
 constexpr int DEFAULT_CUTOFF_M = 4096; // ... and m/2 >= this (one generation-4 tile row)
 constexpr int DEFAULT_CUTOFF_N = 4096; // ... and n/2 >= this (8 column tiles)
@@ -420,7 +426,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t pas = d0 == 0 ? A.stride : (l >> d0) / 64;
     const uint64_t a4_bytes = (uint64_t)gf2_m4rm8_a4_words(m >> L, l >> L, 1) * 8;  // one packed operand: 32-bit offsets
     prepack = a4_bytes < (1ull << 32) &&
-              (fuse == 3 ? gf2_winograd_down3_pack_ok(aligned16, m >> L, (l >> L) / 64) != 0
+              (fuse >= 3 ? gf2_winograd_down3_pack_ok(aligned16, m >> L, (l >> L) / 64) != 0
                          : gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? 0 : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0);
   }
   // workspace plan
@@ -465,7 +471,12 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
     const int rot = leaf_kind.gen == 4 ? 1 : 0;  // the leaf's pre-rotated index bytes (pack mode)
-    if (step == 3) {
+    if (step == 4) {  // four levels in one pass each way: the top one formed on the fly (aux_kernels.hip)
+      if (prepack) HIPTRY(gf2_launch_winograd_down4_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
+      else HIPTRY(gf2_launch_winograd_down4(st, 0, pa, pas, pabs, Al[d + 4], cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_winograd_down4(st, 1, pb, pbs, pbbs, Bl[d + 4], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * 2657.0 * ((double)cm * (cl / 64) + (double)cl * (cn / 64));  // 256 in + 2401 out
+    } else if (step == 3) {
       if (prepack) HIPTRY(gf2_launch_winograd_down3_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down3(st, 0, pa, pas, pabs, Al[d + 3], cnt, cm, cl / 64));
       HIPTRY(gf2_launch_winograd_down3(st, 1, pb, pbs, pbbs, Bl[d + 3], cnt, cl, cn / 64));
@@ -499,7 +510,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
     const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
-    if (step == 3 && acc && acc_tmp) {
+    if (step == 4) {
+      HIPTRY(gf2_launch_winograd_up4(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (2401.0 + 512.0 + (acc ? 0.0 : 256.0));  // products in, every word read + written once, the clear
+    } else if (step == 3 && acc && acc_tmp) {
       HIPTRY(gf2_launch_winograd_up3(st, 0, Pl[d], acc_tmp, n / 64, 0, cnt, cm, cn / 64));
       HIPTRY(gf2_launch_rowwise(st, 0, C.p, C.stride, C.p, C.stride, acc_tmp, n / 64, m, n / 64));
       e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * 407.0 + 8.0 * 3.0 * (double)m * (n / 64);
@@ -779,7 +793,7 @@ int64_t m4ri_amd_set_workspace_budget(int64_t bytes) {
 int m4ri_amd_set_max_fuse(int levels) {
   std::lock_guard<std::mutex> lk(g_cfg_mu);
   const int old = g_max_fuse;
-  if (levels >= 1 && levels <= 3) g_max_fuse = levels;
+  if (levels >= 1 && levels <= 4) g_max_fuse = levels;
   return old;
 }
 

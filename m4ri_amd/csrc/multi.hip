@@ -476,8 +476,10 @@ m4ri_amd_dmat *dmat_new(int64_t rows, int64_t ncols, int layout) {  // g_multi_m
     d->device[(size_t)r] = g_ranks[(size_t)r]->device;
     d->lrows[(size_t)r]  = local_rows_of(layout, W, r, rows);
     const size_t bytes   = (size_t)(d->lrows[(size_t)r] > 0 ? d->lrows[(size_t)r] : 1) * (size_t)d->stride * 8;
+    // the padding is zero from here on: every operation keeps it so.  The clear runs on the NULL stream, which the ranks' non-blocking
+    // streams do not wait for: it has to be complete before the handle exists
     ok = hipSetDevice(d->device[(size_t)r]) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d->local[(size_t)r]), bytes) == hipSuccess &&
-         hipMemset(d->local[(size_t)r], 0, bytes) == hipSuccess;  // the padding is zero from here on: every operation keeps it so
+         hipMemset(d->local[(size_t)r], 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   }
   (void)hipSetDevice(cur);
   if (!ok) {
@@ -526,6 +528,10 @@ int carve(Rank &r, const int64_t *words) {
   size_t need = 0;
   for (int k = 0; k < B_COUNT; ++k) need += (size_t)pad32(words[k] > 0 ? words[k] : 0);
   if (need > r.cap) {
+    // the old arena goes away: OTHER ranks may still be pulling slabs out of it (their part of the previous operation, on their
+    // devices), so everybody's previous operation has to be over, not just this device's
+    for (auto &other : g_ranks)
+      if (other->done_recorded) HIPTRY(hipEventSynchronize(other->ev_done));
     HIPTRY(hipDeviceSynchronize());
     if (r.arena) HIPTRY(hipFree(r.arena));
     r.arena = nullptr; r.cap = 0;

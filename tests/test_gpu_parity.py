@@ -369,6 +369,42 @@ def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
         m4ri_amd.set_max_fuse(old)
 
 
+@pytest.mark.parametrize("m,l,n,cutoff,add,strided", [
+    (8192, 8192, 8192, 512, False, False),     # 2401 leaves of 512^3: the four-level passes, packed A from the pass itself
+    (4096, 5120, 4096, 256, True, False),      # accumulate: the atomic top level adds onto C; 5-word leaf rows: plain passes + separate pack
+    (16384, 8192, 8192, 512, False, True),     # operands and result inside wider parents (strided ancestors), 1024-row leaves
+    (16384 + 40, 8192 + 70, 8192 + 130, 512, True, False),   # remainder strips around the even block
+])
+def test_four_level_fused_passes(oracle, m, l, n, cutoff, add, strided):
+    """Four levels in one pass each way (aux_kernels.hip winograd_down4 / down4_pack / up4: the three-level passes with the top level
+    formed on the fly, the seven top-level products of a word meeting by atomic XOR): a scheduling choice like the others -- fusing
+    4, 3 or 1 levels must not change a bit."""
+    hA, hB, hC = Mzd.random(m, l, 81), Mzd.random(l, n, 82), Mzd.random(m, n, 83)
+    pad = 6 if strided else 0          # words of a wider parent to the right of every operand
+    wa, wn = hA.rowstride + pad, hB.rowstride + pad
+
+    def dev(h, stride):
+        t = torch.full((h.nrows, stride), -1, dtype=torch.int64, device="cuda")
+        t[:, :h.rowstride] = torch.from_numpy(h.rows().view(np.int64).copy()).cuda()
+        return t
+    A, B, C0 = dev(hA, wa), dev(hB, wn), dev(hC, wn)
+    want = oracle.addmul(hC.copy(), hA, hB, cutoff) if add else oracle.mul(None, hA, hB, cutoff)
+    old = m4ri_amd.set_max_fuse(0)
+    try:
+        for fuse in (4, 3, 1):
+            m4ri_amd.set_max_fuse(fuse)
+            C = C0.clone()
+            m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wa, B.data_ptr(), wn, m, l, n, add=add, cutoff=cutoff)
+            st = m4ri_amd.get_stats()
+            assert st.levels == 4
+            got = Mzd(m, n)
+            got.rows()[:, :] = C[:, :hC.rowstride].cpu().numpy().view(np.uint64)
+            assert got.equal(want), f"max_fuse={fuse}"
+            assert bool((C[:, hC.rowstride:] == -1).all()), f"max_fuse={fuse}: words of the parent outside C were written"
+    finally:
+        m4ri_amd.set_max_fuse(old)
+
+
 def test_randomized_shapes_windows_cutoffs(oracle):
     """Seeded fuzz through the C ABI: random shapes, cutoffs, mul/addmul, operands and results that are
     windows of larger parents (column offsets on word boundaries, mzd.c:161), checked word for word
