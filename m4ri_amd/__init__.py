@@ -206,6 +206,9 @@ SYMBOLS = {
     "m4ri_amd_get_device_list": (_I, [ctypes.POINTER(_I), _I]),
     "m4ri_amd_set_multi_threshold": (_I64, [_I64]),
     "m4ri_amd_release_workspace": (None, []),
+    "m4ri_amd_set_small_product_threshold": (_I64, [_I64]),
+    "m4ri_amd_small_product_count": (_I64, []),
+    "m4ri_amd_small_mul_host": (_I, [MzdPtr, MzdPtr, MzdPtr, _I]),
     "m4ri_amd_dmat_create": (_P, [_I64, _I64, _I]),
     "m4ri_amd_dmat_free": (None, [_P]),
     "m4ri_amd_dmat_info": (_I, [_P, ctypes.POINTER(DmatInfo)]),
@@ -610,6 +613,22 @@ def layout_runs(layout: int, world: int, rank: int, rows: int) -> list:
 
 def set_multi_variant(variant: int) -> int:
     return lib().m4ri_amd_set_multi_variant(variant)
+
+
+def set_small_product_threshold(ops: int) -> int:
+    """m * l * n at or below which a product from host memory is computed on the host (0: never); returns the previous value."""
+    return int(lib().m4ri_amd_set_small_product_threshold(int(ops)))
+
+
+def small_product_count() -> int:
+    return int(lib().m4ri_amd_small_product_count())
+
+
+def small_mul_host(C: Mzd, A: Mzd, B: Mzd, add: bool = False) -> Mzd:
+    """The host Four Russians of the small-product path, called directly (no device involved)."""
+    if lib().m4ri_amd_small_mul_host(C.ptr, A.ptr, B.ptr, int(add)) != 0:
+        raise ValueError("m4ri_amd_small_mul_host: mismatched dimensions")
+    return C
 
 
 def pin(M: Mzd) -> None:

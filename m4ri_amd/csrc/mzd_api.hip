@@ -378,6 +378,10 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 // so of the 1.5 GiB over PCIe at 65536^3 only the first pair of blocks (256 MiB) and the last block of C (128 MiB) stay
 // exposed.  Same bits as the one-shot schedule (every step is an ordinary product or addmul).  Returns false when the
 // product is too small to pay for it.
+// m * l * n at or below which a product from host memory is computed on the host (m4ri_amd_set_small_product_threshold; the measured
+// crossover against the reference on the GPU box, profiles/r04_crossover_cpu_gpu.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
+int64_t g_small_threshold = getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 24);
+int64_t g_small_count     = 0;  // products that took the host path (under g_api_mu)
 size_t g_pipeline_min_bytes = (size_t)64 << 20;  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
@@ -536,6 +540,13 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   HIPDIE(m4ri_amd_init(dev));
   const bool same = (A == B);
   Pin *pinC = late ? nullptr : find_pin(C);
+  // products the launch / PCIe floor of a call would dominate: this library's own host Four Russians (small_host.cpp), on an
+  // initialised device and only for matrices that live in host memory (a pinned operand is already on the GPU)
+  if (!late && !pinC && g_small_threshold > 0 && (double)cm * (double)A->ncols * (double)cn <= (double)g_small_threshold && !find_pin(A) && !find_pin(B)) {
+    if (m4ri_amd_small_mul_host(C, A, B, add ? 1 : 0)) die("m4ri_amd: small product failed (internal error)\n");
+    g_small_count += 1;
+    return C;
+  }
   if (strassen && !same && !pinC && !find_pin(A) && !find_pin(B) && run_pipelined(C, A, B, add, cutoff, late)) return late ? late->get() : C;
   // a pinned C whose last word is shared with other columns of its parent is computed in staging and
   // merged under the column mask; otherwise the engine writes straight into the parent
@@ -770,6 +781,18 @@ mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {  // br
 mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear) {  // brilliantrussian.c:1032
   (void)k;
   return run(C, A, B, clear == 0, false, 0);
+}
+
+int64_t m4ri_amd_set_small_product_threshold(int64_t ops) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  const int64_t old = g_small_threshold;
+  if (ops >= 0) g_small_threshold = ops;
+  return old;
+}
+
+int64_t m4ri_amd_small_product_count(void) {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  return g_small_count;
 }
 
 // A + B + C bytes from which the host entry points pipeline a product over row slabs (0: never); returns the previous value

@@ -27,3 +27,14 @@ def reference():
     if ref is None:
         pytest.skip("oracle/_ref/libm4ri_ref.so not built (needs /root/reference: `make -C oracle ref`)")
     return ref
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _every_product_on_the_gpu():
+    """The parity tests are about the HIP path: in this process every product goes to the GPU, however small.  (The library's host
+    routine for tiny products has its own tests, test_small_products.py, which switch its threshold back on; programs the tests
+    start -- bench.py, the LD_PRELOAD driver -- run with the library's default.)"""
+    import m4ri_amd
+    old = m4ri_amd.set_small_product_threshold(0)
+    yield
+    m4ri_amd.set_small_product_threshold(old)

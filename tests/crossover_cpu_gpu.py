@@ -31,6 +31,30 @@ def best(fn, reps):
 
 m4ri_amd.init(0)
 ref, omp = cpu_libs.reference(), cpu_libs.reference(openmp=True)
+# ---- small products: the reference, the GPU path whatever the size (threshold 0) and the library's host routine (small_host.cpp),
+#      all through mzd_mul on host matrices: where the library's size switch belongs
+print(f"{'n':>6} | {'ref seq us':>10} | {'gpu path us':>11} {'host routine us':>15} | m*l*n")
+old = m4ri_amd.set_small_product_threshold(0)
+for n in (32, 64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 1024):
+    A, B, C = Mzd.random(n, n, 3), Mzd.random(n, n, 4), Mzd.init(n, n)
+    t_seq = best(lambda: ref.mul(C, A, B, 0), 20) if ref else float("nan")
+    want = C.copy()
+    m4ri_amd.set_small_product_threshold(0)
+    t_gpu = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 20)
+    assert C.equal(want)
+    m4ri_amd.set_small_product_threshold(1 << 62)
+    t_host = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 20)
+    assert C.equal(want)
+    print(f"{n:6d} | {t_seq * 1e6:10.1f} | {t_gpu * 1e6:11.1f} {t_host * 1e6:15.1f} | 2^{(3 * n.bit_length() - 3)}", flush=True)
+for (m, l, n) in ((1000, 10, 20), (16, 4096, 16), (4096, 16, 64), (64, 64, 4096), (2048, 64, 64)):
+    A, B, C = Mzd.random(m, l, 3), Mzd.random(l, n, 4), Mzd.init(m, n)
+    t_seq = best(lambda: ref.mul(C, A, B, 0), 20) if ref else float("nan")
+    m4ri_amd.set_small_product_threshold(0)
+    t_gpu = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 20)
+    m4ri_amd.set_small_product_threshold(1 << 62)
+    t_host = best(lambda: m4ri_amd.mzd_mul(C, A, B, 0), 20)
+    print(f"{m}x{l}x{n}: ref {t_seq * 1e6:.1f} us | gpu path {t_gpu * 1e6:.1f} us, host routine {t_host * 1e6:.1f} us | m*l*n = {m * l * n:.2e}", flush=True)
+m4ri_amd.set_small_product_threshold(old)
 print(f"{'n':>6} | {'ref seq ms':>10} {'ref omp ms':>10} | {'gpu host ms':>11} {'gpu pinned ms':>13} | speedup vs best cpu (host / pinned)")
 for n in (512, 1024, 2048, 4096, 8192, 16384, 32768):
     A, B, C = Mzd.random(n, n, 3), Mzd.random(n, n, 4), Mzd.init(n, n)

@@ -1,0 +1,91 @@
+"""Products below the GPU's crossover: the library's own host Method of Four Russians (m4ri_amd/csrc/small_host.cpp; the
+counterpart of the reference's switch to mzd_mul_naive inside _mzd_mul_m4rm, m4ri/brilliantrussian.c:1063-1068,
+m4ri/mzd.c:1141-1172).  The routine itself against the oracle on the reference's own shape lists (no GPU needed); on the GPU box,
+that the entry points take it exactly when they should and never when an operand lives on the device."""
+import numpy as np
+import pytest
+
+import m4ri_amd
+import shapes
+from m4ri_amd.mzd import Mzd
+
+
+@pytest.mark.parametrize("m,l,n,k,cutoff", shapes.MUL + shapes.EDGE)
+def test_host_routine_mul_vs_oracle(oracle, m, l, n, k, cutoff):
+    A, B = Mzd.random(m, l, shapes.seed_of(m, l, n, 1)), Mzd.random(l, n, shapes.seed_of(m, l, n, 2))
+    C = Mzd.random(m, n, 5)                       # a dirty C is overwritten, its excess bits end up zero
+    m4ri_amd.small_mul_host(C, A, B, False)
+    assert C.equal(oracle.mul(None, A, B, 0)) and not (C.rows()[:, C.width:] != 0).any()
+    if m and n and n % 64:
+        assert not (C.valid_words()[:, -1] & ~np.uint64(C.high_bitmask)).any()
+
+
+@pytest.mark.parametrize("m,l,n,k,cutoff", shapes.ADDMUL + [(5, 0, 7, 0, 0)])
+def test_host_routine_addmul_vs_oracle(oracle, m, l, n, k, cutoff):
+    A, B, C = Mzd.random(m, l, 11), Mzd.random(l, n, 12), Mzd.random(m, n, 13)
+    want = oracle.addmul(C.copy(), A, B, 0) if l else C.copy()
+    assert m4ri_amd.small_mul_host(C, A, B, True).equal(want)
+
+
+def test_host_routine_squares_and_empty_inner(oracle):
+    for n in (1, 64, 131, 193, 300):
+        A = Mzd.random(n, n, 21 + n)
+        assert m4ri_amd.small_mul_host(Mzd.init(n, n), A, A, False).equal(oracle.mul(None, A, A, 0))
+    for (m, l, n) in shapes.EMPTY_INNER:
+        C = Mzd.random(m, n, 3)
+        m4ri_amd.small_mul_host(C, Mzd.init(m, l), Mzd.init(l, n), False)
+        assert not C.valid_words().any()
+
+
+@pytest.mark.parametrize("M,N,m,n", shapes.SMALLOPS)
+def test_host_routine_windows_keep_their_parents(oracle, M, N, m, n):
+    """Operands and result are windows with dirty bits around them (tests/test_smallops.c:115-121): every bit of C's parent outside
+    the window survives, the bits of A's and B's parents outside their windows do not leak in."""
+    PA, PB, PC = Mzd.random(M, N, 31), Mzd.random(M, N, 32), Mzd.random(M, N, 33)
+    lowc = 64 if N - 64 >= max(m, n) else 0
+    a, b = PA.window(0, 0, m, n), PB.window(1 if M > n else 0, lowc, (1 if M > n else 0) + n, lowc + m)
+    c = PC.window(M - m, 0, M, m)
+    want_parent = Mzd(M, N, buf=PC.buf.copy())
+    co = want_parent.window(M - m, 0, M, m)
+    oracle.mul(co, a.copy(), b.copy(), 0)
+    m4ri_amd.small_mul_host(c, a, b, False)
+    assert np.array_equal(PC.buf, want_parent.buf)
+    oracle.addmul(co, a.copy(), b.copy(), 0)
+    m4ri_amd.small_mul_host(c, a, b, True)
+    assert np.array_equal(PC.buf, want_parent.buf)
+
+
+def test_threshold_is_a_plain_setting():
+    old = m4ri_amd.set_small_product_threshold(12345)
+    assert m4ri_amd.set_small_product_threshold(-1) == 12345 and m4ri_amd.set_small_product_threshold(old) == 12345
+
+
+@pytest.mark.gpu
+def test_entry_points_take_the_host_routine_exactly_when_they_should(oracle):
+    assert m4ri_amd.lib().m4ri_amd_device_count() >= 1
+    m4ri_amd.init(0)
+    old = m4ri_amd.set_small_product_threshold(1 << 24)
+    try:
+        for (m, l, n) in [(1, 1, 1), (64, 64, 64), (21, 171, 31), (193, 65, 65), (256, 256, 256), (1000, 10, 20)]:
+            A, B, C0 = Mzd.random(m, l, 41), Mzd.random(l, n, 42), Mzd.random(m, n, 43)
+            before = m4ri_amd.small_product_count()
+            assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0))
+            assert m4ri_amd.mzd_addmul(C0.copy(), A, B, 0).equal(oracle.addmul(C0.copy(), A, B, 0))
+            assert m4ri_amd.mzd_mul_m4rm(None, A, B, 0).equal(oracle.mul(None, A, B, 0))
+            assert m4ri_amd.small_product_count() == before + 3, (m, l, n)
+        A, B = Mzd.random(300, 300, 44), Mzd.random(300, 300, 45)        # 2.7e7 > 2^24: the GPU
+        before = m4ri_amd.small_product_count()
+        assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0)) and m4ri_amd.small_product_count() == before
+        A, B, C = Mzd.random(128, 128, 46), Mzd.random(128, 128, 47), Mzd.init(128, 128)
+        for M in (A, B, C):                                               # operands on the device: the product goes where they are
+            m4ri_amd.pin(M)
+        m4ri_amd.mzd_mul(C, A, B, 0)
+        assert m4ri_amd.small_product_count() == before and m4ri_amd.is_pinned(C) == 2
+        for M in (A, B, C):
+            m4ri_amd.unpin(M)
+        assert C.equal(oracle.mul(None, A, B, 0))
+        m4ri_amd.set_small_product_threshold(0)
+        A, B = Mzd.random(64, 64, 48), Mzd.random(64, 64, 49)
+        assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0)) and m4ri_amd.small_product_count() == before
+    finally:
+        m4ri_amd.set_small_product_threshold(old)
