@@ -396,24 +396,40 @@ def run_rung(transport: str, n_ranks: int, argv: list, watchdog_s: float):
 
 def controller(args) -> int:
     """`bench.py --gpus N` as a command: start the ranks, watch them, fall back down the ladder rccl -> peer, and end with exactly
-    one JSON line either way (the reference switches to its multi-core path inside the same command, bench/bench_multiplication.c:94-103)."""
+    one JSON line either way (the reference switches to its multi-core path inside the same command, bench/bench_multiplication.c:94-103).
+    With `--transport auto` on the real backend BOTH transports are measured when both work -- the same product through two complete
+    implementations -- and the line is the faster one's, the other's numbers beside it (`config.transports_measured`)."""
     ladder = {"auto": ["rccl", "peer"], "rccl": ["rccl"], "peer": ["peer"]}[args.transport]
     if args.variant == "blocks" or args.layout == "owner":
         ladder = [t for t in ladder if t == "rccl"] or ["rccl"]  # scatter / gather layouts exist over torch.distributed only
-    failed = []
+    measure_all = args.transport == "auto" and args.backend == "nccl" and len(ladder) > 1
+    failed, done = [], {}
     for transport in ladder:
         line, why, rest = run_rung(transport, args.gpus, sys.argv[1:], args.watchdog)
         for ln in rest:
             print(ln, flush=True)
         if line is not None:
-            out = json.loads(line)
-            out["config"]["transport"] = transport
-            out["config"]["transport_fallback"] = failed
-            print(json.dumps(out), flush=True)
-            return 0
-        failed.append({"transport": transport, "reason": why})
-    print(json.dumps({"error": f"no transport completed the {args.gpus}-GPU run", "gpus_requested": args.gpus, "transport_fallback": failed}), flush=True)
-    return 1
+            done[transport] = json.loads(line)
+            if not measure_all:
+                break
+        else:
+            failed.append({"transport": transport, "reason": why})
+    if not done:
+        print(json.dumps({"error": f"no transport completed the {args.gpus}-GPU run", "gpus_requested": args.gpus, "transport_fallback": failed}), flush=True)
+        return 1
+    best = min(done, key=lambda t: done[t]["ms_per_step"])
+    out = done[best]
+    out["config"]["transport"] = best
+    first_ok = min(ladder.index(t) for t in done)
+    out["config"]["transport_fallback"] = [f for f in failed if ladder.index(f["transport"]) < first_ok]
+    later = [f for f in failed if ladder.index(f["transport"]) > first_ok]
+    if later:
+        out["config"]["transports_unavailable"] = later
+    if len(done) > 1:
+        out["config"]["transports_measured"] = {t: {"value": d["value"], "ms_per_step": d["ms_per_step"], "host_issue_ms_per_step": d.get("host_issue_ms_per_step")}
+                                                for t, d in done.items()}
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------
