@@ -380,7 +380,7 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 // product is too small to pay for it.
 // m * l * n at or below which a product from host memory is computed on the host (m4ri_amd_set_small_product_threshold; the measured
 // crossover against the reference on the GPU box, profiles/r04_crossover_cpu_gpu.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
-int64_t g_small_threshold = getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 24);
+int64_t g_small_threshold = getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 26);
 int64_t g_small_count     = 0;  // products that took the host path (under g_api_mu)
 size_t g_pipeline_min_bytes = (size_t)64 << 20;  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];

@@ -9,8 +9,9 @@
 // interposing.  This is an algorithm choice made on an initialised device, never a fallback: a HIP failure still aborts, and the
 // library still refuses to work without its GPU (the entry points bind the device before they look at the size).
 //
-// Own code, the textbook algorithm: the inner dimension in groups of 8 rows of B, one 256-entry table of their XOR combinations
-// per group (built by doubling), every row of A looks its byte up and adds the entry to an accumulator row; windows (row stride
+// Own code, the textbook algorithm: the inner dimension in groups of 4 or 8 rows of B (by the number of rows of A), one table of
+// their XOR combinations per group (built by doubling), every row of A looks its nibble / byte up and adds the entry to an
+// accumulator row; fewer than 16 rows add B's rows bit by bit; windows (row stride
 // larger than the width, dirty bits beyond the last column) are handled by masking what is read and merging what is written
 // under the column mask (mzd.h:117-123).
 #include <cstdint>
@@ -41,24 +42,23 @@ extern "C" int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B,
     for (rci_t i = 0; i < m; ++i)
       for (wi_t k = 0; k < wn; ++k) acc[(size_t)i * wn + k] = rd(C, i, k);
   if (l > 0) {
-    if (m < 64) {
-      // a handful of rows: a table of 256 combinations per 8 rows of B would cost more than it saves -- add B's rows bit by bit
-      std::vector<word> brow((size_t)wn);
-      for (rci_t j = 0; j < l; ++j) {
-        bool any = false;
-        for (rci_t i = 0; i < m && !any; ++i) any = (rd(A, i, j / 64) >> (j % 64)) & 1;
-        if (!any) continue;
-        for (wi_t k = 0; k < wn; ++k) brow[(size_t)k] = rd(B, j, k);
-        for (rci_t i = 0; i < m; ++i)
-          if ((rd(A, i, j / 64) >> (j % 64)) & 1) {
-            word *a = &acc[(size_t)i * wn];
-            for (wi_t k = 0; k < wn; ++k) a[k] ^= brow[(size_t)k];
+    if (m < 16) {
+      // a handful of rows: tables would cost more than they save -- every set bit of A adds one row of B
+      for (rci_t i = 0; i < m; ++i) {
+        word *a = &acc[(size_t)i * wn];
+        for (wi_t q = 0; q < wl; ++q)
+          for (word bitsleft = rd(A, i, q); bitsleft; bitsleft &= bitsleft - 1) {
+            const rci_t j = (rci_t)(q * 64 + __builtin_ctzll(bitsleft));
+            for (wi_t k = 0; k < wn; ++k) a[k] ^= rd(B, j, k);
           }
       }
     } else {
-      std::vector<word> table((size_t)256 * (size_t)wn);
-      for (rci_t g0 = 0; g0 < l; g0 += 8) {
-        const int bits = (l - g0) < 8 ? (int)(l - g0) : 8;
+      // groups of K rows of B, one table of their 2^K XOR combinations per group; per inner bit that costs (2^K + m) / K row
+      // operations: K = 4 below 224 rows, K = 8 above (both divide 64: a group never straddles a word of A)
+      const int K = m < 224 ? 4 : 8;
+      std::vector<word> table(((size_t)1 << K) * (size_t)wn);
+      for (rci_t g0 = 0; g0 < l; g0 += K) {
+        const int bits = (l - g0) < K ? (int)(l - g0) : K;
         // table[x] = XOR of the rows g0 + b of B with bit b of x set, by doubling: the second half of every step is the first
         // half plus one more row
         std::memset(table.data(), 0, (size_t)wn * 8);
@@ -70,8 +70,8 @@ extern "C" int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B,
             for (wi_t k = 0; k < wn; ++k) dst[k] = src[k] ^ rd(B, g0 + b, k);
           }
         }
-        const wi_t aw     = g0 / 64;       // a group of 8 never straddles a word: g0 is a multiple of 8
-        const int shift   = g0 % 64;
+        const wi_t aw      = g0 / 64;
+        const int shift    = g0 % 64;
         const word lowbits = ((word)1 << bits) - 1;
         for (rci_t i = 0; i < m; ++i) {
           const size_t x = (size_t)((rd(A, i, aw) >> shift) & lowbits);
@@ -82,7 +82,6 @@ extern "C" int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B,
         }
       }
     }
-    (void)wl;
   }
   // the result, under the column mask: bits of C's last word beyond its columns keep their value in a window and end up zero otherwise
   const bool window = (C->flags & FLAG_WINDOW) != 0;

@@ -64,7 +64,7 @@ def test_threshold_is_a_plain_setting():
 def test_entry_points_take_the_host_routine_exactly_when_they_should(oracle):
     assert m4ri_amd.lib().m4ri_amd_device_count() >= 1
     m4ri_amd.init(0)
-    old = m4ri_amd.set_small_product_threshold(1 << 24)
+    old = m4ri_amd.set_small_product_threshold(1 << 24)  # (the test pins its own threshold)
     try:
         for (m, l, n) in [(1, 1, 1), (64, 64, 64), (21, 171, 31), (193, 65, 65), (256, 256, 256), (1000, 10, 20)]:
             A, B, C0 = Mzd.random(m, l, 41), Mzd.random(l, n, 42), Mzd.random(m, n, 43)
