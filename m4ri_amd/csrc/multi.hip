@@ -203,7 +203,13 @@ enum Buf { B_CHILD_A = 0, B_CHILD_B, B_SLABS_P, B_OPER_A, B_OPER_B, B_PROD, B_GA
 
 struct Rank {
   int device         = 0;
-  hipStream_t st = nullptr, ci = nullptr, co = nullptr;  // compute; inbound copies (operands); outbound copies (result slabs)
+  hipStream_t st = nullptr, ci = nullptr, co = nullptr;  // compute; the JOIN streams of the inbound (operand) and outbound (result) copies
+  // One copy stream per peer and direction: copies on ONE stream run one after the other, so the pieces a rank pulls from its W - 1
+  // peers go on W - 1 streams and all links of the rank carry data at once (what one group of RCCL send/recvs gives the other
+  // transport); the join streams wait for the link streams' events and carry the events everybody else waits for
+  std::vector<hipStream_t> lin, lout;   // link streams, indexed by the peer rank
+  std::vector<hipEvent_t> ev_lin, ev_lout;
+  std::vector<char> lin_used, lout_used;  // this link stream has copies the next join has not collected yet
   // All events carry timestamps: they double as the marks of the per-phase timeline (m4ri_amd_multi_timeline)
   hipEvent_t ev_start = nullptr, ev_down = nullptr, ev_gather = nullptr, ev_first = nullptr, ev_back = nullptr, ev_done = nullptr;
   hipEvent_t ev_tl0 = nullptr, ev_tl1 = nullptr;  // first and last mark of the most recent PRODUCT (uploads, downloads, conversions leave them alone)
@@ -347,6 +353,10 @@ void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks
     if (r.st) (void)hipStreamSynchronize(r.st);
     if (r.ci) (void)hipStreamSynchronize(r.ci);
     if (r.co) (void)hipStreamSynchronize(r.co);
+    for (auto *v : {&r.lin, &r.lout})
+      for (hipStream_t ls : *v) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
+    for (auto *v : {&r.ev_lin, &r.ev_lout})
+      for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     if (r.arena) (void)hipFree(r.arena);
     for (hipStream_t s : {r.st, r.ci, r.co})
       if (s) (void)hipStreamDestroy(s);
@@ -380,6 +390,20 @@ int ensure_ranks() {
       HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
+      for (size_t k = 0; k < g_devices.size(); ++k) {
+        hipStream_t a = nullptr, b = nullptr;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        HIPTRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        r.lin.push_back(a);
+        HIPTRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+        r.lout.push_back(b);
+        HIPTRY(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+        r.ev_lin.push_back(ea);
+        HIPTRY(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+        r.ev_lout.push_back(eb);
+      }
+      r.lin_used.assign(g_devices.size(), 0);
+      r.lout_used.assign(g_devices.size(), 0);
       for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done, &r.ev_tl0, &r.ev_tl1}) HIPTRY(hipEventCreate(e));
       for (size_t k = 0; k < g_devices.size(); ++k) {  // direct xGMI copies between every pair
         const int other = g_devices[k];
@@ -513,6 +537,22 @@ int op_begin(Rank &R) {
   HIPTRY(hipEventRecord(R.ev_start, R.st));
   HIPTRY(hipStreamWaitEvent(R.ci, R.ev_start, 0));
   HIPTRY(hipStreamWaitEvent(R.co, R.ev_start, 0));
+  for (hipStream_t ls : R.lin) HIPTRY(hipStreamWaitEvent(ls, R.ev_start, 0));
+  for (hipStream_t ls : R.lout) HIPTRY(hipStreamWaitEvent(ls, R.ev_start, 0));
+  return 0;
+}
+// the join stream collects what the link streams have been given since the last join: afterwards an event recorded on it means
+// "all of those copies are done"
+int join_links(Rank &R, bool inbound) {
+  std::vector<hipStream_t> &ls = inbound ? R.lin : R.lout;
+  std::vector<hipEvent_t> &ev  = inbound ? R.ev_lin : R.ev_lout;
+  std::vector<char> &used      = inbound ? R.lin_used : R.lout_used;
+  for (size_t k = 0; k < ls.size(); ++k)
+    if (used[k]) {
+      HIPTRY(hipEventRecord(ev[k], ls[k]));
+      HIPTRY(hipStreamWaitEvent(inbound ? R.ci : R.co, ev[k], 0));
+      used[k] = 0;
+    }
   return 0;
 }
 int op_end(Rank &R) {
@@ -619,8 +659,12 @@ int slabs_rank(const SlabOp &op, int me) {
   for (int k = op.overlap ? 1 : 0; k < W; ++k) {
     const int s      = (me + k) % W;
     const int64_t g0 = kb * s < l ? kb * s : l, g1 = (g0 + kb) < l ? (g0 + kb) : l;
-    if (g1 > g0) RTRY(copy_words(Bfull + g0 * sbw, R.device, op.B->local[(size_t)s], op.B->device[(size_t)s], (g1 - g0) * sbw, R.ci));
+    if (g1 > g0) {
+      RTRY(copy_words(Bfull + g0 * sbw, R.device, op.B->local[(size_t)s], op.B->device[(size_t)s], (g1 - g0) * sbw, R.lin[(size_t)s]));
+      R.lin_used[(size_t)s] = 1;
+    }
   }
+  RTRY(join_links(R, true));
   RTRY(hipEventRecord(R.ev_gather, R.ci));
   if (op.overlap) {
     // own slab first (resident: nothing to wait for), then what lies before and after it in the gathered B
@@ -697,10 +741,12 @@ int strassen_rank(const StrassenOp &op, int me) {
     Rank &H = *g_ranks[(size_t)r];
     if (!waited[r]) {
       if (int e = wait_flag(H.flag_down, op.seq)) return e;
-      HIPTRY(hipStreamWaitEvent(R.ci, H.ev_down, 0));
+      HIPTRY(hipStreamWaitEvent(R.lin[(size_t)r], H.ev_down, 0));
       waited[r] = true;
     }
-    return copy_words(R.buf[side ? B_OPER_B : B_OPER_A] + pc.owner_off, R.device, H.buf[side ? B_CHILD_B : B_CHILD_A] + pc.holder_off, H.device, pc.words, R.ci);
+    R.lin_used[(size_t)r] = 1;
+    return copy_words(R.buf[side ? B_OPER_B : B_OPER_A] + pc.owner_off, R.device, H.buf[side ? B_CHILD_B : B_CHILD_A] + pc.holder_off, H.device, pc.words,
+                      R.lin[(size_t)r]);
   };
   int units = 0;
   for (int q = 0; q < rounds; ++q) {
@@ -712,6 +758,7 @@ int strassen_rank(const StrassenOp &op, int me) {
       if (c == 0)
         for (int k = 0; k < W; ++k) RTRY(pull_operand(1, j, (me + k) % W));  // the whole B operand, own slab first
       for (int r = lo; r < hi; ++r) RTRY(pull_operand(0, j, r));
+      RTRY(join_links(R, true));
       RTRY(hipEventRecord(R.ev_in[(size_t)units], R.ci));
       RTRY(hipStreamWaitEvent(R.st, R.ev_in[(size_t)units], 0));
       const int64_t row0 = cut_of(p.bm, W, lo), rows = cut_of(p.bm, W, hi) - row0;
@@ -738,9 +785,11 @@ int strassen_rank(const StrassenOp &op, int me) {
     Rank &O     = *g_ranks[(size_t)pc.owner];
     const int u = (j / W) * nch + myc;
     RTRY(wait_flag(O.flag_prod, op.seq * 4096 + u + 1));
-    RTRY(hipStreamWaitEvent(R.co, O.ev_prod[(size_t)u], 0));
-    RTRY(copy_words(R.buf[B_SLABS_P] + pc.holder_off, R.device, O.buf[B_PROD] + pc.owner_off, O.device, pc.words, R.co));
+    RTRY(hipStreamWaitEvent(R.lout[(size_t)pc.owner], O.ev_prod[(size_t)u], 0));
+    RTRY(copy_words(R.buf[B_SLABS_P] + pc.holder_off, R.device, O.buf[B_PROD] + pc.owner_off, O.device, pc.words, R.lout[(size_t)pc.owner]));
+    R.lout_used[(size_t)pc.owner] = 1;
   }
+  RTRY(join_links(R, false));
   RTRY(hipEventRecord(R.ev_back, R.co));
   RTRY(hipStreamWaitEvent(R.st, R.ev_back, 0));
   RTRY(m4ri_amd_shard_up_dev(&p, me, R.buf[B_SLABS_P], op.C->local[(size_t)me], op.C->stride, op.add, R.st));
@@ -865,7 +914,10 @@ int sync_all() {
   int rc = 0;
   for (auto &r : g_ranks) {
     if (hipSetDevice(r->device) != hipSuccess) { rc = (int)hipErrorInvalidDevice; continue; }
-    for (hipStream_t s : {r->ci, r->co, r->st}) {
+    std::vector<hipStream_t> all = r->lin;
+    all.insert(all.end(), r->lout.begin(), r->lout.end());
+    all.insert(all.end(), {r->ci, r->co, r->st});
+    for (hipStream_t s : all) {
       const hipError_t e = hipStreamSynchronize(s);
       if (e != hipSuccess && !rc) rc = (int)e;
     }
