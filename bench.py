@@ -469,7 +469,7 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"],
                     help="N > 1: rccl = one process per GPU over torch.distributed; peer = one process, all GPUs, m4ri_amd_dmat_mul (peer copies); "
                          "auto = rccl, falling back to peer when the ranks fail or do not finish within --watchdog seconds")
-    ap.add_argument("--watchdog", type=float, default=420.0, help="N > 1: seconds one rung of the transport ladder may take before its processes are killed")
+    ap.add_argument("--watchdog", type=float, default=240.0, help="N > 1: seconds one rung of the transport ladder may take before its processes are killed")
     ap.add_argument("--virtual-ranks", action="store_true",
                     help="peer transport: allow more ranks than visible GPUs (ranks share devices round robin: how a one-GPU box tests the path)")
     ap.add_argument("--inner", action="store_true", help="internal: this process is a rank / the single process of a rung the controller started")
