@@ -353,10 +353,27 @@ void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks
     if (r.st) (void)hipStreamSynchronize(r.st);
     if (r.ci) (void)hipStreamSynchronize(r.ci);
     if (r.co) (void)hipStreamSynchronize(r.co);
-    for (auto *v : {&r.lin, &r.lout})
-      for (hipStream_t ls : *v) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
-    for (auto *v : {&r.ev_lin, &r.ev_lout})
-      for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    for (auto *v : {&r.lin, &r.lout}) {  // (capped link streams appear several times: destroy each once)
+      std::vector<hipStream_t> seen;
+      for (hipStream_t ls : *v) {
+        bool dup = false;
+        for (hipStream_t x : seen) dup = dup || x == ls;
+        if (dup) continue;
+        seen.push_back(ls);
+        (void)hipStreamSynchronize(ls);
+        (void)hipStreamDestroy(ls);
+      }
+    }
+    for (auto *v : {&r.ev_lin, &r.ev_lout}) {
+      std::vector<hipEvent_t> seen;
+      for (hipEvent_t e : *v) {
+        bool dup = false;
+        for (hipEvent_t x : seen) dup = dup || x == e;
+        if (dup) continue;
+        seen.push_back(e);
+        (void)hipEventDestroy(e);
+      }
+    }
     if (r.arena) (void)hipFree(r.arena);
     for (hipStream_t s : {r.st, r.ci, r.co})
       if (s) (void)hipStreamDestroy(s);
@@ -390,9 +407,19 @@ int ensure_ranks() {
       HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
       HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
+      // M4RI_AMD_LINK_STREAMS=n caps the link streams per direction (peer k uses stream k % n; default: one per peer): a knob for
+      // boxes whose runtime maps many streams onto few hardware queues
+      static const int link_cap = getenv("M4RI_AMD_LINK_STREAMS") ? atoi(getenv("M4RI_AMD_LINK_STREAMS")) : 0;
       for (size_t k = 0; k < g_devices.size(); ++k) {
         hipStream_t a = nullptr, b = nullptr;
         hipEvent_t ea = nullptr, eb = nullptr;
+        if (link_cap > 0 && k >= (size_t)link_cap) {  // share the stream (and its event) of peer k % n
+          r.lin.push_back(r.lin[k % (size_t)link_cap]);
+          r.lout.push_back(r.lout[k % (size_t)link_cap]);
+          r.ev_lin.push_back(r.ev_lin[k % (size_t)link_cap]);
+          r.ev_lout.push_back(r.ev_lout[k % (size_t)link_cap]);
+          continue;
+        }
         HIPTRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         r.lin.push_back(a);
         HIPTRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));

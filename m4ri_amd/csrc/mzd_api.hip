@@ -22,7 +22,9 @@
 #include <ctime>
 #include <sys/mman.h>
 #include <sys/sysinfo.h>
+#include <atomic>
 #include <condition_variable>
+#include <list>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -34,7 +36,20 @@ namespace {
 constexpr uint8_t FLAG_EXCESS = 0x2;  // mzd.h:144
 constexpr uint8_t FLAG_WINDOW = 0x4;  // mzd.h:150
 
-std::mutex g_api_mu;
+// Locks of the host entry points.  One per DEVICE for everything that works on that device's staging arena, solver scratch and
+// engine (ApiLock: host threads that drive different GPUs run side by side, threads on one GPU take turns -- round 3 had one lock
+// for all devices), one short lock for the table of pinned matrices, one for the statistics.
+constexpr int ARENA_DEVICES = 16;
+std::mutex g_dev_mu[ARENA_DEVICES];
+std::mutex g_pin_mu, g_stats_mu;
+struct ApiLock {
+  std::unique_lock<std::mutex> lk;
+  ApiLock() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) dev = 0;
+    lk = std::unique_lock<std::mutex>(g_dev_mu[dev]);
+  }
+};
 
 // M4RI_AMD_STATS=1: at exit, print how many products went through the host entry points, the time
 // spent in them (transfers included) and the bytes moved over PCIe -- for judging what an LD_PRELOAD
@@ -253,9 +268,8 @@ struct Arena {
   size_t cap  = 0;  // words
   size_t used = 0;
 };
-constexpr int ARENA_DEVICES = 16;
 Arena g_arenas[ARENA_DEVICES];  // one per HIP device: run() works on whatever device is current
-int g_arena_dev = 0;
+thread_local int g_arena_dev = 0;  // the device whose arena this thread is carving (set by arena_reserve, under that device's lock)
 #define g_arena g_arenas[g_arena_dev]
 
 void arena_reserve(size_t words) {
@@ -298,7 +312,7 @@ void upload(DevMat &d, const mzd_t *M) {
     HIPDIE(hipMemsetAsync(d.p, 0, (size_t)M->nrows * d.stride * 8, 0));  // but keep it deterministic)
   HIPDIE(hipMemcpy2D(d.p, (size_t)d.stride * 8, M->data, (size_t)M->rowstride * 8, (size_t)M->width * 8,
                      (size_t)M->nrows, hipMemcpyHostToDevice));
-  g_api_stats.h2d += (double)M->width * 8.0 * (double)M->nrows;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.h2d += (double)M->width * 8.0 * (double)M->nrows; }
   HIPDIE(m4ri_amd_mask_tail_dev(d.p, d.stride, M->nrows, M->ncols, nullptr));
 }
 
@@ -306,7 +320,7 @@ void upload(DevMat &d, const mzd_t *M) {
 // inside high_bitmask when C is a window with excess
 void download(const DevMat &d, mzd_t *C) {
   if (C->nrows == 0 || C->width == 0) return;
-  g_api_stats.d2h += (double)C->width * 8.0 * (double)C->nrows;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.d2h += (double)C->width * 8.0 * (double)C->nrows; }
   const bool dangerous = (C->flags & FLAG_WINDOW) && (C->ncols % 64 != 0);
   if (!dangerous) {
     HIPDIE(hipMemcpy2D(C->data, (size_t)C->rowstride * 8, d.p, (size_t)d.stride * 8, (size_t)C->width * 8,
@@ -339,10 +353,11 @@ struct Pin {
   mzd_t *owner;
   int device;  // HIP device the copy lives on
 };
-std::vector<Pin> g_pins;
+std::list<Pin> g_pins;  // a list: entries stay where they are while other threads pin and unpin (g_pin_mu guards the walk and the edits)
 
 Pin *find_pin(const mzd_t *M) {
   if (!M || !M->data) return nullptr;
+  std::lock_guard<std::mutex> pl(g_pin_mu);
   for (Pin &p : g_pins)
     if (M->data >= p.hbase && M->data < p.hbase + p.words && M->rowstride == p.rowstride) return &p;
   return nullptr;
@@ -380,9 +395,9 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 // product is too small to pay for it.
 // m * l * n at or below which a product from host memory is computed on the host (m4ri_amd_set_small_product_threshold; the measured
 // crossover against the reference on the GPU box, profiles/r04_crossover_cpu_gpu.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
-int64_t g_small_threshold = getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 26);
-int64_t g_small_count     = 0;  // products that took the host path (under g_api_mu)
-size_t g_pipeline_min_bytes = (size_t)64 << 20;  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
+std::atomic<int64_t> g_small_threshold{getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 26)};
+std::atomic<int64_t> g_small_count{0};  // products that took the host path
+std::atomic<size_t> g_pipeline_min_bytes{(size_t)64 << 20};  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
 bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutoff, LateC *late) {
@@ -527,13 +542,13 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
 // the whole product: strassen == true runs the Strassen-Winograd engine, false a single leaf
 // `late`: C == nullptr and the result is still being allocated (LateC; never with add, never empty)
 mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, int cutoff, LateC *late = nullptr) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   const rci_t cm = A->nrows, cn = B->ncols;
   if (cm == 0 || cn == 0) return late ? late->get() : C;  // strassen.c:44
   struct Timer {
     timespec t0;
     Timer() { clock_gettime(CLOCK_MONOTONIC, &t0); }
-    ~Timer() { timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); g_api_stats.seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); g_api_stats.calls += 1; }
+    ~Timer() { timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); g_api_stats.calls += 1; }
   } timer;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
@@ -542,7 +557,7 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   Pin *pinC = late ? nullptr : find_pin(C);
   // products the launch / PCIe floor of a call would dominate: this library's own host Four Russians (small_host.cpp), on an
   // initialised device and only for matrices that live in host memory (a pinned operand is already on the GPU)
-  if (!late && !pinC && g_small_threshold > 0 && (double)cm * (double)A->ncols * (double)cn <= (double)g_small_threshold && !find_pin(A) && !find_pin(B)) {
+  if (!late && !pinC && g_small_threshold.load() > 0 && (double)cm * (double)A->ncols * (double)cn <= (double)g_small_threshold.load() && !find_pin(A) && !find_pin(B)) {
     if (m4ri_amd_small_mul_host(C, A, B, add ? 1 : 0)) die("m4ri_amd: small product failed (internal error)\n");
     g_small_count += 1;
     return C;
@@ -634,7 +649,7 @@ void inout_end(InOut &io, mzd_t *M) {
 // B <- T^-1 B (left) or B <- B T^-1 (right) for a unit triangular T (triangular.c:41-514); T's other triangle and
 // diagonal are never read
 void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff, bool right = false) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   if (B->nrows == 0 || B->ncols == 0 || (!right && B->nrows <= 1) || (right && B->ncols <= 1)) return;  // one unknown per system: X = B
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
@@ -660,7 +675,7 @@ void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff, bool right = fal
   else                HIPDIE(m4ri_amd_trsm_lower_left_dev(dT.p, dT.stride, io.d.p, io.d.stride, B->nrows, B->ncols, cutoff, nullptr));
   inout_end(io, B);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
 }
 
 void pin_download(Pin &p) {
@@ -784,20 +799,20 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
 }
 
 int64_t m4ri_amd_set_small_product_threshold(int64_t ops) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   const int64_t old = g_small_threshold;
   if (ops >= 0) g_small_threshold = ops;
   return old;
 }
 
 int64_t m4ri_amd_small_product_count(void) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   return g_small_count;
 }
 
 // A + B + C bytes from which the host entry points pipeline a product over row slabs (0: never); returns the previous value
 int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   const int64_t old = (int64_t)g_pipeline_min_bytes;
   if (min_bytes >= 0) g_pipeline_min_bytes = (size_t)min_bytes;
   return old;
@@ -835,7 +850,7 @@ void _mzd_trsm_lower_right(mzd_t const *L, mzd_t *B, const int cutoff) { run_trs
 
 // ---- PLE decomposition: the reference's names, host mzd_t / mzp_t in and out ---------
 static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q, bool pluq, bool russian) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -851,7 +866,7 @@ static rci_t run_ple(mzd_t *A, mzp_t *P, mzp_t *Q, bool pluq, bool russian) {
                                                        russian ? 0 : M4RI_AMD_PLE_CUTOFF, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return rank;
 }
 
@@ -876,7 +891,7 @@ rci_t _mzd_pluq_russian(mzd_t *A, mzp_t *P, mzp_t *Q, int k) { (void)k; return r
 void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q) {  // mzp.c:279-293
   if (Q->length != A->ncols) die("mzd_apply_p_right_trans_tri: Permutation length (%d) must match A ncols (%d)\n", Q->length, A->ncols);
   if (A->nrows == 0 || A->ncols == 0) return;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -885,13 +900,13 @@ void mzd_apply_p_right_trans_tri(mzd_t *A, mzp_t const *Q) {  // mzp.c:279-293
   HIPDIE(m4ri_amd_apply_p_right_trans_tri_dev(io.d.p, io.d.stride, A->nrows, A->ncols, Q->values, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
 }
 
 // ---- echelon forms and the column permutations (echelon.hip) -----------------------------------------------------
 static rci_t run_echelonize(mzd_t *A, int full) {
   if (A->nrows == 0 || A->ncols == 0) return 0;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -901,7 +916,7 @@ static rci_t run_echelonize(mzd_t *A, int full) {
   HIPDIE(m4ri_amd_echelonize_dev(io.d.p, io.d.stride, A->nrows, A->ncols, full, &rank, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return rank;
 }
 rci_t mzd_echelonize(mzd_t *A, int full) { return run_echelonize(A, full); }                  // echelonform.c:29-31
@@ -915,7 +930,7 @@ rci_t _mzd_echelonize_m4ri(mzd_t *A, const int full, int k, int heuristic, const
 
 static void run_apply_p_right(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:193-260
   if (A->nrows == 0 || A->ncols == 0) return;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -924,7 +939,7 @@ static void run_apply_p_right(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:1
   HIPDIE(m4ri_amd_apply_p_right_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, P->length, trans, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
 }
 void mzd_apply_p_right(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 0); }
 void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P, 1); }
@@ -932,7 +947,7 @@ void mzd_apply_p_right_trans(mzd_t *A, mzp_t const *P) { run_apply_p_right(A, P,
 // ---- the drivers over PLUQ: systems, kernels, inverses, row permutations (solve.hip) ---------------------------------
 static void run_apply_p_left(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:65-81
   if (A->nrows == 0 || A->ncols == 0) return;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -941,14 +956,14 @@ static void run_apply_p_left(mzd_t *A, mzp_t const *P, int trans) {  // mzp.c:65
   HIPDIE(m4ri_amd_apply_p_left_dev(io.d.p, io.d.stride, A->nrows, A->ncols, P->values, P->length, trans, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
 }
 void mzd_apply_p_left(mzd_t *A, mzp_t const *P) { run_apply_p_left(A, P, 0); }
 void mzd_apply_p_left_trans(mzd_t *A, mzp_t const *P) { run_apply_p_left(A, P, 1); }
 
 // A == nullptr-decomposition variant: rank/P/Q given (mzd_pluq_solve_left); otherwise A is decomposed in place
 static int run_solve_left(mzd_t *A, mzd_t const *Adec, rci_t rank, mzp_t const *P, mzp_t const *Q, mzd_t *B, int cutoff, int check) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -969,7 +984,7 @@ static int run_solve_left(mzd_t *A, mzd_t const *Adec, rci_t rank, mzp_t const *
     inout_end(ib, B);
   }
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return retval;
 }
 
@@ -993,7 +1008,7 @@ int _mzd_pluq_solve_left(mzd_t const *A, rci_t rank, mzp_t const *P, mzp_t const
 }
 
 mzd_t *mzd_kernel_left_pluq(mzd_t *A, int const cutoff) {  // solve.c:154-191
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1017,7 +1032,7 @@ mzd_t *mzd_kernel_left_pluq(mzd_t *A, int const cutoff) {  // solve.c:154-191
     download(dR, R);
   }
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return R;
 }
 
@@ -1027,7 +1042,7 @@ mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k) {  // brilliantrussian.c:97
   if (B == nullptr) B = result_init(A->nrows, A->ncols);
   else if (B->nrows != A->nrows || B->ncols != A->ncols) die("mzd_inv_m4ri: B (%d x %d) has wrong dimensions.\n", B->nrows, B->ncols);
   if (A->nrows == 0) return B;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1037,7 +1052,7 @@ mzd_t *mzd_inv_m4ri(mzd_t *B, mzd_t const *A, int k) {  // brilliantrussian.c:97
   HIPDIE(m4ri_amd_inv_dev(ib.d.p, ib.d.stride, dA.p, dA.stride, A->nrows, nullptr));
   inout_end(ib, B);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return B;
 }
 
@@ -1046,7 +1061,7 @@ mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {  // mzd.c:1118-1139
   if (DST == nullptr) DST = result_init(A->ncols, A->nrows);
   else if (DST->nrows != A->ncols || DST->ncols != A->nrows) die("mzd_transpose: Wrong size for return matrix.\n");
   if (A->nrows == 0 || A->ncols == 0) return DST;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1064,14 +1079,14 @@ mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {  // mzd.c:1118-1139
     download(dD, DST);
   }
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return DST;
 }
 
 static mzd_t *run_trtri_upper(mzd_t *A, const char *who) {  // triangular.c:518-547, triangular_russian.c:384-470
   if (A->nrows != A->ncols) die("%s: matrix must be square and is found to be (%d) x (%d).\n", who, A->nrows, A->ncols);
   if (A->nrows <= 1) return A;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1080,7 +1095,7 @@ static mzd_t *run_trtri_upper(mzd_t *A, const char *who) {  // triangular.c:518-
   HIPDIE(m4ri_amd_trtri_upper_dev(io.d.p, io.d.stride, A->nrows, nullptr));
   inout_end(io, A);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
   return A;
 }
 mzd_t *mzd_trtri_upper(mzd_t *A) { return run_trtri_upper(A, "mzd_trtri_upper"); }
@@ -1106,7 +1121,7 @@ static void split_k(int k, int n, int32_t *kb) {
 static void run_process_rows(mzd_t *M, rci_t startrow, rci_t stoprow, rci_t startcol, int k, int nt, mzd_t const *const *T,
                              rci_t const *const *L) {
   if (stoprow <= startrow || M->ncols == 0) return;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1135,7 +1150,7 @@ static void run_process_rows(mzd_t *M, rci_t startrow, rci_t stoprow, rci_t star
   HIPDIE(m4ri_amd_process_rows_dev(io.d.p, io.d.stride, M->width, 0, W.nrows, startcol, nt, kb, dT, ts, dL, idx, nullptr));
   inout_end(io, &W);
   HIPDIE(hipDeviceSynchronize());
-  g_api_stats.calls += 1;
+  { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.calls += 1; }
 }
 
 void mzd_process_rows(mzd_t *M, rci_t startrow, rci_t endrow, rci_t startcol, int k, mzd_t const *T, rci_t const *L) {  // brilliantrussian.c:213
@@ -1180,7 +1195,7 @@ void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L)
     jstar[(size_t)i] = js;
   }
   if (M->ncols == 0 || c / 64 >= M->width) return;
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
   HIPDIE(m4ri_amd_init(dev));
@@ -1213,7 +1228,7 @@ void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L)
 
 void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the current device's arena, the parked result blocks
   g_big_cache.drop();
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) return;
   Arena &a = g_arenas[dev];
@@ -1235,14 +1250,16 @@ void m4ri_amd_result_free(mzd_t *A) {
 
 // ---- part 3: residency ----------------------------------------------------------------------------
 int m4ri_amd_pin(mzd_t *M) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   if (!M || (M->flags & FLAG_WINDOW)) return -1;  // pin the owner of the block; windows into it follow
   if (Pin *old = find_pin(M)) {
     if (old->owner == M && old->hbase == M->data && old->nrows == M->nrows && old->ncols == M->ncols) return 0;
     // a matrix freed without unpin left this entry behind and the allocator reused its address: the
     // device copy belongs to a dead matrix -- drop it (without a download) and pin M afresh
     (void)hipFree(old->dbase);
-    g_pins.erase(g_pins.begin() + (old - g_pins.data()));
+    std::lock_guard<std::mutex> pl(g_pin_mu);
+    for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
+      if (&*it == old) { g_pins.erase(it); break; }
   }
   if (M->nrows == 0 || M->ncols == 0 || !M->data) return -1;
   int dev = 0;
@@ -1254,12 +1271,15 @@ int m4ri_amd_pin(mzd_t *M) {
   p.nrows = M->nrows; p.ncols = M->ncols; p.owner = M;
   HIPDIE(hipMalloc(reinterpret_cast<void **>(&p.dbase), p.words * 8));
   pin_upload(p);
-  g_pins.push_back(p);
+  {
+    std::lock_guard<std::mutex> pl(g_pin_mu);
+    g_pins.push_back(p);
+  }
   return 0;
 }
 
 int m4ri_amd_sync(mzd_t *M) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   Pin *p = find_pin(M);
   if (!p) return -1;
   pin_download(*p);
@@ -1267,7 +1287,7 @@ int m4ri_amd_sync(mzd_t *M) {
 }
 
 int m4ri_amd_host_modified(mzd_t *M) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   Pin *p = find_pin(M);
   if (!p) return -1;
   pin_upload(*p);
@@ -1275,17 +1295,21 @@ int m4ri_amd_host_modified(mzd_t *M) {
 }
 
 int m4ri_amd_unpin(mzd_t *M) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   Pin *p = find_pin(M);
   if (!p) return -1;
   pin_download(*p);
   HIPDIE(hipFree(p->dbase));
-  g_pins.erase(g_pins.begin() + (p - g_pins.data()));
+  {
+    std::lock_guard<std::mutex> pl(g_pin_mu);
+    for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
+      if (&*it == p) { g_pins.erase(it); break; }
+  }
   return 0;
 }
 
 int m4ri_amd_is_pinned(const mzd_t *M) {
-  std::lock_guard<std::mutex> lk(g_api_mu);
+  ApiLock lk;
   Pin *p = find_pin(M);
   return p ? (p->dev_newer ? 2 : 1) : 0;
 }
@@ -1302,7 +1326,7 @@ static mzd_t *mul_mp(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff, bool 
     die("%s: C (%d x %d) has wrong dimensions, expected (%d x %d)\n", who, C->nrows, C->ncols, A->nrows, B->ncols);
   if (add && (A->nrows == 0 || A->ncols == 0 || B->ncols == 0)) return C;
   bool pinned;
-  { std::lock_guard<std::mutex> lk(g_api_mu); pinned = find_pin(A) || find_pin(B) || find_pin(C); }
+  pinned = find_pin(A) || find_pin(B) || find_pin(C);
   if (!pinned && gf2_multi_wanted(A->nrows, A->ncols, B->ncols)) {
     const int rc = m4ri_amd_mul_multi(C, A, B, add ? 1 : 0, cutoff, 0);
     if (rc) die("m4ri_amd: multi-device product failed (hipError_t %d: %s)\n", rc, hipGetErrorString((hipError_t)rc));
