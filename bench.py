@@ -1128,7 +1128,8 @@ def main():
             lds["frac_in_cycles"] = need / traffic_detail["gui_active_cycles"]
             lds["effective_clock_hz"] = traffic_detail["effective_clock_hz"]
             lds["note"] = ("frac prices the launch at the 2.4 GHz peak clock, frac_in_cycles at the clock it really ran at (GRBM_GUI_ACTIVE / duration): "
-                           "the kernel sits on the chip's power limit.  Of the cycles with the LDS idle ~10 % are bubbles of the gather pipeline itself "
+                           "the kernel sits on the chip's power limit (measured: 1338 W of a 1400 W socket cap, the firmware's package-power limiter active 82 % of the launch's time, "
+                           "no thermal limiter -- profiles/r04_leaf_power/).  Of the cycles with the LDS idle ~10 % are bubbles of the gather pipeline itself "
                            "(gathers alone: 90 % busy) and ~4.5 % the stage barrier (profiles/r03_leaf_decomposition/README.md)")
         if step_ms:
             out["step_ms_min"], out["step_ms_median"] = step_ms[0], step_ms[len(step_ms) // 2]
