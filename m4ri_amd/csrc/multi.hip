@@ -542,10 +542,15 @@ m4ri_amd_dmat *dmat_new(int64_t rows, int64_t ncols, int layout) {  // g_multi_m
   return d.release();
 }
 
+int sync_all();
+
 void dmat_delete(m4ri_amd_dmat *d) {
   if (!d) return;
   int cur = 0;
   (void)hipGetDevice(&cur);
+  // other ranks may still be pulling rows out of this matrix's buffers (their part of an operation issued a moment ago, on THEIR
+  // devices): everybody's streams first, then the buffers go
+  if (d->config_gen == g_config_gen) (void)sync_all();
   for (size_t r = 0; r < d->local.size(); ++r)
     if (d->local[r]) {
       (void)hipSetDevice(d->device[r]);

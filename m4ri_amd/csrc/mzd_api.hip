@@ -339,6 +339,58 @@ void download(const DevMat &d, mzd_t *C) {
   }
 }
 
+// ---- one transfer each way for products of a few MiB ----------------------------------------------------
+// A product from host memory used to cost two blocking 2-D uploads (each with its own clear and tail-mask launch), the
+// kernels, a blocking 2-D download and a device synchronisation: 85 ... 130 us whatever the size.  Operands of a few MiB
+// are instead packed by the CPU into ONE pinned buffer per device (rows at the device stride, padding words cleared, the bits
+// beyond the last column masked on the way -- a window's neighbours never reach the device), sent with one asynchronous copy,
+// and the result comes back the same way and is merged into C's rows under the column mask by the CPU.
+struct HostStage {
+  word *p    = nullptr;
+  size_t cap = 0;  // words
+};
+HostStage g_host_stage[ARENA_DEVICES];
+constexpr size_t SMALL_STAGE_BYTES = (size_t)6 << 20;  // A + B + C above this: the 2-D copies straight from / to the caller's rows
+
+word *host_stage(int dev, size_t words) {
+  HostStage &h = g_host_stage[dev];
+  if (words > h.cap) {
+    if (h.p) { HIPDIE(hipDeviceSynchronize()); HIPDIE(hipHostFree(h.p)); }
+    h.p = nullptr; h.cap = 0;
+    HIPDIE(hipHostMalloc(reinterpret_cast<void **>(&h.p), words * 8, hipHostMallocDefault));
+    h.cap = words;
+  }
+  return h.p;
+}
+
+// rows of M -> `dst` at `stride` words per row: valid words copied, the last one masked, padding words cleared
+void pack_rows(word *dst, int64_t stride, const mzd_t *M) {
+  const int64_t w = M->width;
+  for (rci_t i = 0; i < M->nrows; ++i) {
+    word *d       = dst + (int64_t)i * stride;
+    const word *r = M->data + (int64_t)i * M->rowstride;
+    if (w > 0) {
+      memcpy(d, r, (size_t)w * 8);
+      d[w - 1] &= M->high_bitmask;
+    }
+    for (int64_t k = w; k < stride; ++k) d[k] = 0;
+  }
+}
+
+// `src` (rows at `stride`) -> C's rows: whole words, the last one under the column mask when C is a window
+void unpack_rows(mzd_t *C, const word *src, int64_t stride) {
+  const int64_t w = C->width;
+  if (w == 0) return;
+  const bool window = (C->flags & FLAG_WINDOW) != 0;
+  const word mask   = C->high_bitmask;
+  for (rci_t i = 0; i < C->nrows; ++i) {
+    word *c       = C->data + (int64_t)i * C->rowstride;
+    const word *r = src + (int64_t)i * stride;
+    if (w > 1) memcpy(c, r, (size_t)(w - 1) * 8);
+    c[w - 1] = window ? ((c[w - 1] & ~mask) | (r[w - 1] & mask)) : (r[w - 1] & mask);
+  }
+}
+
 // ---- residency table (include/m4ri_amd.h part 3) ------------------------------------
 // A pinned matrix keeps a device copy with the host layout (same rowstride), so any window into it
 // is the same offset into the device copy.  Products read pinned operands where they are and leave a
@@ -563,6 +615,32 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
     return C;
   }
   if (strassen && !same && !pinC && !find_pin(A) && !find_pin(B) && run_pipelined(C, A, B, add, cutoff, late)) return late ? late->get() : C;
+  // nothing pinned and a few MiB in all: one asynchronous transfer each way through the device's pinned buffer
+  if (!late && !pinC && !find_pin(A) && !find_pin(B)) {
+    const size_t wa = dev_words(A->nrows, A->ncols), wb = same ? 0 : dev_words(B->nrows, B->ncols), wc = dev_words(cm, cn);
+    if ((wa + wb + wc) * 8 <= SMALL_STAGE_BYTES) {
+      arena_reserve(wa + wb + wc);
+      word *hs = host_stage(dev, wa + wb + wc);
+      DevMat dA, dB, dC;
+      dev_alloc(dA, A->nrows, A->ncols);
+      if (same) dB = dA; else dev_alloc(dB, B->nrows, B->ncols);
+      dev_alloc(dC, cm, cn);
+      pack_rows(hs, dA.stride, A);
+      if (!same) pack_rows(hs + wa, dB.stride, B);
+      if (add) pack_rows(hs + wa + wb, dC.stride, C);
+      const size_t up = (wa + wb + (add ? wc : 0)) * 8;
+      HIPDIE(hipMemcpyAsync(dA.p, hs, up, hipMemcpyHostToDevice, nullptr));   // dA, dB, dC are consecutive in the arena, like hs
+      if (strassen)
+        HIPDIE(m4ri_amd_mul_dev(dC.p, dC.stride, dA.p, dA.stride, dB.p, dB.stride, A->nrows, A->ncols, B->ncols, add, cutoff, nullptr));
+      else
+        HIPDIE(m4ri_amd_m4rm_dev(dC.p, dC.stride, dA.p, dA.stride, dB.p, dB.stride, A->nrows, A->ncols, B->ncols, add, 0, nullptr));
+      HIPDIE(hipMemcpyAsync(hs + wa + wb, dC.p, wc * 8, hipMemcpyDeviceToHost, nullptr));
+      HIPDIE(hipStreamSynchronize(nullptr));
+      unpack_rows(C, hs + wa + wb, dC.stride);
+      { std::lock_guard<std::mutex> sl(g_stats_mu); g_api_stats.h2d += (double)up; g_api_stats.d2h += (double)wc * 8.0; }
+      return C;
+    }
+  }
   // a pinned C whose last word is shared with other columns of its parent is computed in staging and
   // merged under the column mask; otherwise the engine writes straight into the parent
   const bool c_staged = !pinC || (cn % 64 != 0 && cn != pinC->ncols);
@@ -1231,6 +1309,11 @@ void gf2_release_staging(void) {  // called by m4ri_amd_release_workspace: the c
   ApiLock lk;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) return;
+  if (g_host_stage[dev].p) {
+    (void)hipDeviceSynchronize();
+    (void)hipHostFree(g_host_stage[dev].p);
+    g_host_stage[dev] = HostStage{};
+  }
   Arena &a = g_arenas[dev];
   if (!a.base) return;
   (void)hipDeviceSynchronize();
