@@ -350,7 +350,7 @@ struct HostStage {
   size_t cap = 0;  // words
 };
 HostStage g_host_stage[ARENA_DEVICES];
-constexpr size_t SMALL_STAGE_BYTES = (size_t)6 << 20;  // A + B + C above this: the 2-D copies straight from / to the caller's rows
+constexpr size_t SMALL_STAGE_BYTES = (size_t)2 << 20;  // A + B + C above this: the 2-D copies straight from / to the caller's rows (4096^3 = 6 MiB: 0.32 ms packed against 0.25 ms direct)
 
 word *host_stage(int dev, size_t words) {
   HostStage &h = g_host_stage[dev];
