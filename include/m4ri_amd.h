@@ -353,7 +353,7 @@ int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes);
 
 /* Small products.  The reference switches algorithm by size inside the functions this library replaces (_mzd_mul_m4rm -> mzd_mul_naive
    below 54 columns / 16 rows, m4ri/brilliantrussian.c:1063-1068, m4ri/mzd.c:1141-1172); here the switch sits where a call's upload,
-   launches and download (50 ... 85 us whatever the size) stop paying: a product with m * l * n at or below the threshold whose
+   launches and download (28 ... 80 us whatever the size) stop paying: a product with m * l * n at or below the threshold whose
    matrices live in host memory is computed by the library's own host Method of Four Russians (small_host.cpp) on the calling
    thread -- on an initialised device, never instead of one: without a GPU the entry points still abort.  Default 2^26 (406^3);
    0 sends every product to the GPU; returns the previous value, negative arguments only query.  m4ri_amd_small_product_count: how

@@ -2,7 +2,7 @@
 //
 // The reference switches algorithm by size inside the very function this library replaces (_mzd_mul_m4rm falls to
 // mzd_mul_naive / mzd_addmul_naive below 54 columns or 16 rows, /root/reference m4ri/brilliantrussian.c:1063-1068,
-// m4ri/mzd.c:1141-1172).  The GPU's own switch sits higher: every call through the host entry points pays 50 ... 85 us for the
+// m4ri/mzd.c:1141-1172).  The GPU's own switch sits higher: every call through the host entry points pays 28 ... 80 us for the
 // upload, the launches and the download whatever its size, which a product of a few hundred rows does not repay
 // (profiles/r04_crossover_cpu_gpu.log).  Below m4ri_amd_set_small_product_threshold (m * l * n bit operations) the entry points of
 // mzd_api.hip therefore compute the product here, on the calling thread -- so that a program under LD_PRELOAD never gets slower by
