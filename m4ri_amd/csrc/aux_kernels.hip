@@ -987,6 +987,94 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up4_kernel(
   }
 }
 
+// The same pass with the seven top-level products of a word meeting in LDS instead of in HBM: a workgroup owns 32 word positions,
+// half-wave g (of 8; the last idles through the fold) folds the 343 products of top-level product g for them, scatters its 8 x 8
+// blocks into the 16 x 16 grid held in LDS (64 KiB, ds_xor) and, after ONE barrier, the workgroup writes the grid out -- every word of
+// C written once (or read-modify-written once when accumulating), no clear, no atomics beyond the CU.  By the counters the atomic form
+// writes 3.5 x the result (every atomic reaches HBM) on top of the clear.
+constexpr int U4_POS = 32;
+
+template <bool ACC, bool NT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_up4_lds_kernel(
+    const word *__restrict__ prod, int64_t p_bs,  // 2401 products per ancestor, stride == cw
+    word *anc, int64_t o_stride, int64_t o_bs,    // ancestor array
+    int64_t crows, int64_t cw) {                  // cw % U4_POS == 0: the 32 positions of a workgroup lie in one row
+  __shared__ unsigned long long grid[256 * U4_POS];
+  const int tid = threadIdx.x, pp = tid & (U4_POS - 1), j0 = tid >> 5;
+  for (int k = tid; k < 256 * U4_POS; k += AUX_THREADS) grid[k] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * U4_POS + pp, pi = blockIdx.y;
+  const int64_t r = i / cw, w = i - r * cw;
+  if (j0 < 7) {
+    const word *q = prod + (pi * 2401 + 343 * j0) * p_bs + r * cw + w;
+    word out[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) out[a][b] = 0;
+    word buf[2][7];
+    auto load_group = [&](int g, word (&dst)[7]) {
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) dst[j3] = NT ? __builtin_nontemporal_load(&q[(int64_t)(7 * g + j3) * p_bs]) : q[(int64_t)(7 * g + j3) * p_bs];
+    };
+    load_group(0, buf[0]);
+#pragma unroll
+    for (int j1 = 0; j1 < 7; ++j1) {
+      word c1[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c1[a][b] = 0;
+#pragma unroll
+      for (int j2 = 0; j2 < 7; ++j2) {
+        const int g = 7 * j1 + j2;
+        if (g + 1 < 49) load_group(g + 1, buf[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        word c2[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int j3 = 0; j3 < 7; ++j3) winograd_scatter<word>(buf[g & 1][j3], j3, c2[0][0], c2[0][1], c2[1][0], c2[1][1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) winograd_scatter<word>(c2[a][b], j2, c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) winograd_scatter<word>(c1[a][b], j1, out[a][b], out[a][b + 4], out[a + 4][b], out[a + 4][b + 4]);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(out[a][b]));  // the folds stay above the predicated stores (see winograd_up4_kernel)
+    // top level, per lane (the two half-waves of a wave fold different products): quadrant (qa, qb) of the grid gets the block when
+    // the product belongs to it (winograd_scatter's table)
+    const bool t11 = j0 <= 1, t12 = j0 == 0 || j0 == 2 || j0 == 4 || j0 == 5, t21 = j0 == 0 || j0 == 3 || j0 == 5 || j0 == 6,
+               t22 = j0 == 0 || j0 == 4 || j0 == 5 || j0 == 6;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long v = out[a][b];
+        if (t11) atomicXor(&grid[((a) * 16 + b) * U4_POS + pp], v);
+        if (t12) atomicXor(&grid[((a) * 16 + b + 8) * U4_POS + pp], v);
+        if (t21) atomicXor(&grid[((a + 8) * 16 + b) * U4_POS + pp], v);
+        if (t22) atomicXor(&grid[((a + 8) * 16 + b + 8) * U4_POS + pp], v);
+      }
+  }
+  __syncthreads();
+  // write-out: grid block k * 8 + (tid >> 5) for k = 0 .. 31, the 32 lanes of a half-wave = the 32 positions = 256 contiguous bytes
+  word *o = anc + pi * o_bs + r * o_stride + w;
+#pragma unroll 4
+  for (int k = 0; k < 32; ++k) {
+    const int blk = k * 8 + (tid >> 5), ga = blk >> 4, gb = blk & 15;
+    word *oo      = o + (int64_t)ga * crows * o_stride + (int64_t)gb * cw;
+    const word v  = grid[blk * U4_POS + pp];
+    *oo           = ACC ? (*oo ^ v) : v;
+  }
+}
+
 template <int ROT, bool NT>
 __global__ __launch_bounds__(DP3_THREADS) void winograd_down4_pack_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
@@ -1065,6 +1153,17 @@ extern "C" hipError_t gf2_launch_winograd_up4(hipStream_t s, int acc, const word
                                               int64_t nparents, int64_t crows, int64_t cw) {
   const int64_t p_bs = crows * cw;
   if (nparents * p_bs == 0) return hipSuccess;
+  // the form that combines the seven top-level products in LDS needs the 32 positions of a workgroup inside one row
+  // (M4RI_AMD_UP4=atomic selects the other form: products meeting in HBM by atomic XOR, for measurements)
+  static const bool want_lds = !(getenv("M4RI_AMD_UP4") && getenv("M4RI_AMD_UP4")[0] == 'a');
+  if (want_lds && cw % U4_POS == 0 && p_bs / U4_POS <= 0x7fffffffLL && nparents <= 65535) {
+    const dim3 g((unsigned)(p_bs / U4_POS), (unsigned)nparents);
+#define U4L_LAUNCH(AC, NT) hipLaunchKernelGGL((winograd_up4_lds_kernel<AC, NT>), g, dim3(AUX_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw)
+    if (pass_nt() & 2) { if (acc) U4L_LAUNCH(true, true); else U4L_LAUNCH(false, true); }
+    else { if (acc) U4L_LAUNCH(true, false); else U4L_LAUNCH(false, false); }
+#undef U4L_LAUNCH
+    return hipGetLastError();
+  }
   const int64_t nposblocks = (p_bs + AUX_THREADS - 1) / AUX_THREADS, grid = pass4_grid(nposblocks);
   if (grid > 0x7fffffffLL || nparents > 65535 || (crows * o_stride + cw) * 8 >= (1ll << 31)) return hipErrorInvalidValue;
   if (!acc)
