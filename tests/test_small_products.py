@@ -89,3 +89,35 @@ def test_entry_points_take_the_host_routine_exactly_when_they_should(oracle):
         assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0)) and m4ri_amd.small_product_count() == before
     finally:
         m4ri_amd.set_small_product_threshold(old)
+
+
+def test_host_routine_fuzz_shapes_and_windows(oracle):
+    """Seeded fuzz of the host routine alone: random shapes around its three regimes (fewer than 16 rows, 4-bit tables, 8-bit tables),
+    mul and addmul, operands and result windows of larger parents; every word of C's parent is compared."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("M4RI_AMD_FUZZ_SEED", "20260929")))
+    for case in range(int(os.environ.get("M4RI_AMD_FUZZ_CASES", "150"))):
+        m = int(rng.choice([rng.integers(1, 16), rng.integers(16, 224), rng.integers(224, 400)]))
+        l, n = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        add = bool(rng.integers(0, 2))
+
+        def operand(rows, cols, seed):
+            if rng.integers(0, 2):
+                return Mzd.random(rows, cols, seed), None, (0, 0)
+            pr, pc = rows + int(rng.integers(0, 9)), cols + int(rng.integers(0, 200))
+            parent = Mzd.random(pr, pc, seed)
+            lowr, lowc = int(rng.integers(0, pr - rows + 1)), int(rng.integers(0, (pc - cols) // 64 + 1)) * 64
+            return parent.window(lowr, lowc, lowr + rows, lowc + cols), parent, (lowr, lowc)
+        A, _, _ = operand(m, l, 1000 + case)
+        B, _, _ = operand(l, n, 2000 + case)
+        C, Cp, (r0, c0) = operand(m, n, 3000 + case)
+        if Cp is None:
+            want = oracle.addmul(C.copy(), A.copy(), B.copy(), 0) if add else oracle.mul(None, A.copy(), B.copy(), 0)
+            m4ri_amd.small_mul_host(C, A, B, add)
+            assert C.equal(want), (case, m, l, n, add)
+        else:
+            wp = Mzd(Cp.nrows, Cp.ncols, buf=Cp.buf.copy())
+            wc = wp.window(r0, c0, r0 + m, c0 + n)
+            (oracle.addmul if add else oracle.mul)(wc, A.copy(), B.copy(), 0)
+            m4ri_amd.small_mul_host(C, A, B, add)
+            assert np.array_equal(Cp.buf, wp.buf), (case, m, l, n, add)
