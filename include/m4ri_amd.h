@@ -332,7 +332,7 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out);
 /* Strassen-Winograd levels the engine uses for an m x l x n product and this cutoff (pure host
    logic, callable without a GPU): cutoff > 0 follows the reference's rule (strassen.c:39,51 --
    halve while no dimension satisfies 3*dim < 4*cutoff, cutoff rounded down to a multiple of 64),
-   cutoff == 0 the engine's own default (split while m/2 >= 4096, l/2 >= 8192, n/2 >= 4096); both
+   cutoff == 0 the engine's own default (split while m/2 >= 4096, l/2 >= 4096, n/2 >= 4096); both
    capped so that every level still halves whole words. */
 int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
 
@@ -341,7 +341,7 @@ int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
    recursion -- same bits.  Returns the previous value; negative arguments only query. */
 int64_t m4ri_amd_set_workspace_budget(int64_t bytes);
 
-/* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..4, default 3;
+/* How many of the deepest Strassen-Winograd levels one fused pass covers each way (1..4, default 4;
    a scheduling knob: results are bit-identical for every value).  Returns the previous value;
    out-of-range arguments only query. */
 int m4ri_amd_set_max_fuse(int levels);

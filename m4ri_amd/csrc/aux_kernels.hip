@@ -705,7 +705,7 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
     uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed great-grandchildren, a4_bs dwords each
     int64_t crows, int64_t cw, int64_t tiles_r, int64_t tiles_w) {
-  __shared__ __attribute__((aligned(16))) uint32_t tile[2][DP3_ROWS * DP3_PITCH];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][7 * DP3_ROWS * DP3_PITCH];  // two sets of seven 4 KiB tiles
   int64_t bid      = blockIdx.x;
   const int64_t wt = bid % tiles_w; bid /= tiles_w;
   const int64_t rt = bid % tiles_r; bid /= tiles_r;
@@ -737,14 +737,20 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down3_pack_kernel(
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, false>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+      // the seven outputs of (j1, j2) go through seven tiles of one of two sets and ONE barrier: the other set is only rewritten after the
+      // next barrier, when every thread has read this one (49 barriers per workgroup instead of 343: with one 512-thread workgroup per
+      // CU a barrier per 4 KiB of output was a visible part of the pass)
+      uint32_t *set = tile[(7 * j1 + j2) & 1];
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3)
+        *reinterpret_cast<word *>(set + j3 * (DP3_ROWS * DP3_PITCH) + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
+            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+      __syncthreads();
+      const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);  // rows r2 and r2 + 1 share the swizzle
 #pragma unroll
       for (int j3 = 0; j3 < 7; ++j3) {
-        const int k  = 49 * j1 + 7 * j2 + j3;
-        uint32_t *tb = tile[k & 1];
-        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
-            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
-        __syncthreads();  // one barrier per output: the other buffer is only rewritten after the next one
-        const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);  // rows r2 and r2 + 1 share the swizzle
+        const int k        = 49 * j1 + 7 * j2 + j3;
+        const uint32_t *tb = set + j3 * (DP3_ROWS * DP3_PITCH);
         uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + rs], w1 = tb[(r2 + 1) * DP3_PITCH + rs];
         if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
         if (NT) __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)w1 << 32), reinterpret_cast<unsigned long long *>(o + (int64_t)k * a4_bs));
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down4_pack_kernel(
     const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
     uint32_t *__restrict__ a4, int64_t a4_bs,                       // packed descendants, a4_bs dwords each
     int64_t crows, int64_t cw, int64_t tiles_r, int64_t tiles_w) {
-  __shared__ __attribute__((aligned(16))) uint32_t tile[2][DP3_ROWS * DP3_PITCH];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][7 * DP3_ROWS * DP3_PITCH];  // two sets of seven 4 KiB tiles
   int64_t tb_;
   int j0;
   pass4_block(blockIdx.x, tb_, j0);
@@ -1112,14 +1118,20 @@ __global__ __launch_bounds__(DP3_THREADS) void winograd_down4_pack_kernel(
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, false>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+      // the seven outputs of (j1, j2) go through seven tiles of one of two sets and ONE barrier: the other set is only rewritten after the
+      // next barrier, when every thread has read this one (49 barriers per workgroup instead of 343: with one 512-thread workgroup per
+      // CU a barrier per 4 KiB of output was a visible part of the pass)
+      uint32_t *set = tile[(7 * j1 + j2) & 1];
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3)
+        *reinterpret_cast<word *>(set + j3 * (DP3_ROWS * DP3_PITCH) + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
+            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+      __syncthreads();
+      const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);  // rows r2 and r2 + 1 share the swizzle
 #pragma unroll
       for (int j3 = 0; j3 < 7; ++j3) {
-        const int k  = 49 * j1 + 7 * j2 + j3;
-        uint32_t *tb = tile[k & 1];
-        *reinterpret_cast<word *>(tb + r * DP3_PITCH + 2 * (v ^ ((r >> 1) & 15))) =
-            winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
-        __syncthreads();
-        const int rs = 2 * ((q >> 1) ^ ((r2 >> 1) & 15)) + (q & 1);
+        const int k        = 49 * j1 + 7 * j2 + j3;
+        const uint32_t *tb = set + j3 * (DP3_ROWS * DP3_PITCH);
         uint32_t w0 = tb[(r2 + 0) * DP3_PITCH + rs], w1 = tb[(r2 + 1) * DP3_PITCH + rs];
         if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
         if (NT) __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)w1 << 32), reinterpret_cast<unsigned long long *>(o + (int64_t)k * a4_bs));

@@ -82,8 +82,12 @@ constexpr int64_t PART_SLABS  = 768;  // slabs (256 KiB each) a split generation
 #ifndef LEAF_MIN_SPLIT_BITS_G4
 #define LEAF_MIN_SPLIT_BITS_G4 128  // the same for generation 4 (slabs + reduce pass)
 #endif
-int g_max_fuse = 3;  // deepest levels covered by one fused pass each way (1..4); m4ri_amd_set_max_fuse
-constexpr int DEFAULT_CUTOFF  = 8192;  // engine default: split while min(l,n)/2 >= this ...
+int g_max_fuse = 4;  // deepest levels covered by one fused pass each way (1..4); m4ri_amd_set_max_fuse
+// Round 4: leaves of 4096 inner bits (was 8192).  The leaf runs on the chip's power limit and the passes do not, so a level more
+// trades a power-bound eighth of the leaf for HBM-bound pass time -- a tie while the fourth level cost a separate pass, a win since
+// the four-level passes (aux_kernels.hip): 65536^3 28.4 -> 27.7 ms, 32768^3 4.13 -> 3.96, 131072 x 16384 x 131072 37.9 -> 32.5,
+// 131072^3 201 -> 195 (profiles/r04_depth_rule_sweep.log)
+constexpr int DEFAULT_CUTOFF  = 4096;  // engine default: split while l/2 >= this ...
 constexpr int DEFAULT_CUTOFF_M = 4096; // ... and m/2 >= this (one generation-4 tile row)
 constexpr int DEFAULT_CUTOFF_N = 4096; // ... and n/2 >= this (8 column tiles)
 constexpr int NUM_DEVICES_MAX = 16;
@@ -389,7 +393,7 @@ bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strass
 int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   int L = 0;
   if (cutoff == 0) {
-    // leaves keep >= 8192 inner bits and columns (256 stages, 16 column tiles per product) but may
+    // leaves keep >= 4096 inner bits and columns (128 stages, 8 column tiles per product) and may
     // be as short as ONE 4096-row tile: the rectangular blocks of a multi-GPU split (e.g.
     // 16384 x 65536 x 32768 per rank at 8 GPUs) then still get their full Strassen depth
     int64_t mm = m, ll = l, nn = n;

@@ -841,8 +841,8 @@ void plan_for(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n
 }
 
 // sharding.default_variant: row slabs up to 4 ranks (2 ranks share ONE link, which the Strassen exchange would saturate) and
-// for every product the single-GPU engine would not split once more in all three dimensions (engine.hip: default depth --
-// m/2 >= 4096, l/2 >= 8192, n/2 >= 4096; BASELINE.json configs[4], 131072 x 8192 x 131072, has l/2 < 8192: row slabs of A
+// for every product whose halves a sharded Strassen level would leave too thin to pay for the exchange of operands and results
+// (m/2 < 4096, l/2 < 8192 or n/2 < 4096; BASELINE.json configs[4], 131072 x 8192 x 131072, has l/2 < 8192: row slabs of A
 // and C with B replicated, no reduction); the Strassen sub-products from 5 ranks on
 int default_variant(int world, int64_t m, int64_t l, int64_t n) {
   if (world <= 4) return M4RI_AMD_VARIANT_SLABS;

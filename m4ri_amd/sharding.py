@@ -465,8 +465,8 @@ def slab_product_pieces(cuts, rank):
     return [p for p in out if p[1] > p[0]]
 
 
-# the single-GPU engine's own rule for one more Strassen-Winograd level (engine.hip: default depth): a leaf keeps at
-# least one 4096-row tile, 4096 columns and 8192 inner bits
+# what the halves of a product must keep for a SHARDED Strassen level to pay for its exchange: one 4096-row tile, 4096 columns and
+# 8192 inner bits (the single-GPU engine itself splits down to 4096 inner bits since round 4; across links the bar stays higher)
 ENGINE_MIN_HALF = (4096, 8192, 4096)
 
 

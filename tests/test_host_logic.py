@@ -39,9 +39,10 @@ def test_reference_default_cutoff_depths_of_the_survey():
     assert [m4ri_amd.plan_levels(n, n, n, 4096) for n in (4096, 16384, 65536)] == [0, 2, 4]
 
 
-@pytest.mark.parametrize("shape,levels", [
-    ((65536, 65536, 65536), 3), ((32768, 32768, 32768), 2), ((16384, 16384, 16384), 1), ((8192, 8192, 8192), 0),
-    ((131072, 131072, 131072), 4), ((131072, 8192, 131072), 0), ((16421, 16453, 16523), 1),
+@pytest.mark.parametrize("shape,levels", [   # the engine's own depth: split while every half keeps 4096 rows, inner bits and columns
+    ((65536, 65536, 65536), 4), ((32768, 32768, 32768), 3), ((16384, 16384, 16384), 2), ((8192, 8192, 8192), 1), ((4096, 4096, 4096), 0),
+    ((131072, 131072, 131072), 5), ((131072, 8192, 131072), 1), ((131072, 16384, 131072), 2), ((16421, 16453, 16523), 2), ((24576, 24576, 24576), 2),
+    ((70000, 524288, 512), 0),
 ])
 def test_engine_default_depth(shape, levels):
     assert m4ri_amd.plan_levels(*shape, 0) == levels
@@ -49,7 +50,7 @@ def test_engine_default_depth(shape, levels):
 
 def test_per_rank_blocks_of_the_default_grids_keep_their_depth():
     n = 65536
-    want = {1: 3, 2: 3, 4: 3, 8: 2}
+    want = {1: 4, 2: 3, 4: 3, 8: 2}
     for world, L in want.items():
         p = sharding.make_plan(world, 0, n, n, n)
         (r0, r1), (c0, c1), (k0, k1) = p.row_range(), p.col_range(), p.inner_range()
