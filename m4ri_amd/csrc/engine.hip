@@ -398,6 +398,14 @@ int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
     // 16384 x 65536 x 32768 per rank at 8 GPUs) then still get their full Strassen depth
     int64_t mm = m, ll = l, nn = n;
     while (L < MAX_LEVELS && mm / 2 >= DEFAULT_CUTOFF_M && ll / 2 >= DEFAULT_CUTOFF && nn / 2 >= DEFAULT_CUTOFF_N) { mm /= 2; ll /= 2; nn /= 2; ++L; }
+    // leaf rows come in tiles of 4096: a level that leaves 1.5 tiles per leaf (24576 -> 6144 rows) pays for 2.  One level less when
+    // its leaves waste less than the level saves (7/8 of the leaf work): 24576^3 runs 1.96 ms with 12288-row leaves, 2.34 ms with
+    // 6144-row ones; 100003 x 50021 x 70017 keeps its third level (48.3 against 49.1 ms) -- profiles/r04_depth_rule_sweep.log
+    auto waste = [&](int lv) {
+      const int64_t rows = m >> lv;
+      return rows <= 4096 ? 1.0 : (double)(((rows + 4095) / 4096) * 4096) / (double)rows;
+    };
+    if (L > 0 && waste(L - 1) <= 0.85 * waste(L)) --L;
   } else {
     // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
     int64_t a = m, b = l, c = n;

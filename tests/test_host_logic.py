@@ -41,7 +41,8 @@ def test_reference_default_cutoff_depths_of_the_survey():
 
 @pytest.mark.parametrize("shape,levels", [   # the engine's own depth: split while every half keeps 4096 rows, inner bits and columns
     ((65536, 65536, 65536), 4), ((32768, 32768, 32768), 3), ((16384, 16384, 16384), 2), ((8192, 8192, 8192), 1), ((4096, 4096, 4096), 0),
-    ((131072, 131072, 131072), 5), ((131072, 8192, 131072), 1), ((131072, 16384, 131072), 2), ((16421, 16453, 16523), 2), ((24576, 24576, 24576), 2),
+    ((131072, 131072, 131072), 5), ((131072, 8192, 131072), 1), ((131072, 16384, 131072), 2), ((100003, 50021, 70017), 3),
+    ((16421, 16453, 16523), 1), ((24576, 24576, 24576), 1),   # one level less where the leaves would be 1.5 tiles of rows (6144) or barely more than one (4105)
     ((70000, 524288, 512), 0),
 ])
 def test_engine_default_depth(shape, levels):
