@@ -1169,7 +1169,7 @@ def main():
                 "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
                 "copy_peak": copy_gbs, "frac_of_copy_peak": bs / (ms_per_step * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
                 "note": "unfused reference schedule bytes (15 quadrant adds/level) of the rank's sub-product(s) over the measured step time; "
-                        "our fused three-level passes move far fewer bytes; copy_peak = this GPU's measured "
+                        "our fused multi-level passes move far fewer bytes; copy_peak = this GPU's measured "
                         "device-to-device copy rate (read + write bytes)",
             }
         if not multi and args.workload != "leaf16384" and not args.no_api:

@@ -5,14 +5,14 @@
 //   _mzd_mul_even / _mzd_addmul_even      /root/reference m4ri/strassen.c:41-208, :367-526
 // by a BREADTH-FIRST schedule sized for 288 GB of HBM: for L levels
 //   "down" passes per operand    (a parent -> its Winograd operand combinations; the deepest
-//                                 min(L, 3) levels in ONE fused pass, the A side written straight
+//                                 min(L, 4) levels in ONE fused pass, the A side written straight
 //                                 into the leaf's packed form),
 //   ONE batched M4RM leaf launch (all 7^L products at once: >> 256 workgroups),
 //   "up" passes                  (products -> the quadrants of the parent, fused the same way; the
 //                                 last one writes, or XORs into, the caller's C).
 // The depth-first reference needs 2-3 quadrant temporaries per level and runs 7^L small leaves one
 // after another; on a GPU that starves the chip (a 4096^3 leaf is 8 workgroups).  Breadth-first
-// keeps the 7^L leaf operands and products -- 8.4 GiB at n = 65536, L = 3, intermediate levels never
+// keeps the 7^L leaf operands and products -- 16.9 GiB at n = 65536, L = 4, intermediate levels never
 // materialised -- and turns the whole product into four large launches on one stream.
 // Remainders that do not fit the even 2^L split are peeled with direct leaf launches exactly like
 // strassen.c:170-204.
@@ -422,7 +422,7 @@ int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
 int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
-  // The deepest levels are done by ONE fused pass each way: up to three of them (g_max_fuse), whose
+  // The deepest levels are done by ONE fused pass each way: up to four of them (g_max_fuse), whose
   // intermediate levels are never materialised -- that saves their buffers and a write + a read of
   // the 7/4-times-larger operands per skipped level.  Levels above go one at a time.
   const int fuse = L < g_max_fuse ? L : g_max_fuse;            // levels covered by the bottom pass
