@@ -374,11 +374,13 @@ def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
     (4096, 5120, 4096, 256, True, False),      # accumulate: the atomic top level adds onto C; 5-word leaf rows: plain passes + separate pack
     (16384, 8192, 8192, 512, False, True),     # operands and result inside wider parents (strided ancestors), 1024-row leaves
     (16384 + 40, 8192 + 70, 8192 + 130, 512, True, False),   # remainder strips around the even block
+    (4096, 4096, 32768, 256, True, False),     # 32-word leaf rows: the up pass whose products meet in LDS, accumulating
+    (4096, 4096, 32768, 256, False, True),     # the same, plain, writing into a wider parent
 ])
 def test_four_level_fused_passes(oracle, m, l, n, cutoff, add, strided):
     """Four levels in one pass each way (aux_kernels.hip winograd_down4 / down4_pack / up4: the three-level passes with the top level
-    formed on the fly, the seven top-level products of a word meeting by atomic XOR): a scheduling choice like the others -- fusing
-    4, 3 or 1 levels must not change a bit."""
+    formed on the fly, the seven top-level products of a word meeting in LDS -- or, for leaf rows that are not a multiple of 32 words,
+    by atomic XOR in HBM): a scheduling choice like the others -- fusing 4, 3 or 1 levels must not change a bit."""
     hA, hB, hC = Mzd.random(m, l, 81), Mzd.random(l, n, 82), Mzd.random(m, n, 83)
     pad = 6 if strided else 0          # words of a wider parent to the right of every operand
     wa, wn = hA.rowstride + pad, hB.rowstride + pad
