@@ -448,7 +448,7 @@ def main():
     ap.add_argument("--layout", default="distributed", choices=["distributed", "owner"], help="N > 1: where A, B live and C is left")
     ap.add_argument("--shard-levels", type=int, default=0, help="strassen variant: sharded levels (1, 2; 0 = automatic)")
     ap.add_argument("--grid", default="", help="blocks variant: gi,gj,gh split of (m, n, l) over the ranks (default: sharding.default_grid)")
-    ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..3; 0 = engine default)")
+    ap.add_argument("--max-fuse", type=int, default=0, help="Strassen levels per fused pass (1..4; 0 = engine default: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the host-API (PCIe-inclusive) timing")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
