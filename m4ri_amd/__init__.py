@@ -673,7 +673,7 @@ def set_host_pipeline(min_bytes: int) -> int:
 
 
 def set_max_fuse(levels: int) -> int:
-    """Deepest Strassen-Winograd levels covered by one fused pass (1..3); returns the previous value."""
+    """Deepest Strassen-Winograd levels covered by one fused pass (1..4); returns the previous value."""
     return int(lib().m4ri_amd_set_max_fuse(int(levels)))
 
 
