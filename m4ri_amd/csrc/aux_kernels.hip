@@ -993,6 +993,68 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_up4_kernel(
   }
 }
 
+// Down, with the ancestor read ONCE: a workgroup owns 32 word positions, loads their 16 x 16 grid into LDS (64 KiB, every load 256
+// contiguous bytes), and after one barrier half-wave g (of 8; the last idles) forms top-level child g from the grid -- up to four
+// LDS reads per word, chosen by per-lane masks -- and expands it through the three levels in registers.  (The form above leaves the
+// siblings' re-reads to the L2, which absorbs half of them: 0.97 GB read for a 0.54 GB ancestor.)
+template <bool BSIDE, bool NT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down4_lds_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,  // ancestor array: 16 * crows rows x 16 * cw words each
+    word *__restrict__ gchild, int64_t c_bs,                       // 2401 descendants per ancestor, stride == cw
+    int64_t crows, int64_t cw) {                                   // cw % 32 == 0
+  __shared__ word grid[256 * 32];
+  const int tid = threadIdx.x, pp = tid & 31, g = tid >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + pp, pi = blockIdx.y;
+  const int64_t r = i / cw, w = i - r * cw;
+  const word *p   = anc + pi * p_bs + r * p_stride + w;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) {
+    const int blk = k * 8 + g;
+    grid[blk * 32 + pp] = p[(int64_t)(blk >> 4) * crows * p_stride + (int64_t)(blk & 15) * cw];
+  }
+  __syncthreads();
+  if (g >= 7) return;
+  // which quadrants top-level child g is made of (winograd_child's table), as all-ones / zero masks per lane
+  const int j0 = g;
+  bool u11, u12, u21, u22;
+  if (!BSIDE) {  // [A11, A12, S4, A22, S1, S2, S3]
+    u11 = j0 == 0 || j0 == 2 || j0 == 5 || j0 == 6; u12 = j0 == 1 || j0 == 2; u21 = j0 == 2 || j0 == 4 || j0 == 5 || j0 == 6; u22 = j0 >= 2 && j0 <= 5;
+  } else {       // [B11, B21, B22, T4, T1, T2, T3]
+    u11 = j0 == 0 || j0 == 3 || j0 == 4 || j0 == 5; u12 = j0 >= 3; u21 = j0 == 1 || j0 == 3; u22 = j0 == 2 || j0 == 3 || j0 == 5 || j0 == 6;
+  }
+  const word m11 = u11 ? ~(word)0 : 0, m12 = u12 ? ~(word)0 : 0, m21 = u21 ? ~(word)0 : 0, m22 = u22 ? ~(word)0 : 0;
+  word x[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      x[a][b] = (grid[(a * 16 + b) * 32 + pp] & m11) ^ (grid[(a * 16 + b + 8) * 32 + pp] & m12) ^ (grid[((a + 8) * 16 + b) * 32 + pp] & m21) ^
+                (grid[((a + 8) * 16 + b + 8) * 32 + pp] & m22);
+  word *c = gchild + (pi * 2401 + 343 * j0) * c_bs + r * cw + w;
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c1[a][b] = winograd_child<word, BSIDE>(x[a][b], x[a][b + 4], x[a + 4][b], x[a + 4][b + 4], j1);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      word c2[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c2[a][b] = winograd_child<word, BSIDE>(c1[a][b], c1[a][b + 2], c1[a + 2][b], c1[a + 2][b + 2], j2);
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) {
+        const word v = winograd_child<word, BSIDE>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        if (NT) __builtin_nontemporal_store(v, &c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs]);
+        else c[(int64_t)(49 * j1 + 7 * j2 + j3) * c_bs] = v;
+      }
+    }
+  }
+}
+
 // The same pass with the seven top-level products of a word meeting in LDS instead of in HBM: a workgroup owns 32 word positions,
 // half-wave g (of 8; the last idles through the fold) folds the 343 products of top-level product g for them, scatters its 8 x 8
 // blocks into the 16 x 16 grid held in LDS (64 KiB, ds_xor) and, after ONE barrier, the workgroup writes the grid out -- every word of
@@ -1148,6 +1210,17 @@ extern "C" hipError_t gf2_launch_winograd_down4(hipStream_t s, int bside, const 
                                                 word *gchild, int64_t nparents, int64_t crows, int64_t cw) {
   const int64_t c_bs = crows * cw;
   if (nparents * c_bs == 0) return hipSuccess;
+  // the form that reads the ancestor once through LDS needs the 32 positions of a workgroup inside one descendant row: 0.92 ms against
+  // 1.26 ... 1.38 ms for the B side of 65536^3 (M4RI_AMD_DOWN4=direct selects the other form, for measurements)
+  static const bool want_lds = !(getenv("M4RI_AMD_DOWN4") && getenv("M4RI_AMD_DOWN4")[0] == 'd');
+  if (want_lds && cw % 32 == 0 && c_bs / 32 <= 0x7fffffffLL && nparents <= 65535) {
+    const dim3 g((unsigned)(c_bs / 32), (unsigned)nparents);
+#define D4L_LAUNCH(BS, NT) hipLaunchKernelGGL((winograd_down4_lds_kernel<BS, NT>), g, dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs, gchild, c_bs, crows, cw)
+    if (pass_nt() & 1) { if (bside) D4L_LAUNCH(true, true); else D4L_LAUNCH(false, true); }
+    else { if (bside) D4L_LAUNCH(true, false); else D4L_LAUNCH(false, false); }
+#undef D4L_LAUNCH
+    return hipGetLastError();
+  }
   const int64_t nposblocks = (c_bs + AUX_THREADS - 1) / AUX_THREADS, grid = pass4_grid(nposblocks);
   if (grid > 0x7fffffffLL || nparents > 65535) return hipErrorInvalidValue;
 #define D4_LAUNCH(BS, NT)                                                                                                             \
