@@ -1055,6 +1055,72 @@ __global__ __launch_bounds__(AUX_THREADS) void winograd_down4_lds_kernel(
   }
 }
 
+// The A side in the leaf's packed form, the same way -- and without the transpose.  A workgroup owns ONE word column and 32 consecutive
+// ROWS: lane = row, so that the two 32-bit chunks of a lane's word land in the packed array A4[chunk][row] as 32 consecutive dwords
+// = one full 128-byte line per chunk and child, straight from the registers (no LDS transpose, no barrier per output).  The price is
+// paid where it is cheap: the grid is LOADED 8 bytes per row (32 lines touched per block), and the other 15 words of every line belong
+// to the workgroups of the neighbouring word columns, which are numbered 8 apart so that they run on the same XCD next to each other and
+// find the line in its L2.
+template <int ROT, bool NT>
+__global__ __launch_bounds__(AUX_THREADS) void winograd_down4_pack_lds_kernel(
+    const word *__restrict__ anc, int64_t p_stride, int64_t p_bs,
+    uint32_t *__restrict__ a4, int64_t a4_bs,       // packed descendants, a4_bs dwords each
+    int64_t crows, int64_t cw) {                    // crows % 32 == 0, cw % 16 == 0
+  __shared__ word grid[256 * 32];
+  const int tid = threadIdx.x, pp = tid & 31, g = tid >> 5;
+  // blockIdx -> (row block, word column): 8 row blocks x 16 word columns per group of 128 workgroups, the 16 sharers of a line 8 apart
+  const int64_t b = blockIdx.x, grp = b >> 7, xcd = b & 7, slot = (b >> 3) & 15;
+  const int64_t wgroups = cw >> 4;                   // groups of 16 word columns per row block
+  const int64_t rb = (grp / wgroups) * 8 + xcd, wc = (grp % wgroups) * 16 + slot;
+  if (rb * 32 >= crows) return;                      // (whole workgroups: the row blocks of the last group may not all exist)
+  const int64_t r = rb * 32 + pp, pi = blockIdx.y;
+  const word *p   = anc + pi * p_bs + r * p_stride + wc;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) {
+    const int blk = k * 8 + g;
+    grid[blk * 32 + pp] = p[(int64_t)(blk >> 4) * crows * p_stride + (int64_t)(blk & 15) * cw];
+  }
+  __syncthreads();
+  if (g >= 7) return;
+  const int j0 = g;   // [A11, A12, S4, A22, S1, S2, S3]
+  const bool u11 = j0 == 0 || j0 == 2 || j0 == 5 || j0 == 6, u12 = j0 == 1 || j0 == 2, u21 = j0 == 2 || j0 == 4 || j0 == 5 || j0 == 6, u22 = j0 >= 2 && j0 <= 5;
+  const word m11 = u11 ? ~(word)0 : 0, m12 = u12 ? ~(word)0 : 0, m21 = u21 ? ~(word)0 : 0, m22 = u22 ? ~(word)0 : 0;
+  word x[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+      x[a][bb] = (grid[(a * 16 + bb) * 32 + pp] & m11) ^ (grid[(a * 16 + bb + 8) * 32 + pp] & m12) ^ (grid[((a + 8) * 16 + bb) * 32 + pp] & m21) ^
+                 (grid[((a + 8) * 16 + bb + 8) * 32 + pp] & m22);
+  const uint32_t rot = ROT == 1 ? (uint32_t)((r >> 6) & 3) : 0u;   // generation 4's byte rotation of the index dwords (m4rm8q_leaf.hip)
+  uint32_t *o = a4 + (pi * 2401 + 343 * j0) * a4_bs + (2 * wc) * crows + r;
+#pragma unroll
+  for (int j1 = 0; j1 < 7; ++j1) {
+    word c1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) c1[a][bb] = winograd_child<word, false>(x[a][bb], x[a][bb + 4], x[a + 4][bb], x[a + 4][bb + 4], j1);
+#pragma unroll
+    for (int j2 = 0; j2 < 7; ++j2) {
+      word c2[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) c2[a][bb] = winograd_child<word, false>(c1[a][bb], c1[a][bb + 2], c1[a + 2][bb], c1[a + 2][bb + 2], j2);
+#pragma unroll
+      for (int j3 = 0; j3 < 7; ++j3) {
+        const word v = winograd_child<word, false>(c2[0][0], c2[0][1], c2[1][0], c2[1][1], j3);
+        uint32_t w0 = (uint32_t)v, w1 = (uint32_t)(v >> 32);
+        if (ROT) { w0 = __builtin_amdgcn_alignbyte(w0, w0, rot); w1 = __builtin_amdgcn_alignbyte(w1, w1, rot); }
+        uint32_t *oo = o + (int64_t)(49 * j1 + 7 * j2 + j3) * a4_bs;
+        if (NT) { __builtin_nontemporal_store(w0, oo); __builtin_nontemporal_store(w1, oo + crows); }
+        else { oo[0] = w0; oo[crows] = w1; }
+      }
+    }
+  }
+}
+
 // The same pass with the seven top-level products of a word meeting in LDS instead of in HBM: a workgroup owns 32 word positions,
 // half-wave g (of 8; the last idles through the fold) folds the 343 products of top-level product g for them, scatters its 8 x 8
 // blocks into the 16 x 16 grid held in LDS (64 KiB, ds_xor) and, after ONE barrier, the workgroup writes the grid out -- every word of
@@ -1269,6 +1335,19 @@ extern "C" hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *
                                                      int64_t nparents, int64_t crows, int64_t cw, int rot) {
   if (nparents * crows * cw == 0) return hipSuccess;
   if (!gf2_winograd_down3_pack_ok(a4, crows, cw)) return hipErrorInvalidValue;
+  // the form without the transpose (one word column x 32 rows per workgroup, the grid through LDS): M4RI_AMD_DOWN4_PACK=lds
+  static const bool want_lds = getenv("M4RI_AMD_DOWN4_PACK") && getenv("M4RI_AMD_DOWN4_PACK")[0] == 'l';
+  if (want_lds && rot != 2 && crows % 32 == 0 && cw % 16 == 0 && nparents <= 65535) {
+    const int64_t groups = ((crows / 32 + 7) / 8) * (cw / 16);
+    if (groups * 128 <= 0x7fffffffLL) {
+      const dim3 g((unsigned)(groups * 128), (unsigned)nparents);
+#define DP4L_LAUNCH(R, NT) hipLaunchKernelGGL((winograd_down4_pack_lds_kernel<R, NT>), g, dim3(AUX_THREADS), 0, s, anc, p_stride, p_bs, reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw)
+      if (pass_nt() & 4) { if (rot == 1) DP4L_LAUNCH(1, true); else DP4L_LAUNCH(0, true); }
+      else { if (rot == 1) DP4L_LAUNCH(1, false); else DP4L_LAUNCH(0, false); }
+#undef DP4L_LAUNCH
+      return hipGetLastError();
+    }
+  }
   const int64_t tiles_r = crows / DP3_ROWS, tiles_w = cw / DP3_W;
   const int64_t grid = pass4_grid(tiles_r * tiles_w);
   if (grid > 0x7fffffffLL || nparents > 65535) return hipErrorInvalidValue;

@@ -40,7 +40,7 @@ def main():
                   "--warmup 1` (tools/prof_bench.sh); per-dispatch average summed over all instances; bytes = "
                   "(2*FETCH_SIZE + WRITE_SIZE)*1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
                   "half of a wide coalesced read stream), WRITE_SIZE as reported",
-        "source": f"profiles/{prefix}pmc_fetch.summary.txt, profiles/{prefix}pmc_write.summary.txt",
+        "source": f"profiles/{prefix}_bench{n}_pmc_fetch.summary.txt, profiles/{prefix}_bench{n}_pmc_write.summary.txt" if prefix else "pmc_fetch.summary.txt, pmc_write.summary.txt",
     }, open(out, "w"), indent=1)
     print(open(out).read())
 
