@@ -1335,8 +1335,9 @@ extern "C" hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *
                                                      int64_t nparents, int64_t crows, int64_t cw, int rot) {
   if (nparents * crows * cw == 0) return hipSuccess;
   if (!gf2_winograd_down3_pack_ok(a4, crows, cw)) return hipErrorInvalidValue;
-  // the form without the transpose (one word column x 32 rows per workgroup, the grid through LDS): M4RI_AMD_DOWN4_PACK=lds
-  static const bool want_lds = getenv("M4RI_AMD_DOWN4_PACK") && getenv("M4RI_AMD_DOWN4_PACK")[0] == 'l';
+  // the form without the transpose (one word column x 32 rows per workgroup, the grid through LDS) wherever the shape allows it:
+  // 1.13 against 1.33 ms at 65536^3; M4RI_AMD_DOWN4_PACK=transpose keeps the other
+  static const bool want_lds = !(getenv("M4RI_AMD_DOWN4_PACK") && getenv("M4RI_AMD_DOWN4_PACK")[0] == 't');
   if (want_lds && rot != 2 && crows % 32 == 0 && cw % 16 == 0 && nparents <= 65535) {
     const int64_t groups = ((crows / 32 + 7) / 8) * (cw / 16);
     if (groups * 128 <= 0x7fffffffLL) {

@@ -22,6 +22,7 @@
 #include <ctime>
 #include <sys/mman.h>
 #include <sys/sysinfo.h>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <list>
@@ -512,6 +513,18 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     return S;
   };
   const int nt = gi * gj;
+  // M4RI_AMD_PIPE_TRACE=1: the timeline of this call on stderr (host clock for the copies, HIP events for the products)
+  static const bool trace = getenv("M4RI_AMD_PIPE_TRACE") != nullptr;
+  struct Mark { char what; int a, b; double t0, t1; };
+  std::vector<Mark> marks;
+  std::mutex marks_mu;
+  timespec tl0;
+  clock_gettime(CLOCK_MONOTONIC, &tl0);
+  auto now_ms = [&]() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)(t.tv_sec - tl0.tv_sec) + 1e-6 * (double)(t.tv_nsec - tl0.tv_nsec); };
+  auto mark = [&](char what, int a, int b, double t0) { if (trace) { std::lock_guard<std::mutex> g(marks_mu); marks.push_back({what, a, b, t0, now_ms()}); } };
+  hipEvent_t tr_base = nullptr;
+  std::vector<hipEvent_t> tr_p0, tr_p1;
+  double tr_base_ms = 0;
   std::vector<DevMat> dA((size_t)gi * gk), dB((size_t)gk * gj), dC((size_t)nt);
   std::vector<hipEvent_t> upA((size_t)gi * gk, nullptr), upB((size_t)gk * gj, nullptr), upC((size_t)nt, nullptr), done((size_t)nt, nullptr);
   auto ev = [](hipEvent_t &e) { HIPDIE(hipEventCreateWithFlags(&e, hipEventDisableTiming)); };
@@ -519,7 +532,9 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     hipEvent_t &e = upA[(size_t)i * gk + k];
     if (e) return;
     const mzd_t S = block_of(A, rcut[(size_t)i], rcut[(size_t)i + 1], kcut[(size_t)k], kcut[(size_t)k + 1]);
+    const double t0 = trace ? now_ms() : 0;
     upload(dA[(size_t)i * gk + k], &S);
+    mark('A', i, k, t0);
     ev(e);
     HIPDIE(hipEventRecord(e, nullptr));
   };
@@ -527,7 +542,9 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     hipEvent_t &e = upB[(size_t)k * gj + j];
     if (e) return;
     const mzd_t S = block_of(B, kcut[(size_t)k], kcut[(size_t)k + 1], ccut[(size_t)j], ccut[(size_t)j + 1]);
+    const double t0 = trace ? now_ms() : 0;
     upload(dB[(size_t)k * gj + j], &S);
+    mark('B', k, j, t0);
     ev(e);
     HIPDIE(hipEventRecord(e, nullptr));
   };
@@ -553,9 +570,17 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
       }
       HIPDIE(hipEventSynchronize(done[(size_t)t]));
       mzd_t S = c_block(t / gj, t % gj);
+      const double t0 = trace ? now_ms() : 0;
       download(dC[(size_t)t], &S);
+      mark('D', t / gj, t % gj, t0);
     }
   });
+  if (trace) {
+    HIPDIE(hipEventCreate(&tr_base));
+    HIPDIE(hipEventRecord(tr_base, cs));
+    HIPDIE(hipEventSynchronize(tr_base));
+    tr_base_ms = now_ms();
+  }
   // products in the order (block of C, inner slice); the uploads of step s + 1 are issued right after product s
   const int steps = nt * gk;
   auto need_for = [&](int s) {
@@ -571,7 +596,9 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)k * gj + j], 0));
     HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
     const DevMat &a = dA[(size_t)i * gk + k], &b = dB[(size_t)k * gj + j];
+    if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p0.push_back(e); }
     HIPDIE(m4ri_amd_mul_dev(dC[(size_t)t].p, dC[(size_t)t].stride, a.p, a.stride, b.p, b.stride, R(i), K(k), Cc(j), (add || k > 0) ? 1 : 0, cutoff, cs));
+    if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p1.push_back(e); }
     if (k == gk - 1) {
       ev(done[(size_t)t]);
       HIPDIE(hipEventRecord(done[(size_t)t], cs));
@@ -585,6 +612,22 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
   }
   downloader.join();
   HIPDIE(hipDeviceSynchronize());
+  if (trace) {
+    const double t_end = now_ms();
+    for (size_t s = 0; s < tr_p0.size(); ++s) {
+      float a = 0, b = 0;
+      HIPDIE(hipEventElapsedTime(&a, tr_base, tr_p0[s]));
+      HIPDIE(hipEventElapsedTime(&b, tr_base, tr_p1[s]));
+      marks.push_back({'P', (int)s / gk, (int)s % gk, tr_base_ms + a, tr_base_ms + b});
+      (void)hipEventDestroy(tr_p0[s]);
+      (void)hipEventDestroy(tr_p1[s]);
+    }
+    (void)hipEventDestroy(tr_base);
+    std::sort(marks.begin(), marks.end(), [](const Mark &x, const Mark &y) { return x.t0 < y.t0; });
+    fprintf(stderr, "m4ri_amd pipeline %lld x %lld x %lld, grid %d x %d x %d: %.2f ms (A/B = upload of block (i,k)/(k,j), P = product (block of C, slice), D = download)\n",
+            (long long)m, (long long)l, (long long)n, gi, gj, gk, t_end);
+    for (const Mark &k : marks) fprintf(stderr, "  %c(%d,%d) %8.2f .. %8.2f  (%6.2f ms)\n", k.what, k.a, k.b, k.t0, k.t1, k.t1 - k.t0);
+  }
   for (auto *v : {&upA, &upB, &upC, &done})
     for (hipEvent_t e : *v)
       if (e) (void)hipEventDestroy(e);

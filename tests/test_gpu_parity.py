@@ -376,6 +376,9 @@ def test_three_level_fused_passes(oracle, m, l, n, cutoff, leaf_gen, add):
     (16384 + 40, 8192 + 70, 8192 + 130, 512, True, False),   # remainder strips around the even block
     (4096, 4096, 32768, 256, True, False),     # 32-word leaf rows: the up pass whose products meet in LDS, accumulating
     (4096, 4096, 32768, 256, False, True),     # the same, plain, writing into a wider parent
+    (4096, 16384, 4096, 256, False, False),    # 16-word leaf rows of A: the pack pass without the transpose (lane = row), one full group
+    (2560, 16384, 2048, 128, True, True),      # the same with 5 row blocks of 32 (the group's other three workgroups idle), strided
+    (4096, 32768, 4096, 256, False, False),    # two groups of 16 word columns per row block
 ])
 def test_four_level_fused_passes(oracle, m, l, n, cutoff, add, strided):
     """Four levels in one pass each way (aux_kernels.hip winograd_down4 / down4_pack / up4: the three-level passes with the top level
