@@ -17,6 +17,7 @@
 // Remainders that do not fit the even 2^L split are peeled with direct leaf launches exactly like
 // strassen.c:170-204.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -390,26 +391,76 @@ int reserve_apk(Engine *e, size_t words) {
 // ---- level planning ----------------------------------------------------------------------------
 bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strassen.c:39
 
+// ---- the engine's own depth: a time model -------------------------------------------------------------------------------
+// Rounds 1 - 4a split "while every half keeps 4096 rows, inner bits and columns".  That rule is right for cubes and wrong by up to
+// 13 % where one dimension is short and the others long (131072 x 8192 x 131072 wants leaves of 1024 inner bits: 18.3 against
+// 20.3 ms), and it knows nothing of what the strips of a ragged shape cost.  The depth is now the minimum of a small model of the
+// schedule's time, checked against every depth of 27 shapes (tools/depth_model_sweep.py, profiles/r04_depth_model_sweep.log:
+// the sum of the regrets against the best measured depth fell from 81 % to 11 %, no shape worse than 6 %):
+//   leaf launch  7^L products in tiles of 4096 rows x 512 columns (a partly filled tile costs a whole one), 256 tiles per round,
+//                a tile takes (inner bits / 32 + 4.5) stages of 2.43 us; a last partial round costs 1.2 x its fill + 0.1 of a
+//                round (it runs split); launches of at most one round run split all over the chip at 1.08 of ideal + 45 us
+//   passes       bytes of the fused / single passes of bfs_product at 5.3 TB/s + 4 us per launch; a four-level up pass whose leaf
+//                rows are not a multiple of 32 words falls back to atomics (the children written once more)
+//   strips       the three thin products around the even block, the inner one as a read-modify-write of C
+// The constants are one box's; only the ORDER of the depths matters, and that is set by ratios that move together.
+// Pure host arithmetic (m4ri_amd_plan_levels; tests/test_host_logic.py pins the table).
+double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
+  const int64_t mm = m >> L, ll = (l / (64ll << L)) * 64, nn = (n / (64ll << L)) * 64;
+  if (mm == 0 || ll == 0 || nn == 0) return 1e30;
+  constexpr double UNIT = 2.43e-6, FIXED = 4.5, BW = 5.3e12, LAUNCH = 4e-6, CUS = 256.0;
+  auto leaf = [&](int64_t pm, int64_t pl, int64_t pn, double count) {  // `count` products of one shape in one launch
+    if (pm <= 0 || pl <= 0 || pn <= 0) return 0.0;
+    const double tiles = count * (double)((pm + 4095) / 4096) * (double)((words_of(pn) + 7) / 8);
+    const double units = (double)((pl + 31) / 32) + FIXED;
+    if (tiles > CUS) {
+      const double full = std::floor(tiles / CUS), fr = tiles / CUS - full;
+      return (full + (fr > 0 ? std::min(1.0, 1.2 * fr + 0.1) : 0.0)) * units * UNIT;
+    }
+    return tiles * units / CUS * UNIT * 1.08 + 45e-6;
+  };
+  double p7 = 1;
+  for (int d = 0; d < L; ++d) p7 *= 7;
+  double t = leaf(mm, ll, nn, p7);
+  // passes over the even block
+  const int64_t me = mm << L, le = ll << L, ne = nn << L;
+  const double sa = 8.0 * (double)me * (double)words_of(le), sb = 8.0 * (double)le * (double)words_of(ne), sc = 8.0 * (double)me * (double)words_of(ne);
+  const int fuse = L < g_max_fuse ? L : (g_max_fuse > 0 ? g_max_fuse : 1);
+  auto r = [](int d) { double x = 1; while (d-- > 0) x *= 1.75; return x; };
+  double factor = 0;
+  for (int d = 0; d < L - fuse; ++d) factor += r(d) + r(d + 1);
+  if (L > 0) factor += r(L - fuse) + r(L);
+  double bytes = (sa + sb + sc) * factor;
+  if (L < 2) bytes += 2.0 * sa * r(L);                                // the separate pack pass of A
+  if (fuse == 4 && (words_of(nn) % 32) != 0) bytes += sc * (r(L) + 1);  // atomic up pass: zeroed output, children folded by read-modify-write
+  const int launches = 3 * ((L - fuse > 0 ? L - fuse : 0) + (L > 0 ? 1 : 0)) + 1;
+  t += bytes / BW + launches * LAUNCH;
+  // strips of a ragged shape: columns beyond the even block, inner bits beyond it (C read and written once more), rows beyond it
+  const int64_t rm = m - me, rl = l - le, rn = n - ne;
+  if (rn > 0) t += leaf(me, le, rn, 1) + 2.0 * sa / BW + 15e-6;
+  if (rl > 0) t += leaf(me, rl, n, 1) + 2.0 * 8.0 * (double)me * (double)words_of(n) / BW + 15e-6;
+  if (rm > 0) t += leaf(rm, l, n, 1) + 15e-6;
+  return t;
+}
+
 int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   int L = 0;
   if (cutoff == 0) {
-    // leaves keep >= 4096 inner bits and columns (128 stages, 8 column tiles per product) and may
-    // be as short as ONE 4096-row tile: the rectangular blocks of a multi-GPU split (e.g.
-    // 16384 x 65536 x 32768 per rank at 8 GPUs) then still get their full Strassen depth
-    int64_t mm = m, ll = l, nn = n;
-    while (L < MAX_LEVELS && mm / 2 >= DEFAULT_CUTOFF_M && ll / 2 >= DEFAULT_CUTOFF && nn / 2 >= DEFAULT_CUTOFF_N) { mm /= 2; ll /= 2; nn /= 2; ++L; }
-    // leaf rows come in tiles of 4096: a level that leaves 1.5 tiles per leaf (24576 -> 6144 rows) pays for 2.  One level less when
-    // its leaves waste less than the level saves (7/8 of the leaf work): 24576^3 runs 1.96 ms with 12288-row leaves, 2.34 ms with
-    // 6144-row ones; 100003 x 50021 x 70017 keeps its third level (48.3 against 49.1 ms) -- profiles/r04_depth_rule_sweep.log
-    auto waste = [&](int lv) {
-      const int64_t rows = m >> lv;
-      return rows <= 4096 ? 1.0 : (double)(((rows + 4095) / 4096) * 4096) / (double)rows;
-    };
-    if (L > 0 && waste(L - 1) <= 0.85 * waste(L)) --L;
+    // every depth whose leaves keep a whole tile of rows (half-filled tiles cost whole ones: 16384 x 65536 x 65536 takes 8.6 ms with
+    // leaves of 4096 rows and 12.3 ms with 2048) and at least one word of inner bits and columns; a deeper one has to win by 1 %
+    double best = depth_model_seconds(m, l, n, 0);
+    for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M; ++d) {
+      const double t = depth_model_seconds(m, l, n, d);
+      if (t < 0.99 * best) { best = t; L = d; }
+    }
   } else {
     // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
     int64_t a = m, b = l, c = n;
     while (L < MAX_LEVELS && !(closer(a, cutoff) || closer(b, cutoff) || closer(c, cutoff))) { a /= 2; b /= 2; c /= 2; ++L; }
+  }
+  if (const char *f = getenv("M4RI_AMD_LEVELS")) {  // developer override (tools/depth_model_sweep.py): this many levels, if the shape has them
+    const int want = atoi(f);
+    if (want >= 0 && want <= MAX_LEVELS) L = want;
   }
   // every level halves l and n on word boundaries and m on rows: need a non-empty even block
   while (L > 0 && ((m >> L) == 0 || (l / (64ll << L)) == 0 || (n / (64ll << L)) == 0)) --L;

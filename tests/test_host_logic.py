@@ -39,11 +39,16 @@ def test_reference_default_cutoff_depths_of_the_survey():
     assert [m4ri_amd.plan_levels(n, n, n, 4096) for n in (4096, 16384, 65536)] == [0, 2, 4]
 
 
-@pytest.mark.parametrize("shape,levels", [   # the engine's own depth: split while every half keeps 4096 rows, inner bits and columns
-    ((65536, 65536, 65536), 4), ((32768, 32768, 32768), 3), ((16384, 16384, 16384), 2), ((8192, 8192, 8192), 1), ((4096, 4096, 4096), 0),
-    ((131072, 131072, 131072), 5), ((131072, 8192, 131072), 1), ((131072, 16384, 131072), 2), ((100003, 50021, 70017), 3),
-    ((16421, 16453, 16523), 1), ((24576, 24576, 24576), 1),   # one level less where the leaves would be 1.5 tiles of rows (6144) or barely more than one (4105)
-    ((70000, 524288, 512), 0),
+@pytest.mark.parametrize("shape,levels", [   # the engine's own depth: the minimum of its time model (engine.hip depth_model_seconds),
+    # every row checked against the measured best depth (profiles/r04_depth_model_sweep.log, r04_depth_model_validation.log)
+    ((65536, 65536, 65536), 4), ((32768, 32768, 32768), 3), ((16384, 16384, 16384), 2), ((8192, 8192, 8192), 0), ((4096, 4096, 4096), 0),
+    ((131072, 131072, 131072), 5),
+    ((131072, 8192, 131072), 2), ((131072, 16384, 131072), 3), ((262144, 8192, 32768), 2), ((131072, 8192, 8192), 2),   # short inner dimension, long rows: leaves of 2048 inner bits pay
+    ((32768, 4096, 32768), 0), ((131072, 4096, 131072), 0),                                                          # ... leaves of 1024 do not
+    ((16384, 65536, 65536), 2), ((16384, 16384, 65536), 2),                                                          # leaves keep a whole 4096-row tile
+    ((100003, 50021, 70017), 2), ((16421, 16453, 16523), 0), ((50000, 12000, 90000), 0),                             # ragged: the strips cost more than a level saves
+    ((24576, 24576, 24576), 1), ((40960, 40960, 40960), 1), ((49152, 49152, 49152), 2), ((57344, 57344, 57344), 3),  # rows in whole tiles
+    ((70000, 524288, 512), 0), ((65536, 65536, 1024), 0), ((1100, 1290, 1411), 0),
 ])
 def test_engine_default_depth(shape, levels):
     assert m4ri_amd.plan_levels(*shape, 0) == levels
