@@ -415,9 +415,9 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
     const double units = (double)((pl + 31) / 32) + FIXED;
     if (tiles > CUS) {
       const double full = std::floor(tiles / CUS), fr = tiles / CUS - full;
-      return (full + (fr > 0 ? std::min(1.0, 1.2 * fr + 0.1) : 0.0)) * units * UNIT;
+      return (full + (fr > 0 ? std::min(1.0, 1.2 * fr + 0.1) : 0.0)) * units * UNIT + 20e-6;
     }
-    return tiles * units / CUS * UNIT * 1.08 + 45e-6;
+    return tiles * units / CUS * UNIT * 1.08 + 45e-6;  // (+ the pack, the split's reduce pass)
   };
   double p7 = 1;
   for (int d = 0; d < L; ++d) p7 *= 7;
@@ -448,8 +448,10 @@ int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   if (cutoff == 0) {
     // every depth whose leaves keep a whole tile of rows (half-filled tiles cost whole ones: 16384 x 65536 x 65536 takes 8.6 ms with
     // leaves of 4096 rows and 12.3 ms with 2048) and at least one word of inner bits and columns; a deeper one has to win by 1 %
+    // ... and 1024 inner bits and columns: below that no shape of the sweeps gained (65536 x 4096 x 65536 with leaves of 512 inner
+    // bits: 3.02 against 2.67 ms), and the model is not trusted where per-launch constants decide
     double best = depth_model_seconds(m, l, n, 0);
-    for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M; ++d) {
+    for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M && (l >> d) >= 1024 && (n >> d) >= 1024; ++d) {
       const double t = depth_model_seconds(m, l, n, d);
       if (t < 0.99 * best) { best = t; L = d; }
     }

@@ -1,6 +1,7 @@
 """Host-side scheduling logic of the engine that needs no GPU: the Strassen-Winograd depth rule
 (engine.hip plan_levels) against a restatement of the reference's recursion test (strassen.c:39,51,
 71-80) and the engine's documented default; the multi-GPU per-rank blocks keep their depth."""
+import numpy as np
 import pytest
 
 import m4ri_amd
@@ -52,6 +53,21 @@ def test_reference_default_cutoff_depths_of_the_survey():
 ])
 def test_engine_default_depth(shape, levels):
     assert m4ri_amd.plan_levels(*shape, 0) == levels
+
+
+def test_engine_default_depth_properties():
+    """What must hold for ANY shape, whatever the model's constants: leaves keep a whole 4096-row tile and 1024 inner bits and
+    columns (or the product stays unsplit), and the depth of a power-of-two cube from 16384 up leaves 4096^3 leaves (the
+    reference's own default depth)."""
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        m, l, n = (int(x) for x in np.exp(rng.uniform(np.log(64), np.log(300000), 3)))
+        L = m4ri_amd.plan_levels(m, l, n, 0)
+        assert 0 <= L <= 6
+        if L:
+            assert (m >> L) >= 4096 and (l >> L) >= 1024 and (n >> L) >= 1024, (m, l, n, L)
+    for k in range(14, 19):
+        assert m4ri_amd.plan_levels(1 << k, 1 << k, 1 << k, 0) == k - 12
 
 
 def test_per_rank_blocks_of_the_default_grids_keep_their_depth():
