@@ -332,9 +332,20 @@ int m4ri_amd_get_stats(m4ri_amd_stats *out);
 /* Strassen-Winograd levels the engine uses for an m x l x n product and this cutoff (pure host
    logic, callable without a GPU): cutoff > 0 follows the reference's rule (strassen.c:39,51 --
    halve while no dimension satisfies 3*dim < 4*cutoff, cutoff rounded down to a multiple of 64),
-   cutoff == 0 the engine's own default (split while m/2 >= 4096, l/2 >= 4096, n/2 >= 4096); both
-   capped so that every level still halves whole words. */
+   cutoff == 0 the engine's own plan: the depth a small time model of the schedule gives the first
+   (largest) block of rows -- see m4ri_amd_plan_row_blocks; both capped so that every level still
+   halves whole words. */
 int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
+
+/* The engine's own plan for an m x l x n product (cutoff == 0), pure host logic: the rows of A and C
+   in blocks, largest first, each multiplied by B as a product of its own at its own depth (the leaf's
+   tile is 4096 rows: 65664 = 65536 + 128 rows run as a four-level product and a thin one instead of
+   one level over rows that do not tile).  Writes the first `cap` blocks to rows[] / levels[] (either
+   may be NULL) and returns the number of blocks of the plan. */
+int m4ri_amd_plan_row_blocks(int64_t m, int64_t l, int64_t n, int64_t *rows, int *levels, int cap);
+/* What the engine's time model gives ONE m x l x n product at `levels` Strassen-Winograd levels, in seconds on the box the
+   constants were measured on (the plans above are minima of sums of it; tools/depth_model_sweep.py prints it beside measurements). */
+double m4ri_amd_model_seconds(int64_t m, int64_t l, int64_t n, int levels);
 
 /* Bytes the breadth-first schedule's workspace may take (0 = automatic: what the device has left).
    Levels that do not fit run depth-first, one sub-product after the other, like the reference's

@@ -184,6 +184,8 @@ SYMBOLS = {
     "m4ri_amd_set_profiling": (None, [_I]),
     "m4ri_amd_set_max_fuse": (_I, [_I]),
     "m4ri_amd_plan_levels": (_I, [_I64, _I64, _I64, _I]),
+    "m4ri_amd_plan_row_blocks": (_I, [_I64, _I64, _I64, ctypes.c_void_p, ctypes.c_void_p, _I]),
+    "m4ri_amd_model_seconds": (ctypes.c_double, [_I64, _I64, _I64, _I]),
     "m4ri_amd_set_workspace_budget": (_I64, [_I64]),
     "m4ri_amd_set_host_pipeline": (_I64, [_I64]),
     "m4ri_amd_pin": (_I, [MzdPtr]),
@@ -655,6 +657,19 @@ def unpin(M: Mzd) -> None:
 
 def is_pinned(M: Mzd) -> int:
     return int(lib().m4ri_amd_is_pinned(M.ptr))
+
+
+def plan_row_blocks(m: int, l: int, n: int):
+    """The engine's own plan (cutoff 0): [(rows, levels), ...], largest block of rows first (m4ri_amd_plan_row_blocks)."""
+    rows = (ctypes.c_int64 * 16)()
+    levels = (ctypes.c_int * 16)()
+    k = int(lib().m4ri_amd_plan_row_blocks(m, l, n, ctypes.cast(rows, ctypes.c_void_p), ctypes.cast(levels, ctypes.c_void_p), 16))
+    return [(int(rows[i]), int(levels[i])) for i in range(min(k, 16))]
+
+
+def model_seconds(m: int, l: int, n: int, levels: int) -> float:
+    """The engine's time model for one product at a depth (m4ri_amd_model_seconds)."""
+    return float(lib().m4ri_amd_model_seconds(m, l, n, levels))
 
 
 def plan_levels(m: int, l: int, n: int, cutoff: int = 0) -> int:

@@ -398,15 +398,16 @@ bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strass
 // schedule's time, checked against every depth of 27 shapes (tools/depth_model_sweep.py, profiles/r04_depth_model_sweep.log:
 // the sum of the regrets against the best measured depth fell from 81 % to 11 %, no shape worse than 6 %):
 //   leaf launch  7^L products in tiles of 4096 rows x 512 columns (a partly filled tile costs a whole one), 256 tiles per round,
-//                a tile takes (inner bits / 32 + 4.5) stages of 2.43 us; a last partial round costs 1.2 x its fill + 0.1 of a
-//                round (it runs split); launches of at most one round run split all over the chip at 1.08 of ideal + 45 us
+//                a tile takes (inner bits / 32 + 4.5) stages of 2.43 us; a last partial round costs its fill + 0.05 + 20 stages
+//                (it runs split); launches of at most one round run split all over the chip at 1.08 of ideal + 45 us
 //   passes       bytes of the fused / single passes of bfs_product at 5.3 TB/s + 4 us per launch; a four-level up pass whose leaf
 //                rows are not a multiple of 32 words falls back to atomics (the children written once more)
 //   strips       the three thin products around the even block, the inner one as a read-modify-write of C
 // The constants are one box's; only the ORDER of the depths matters, and that is set by ratios that move together.
 // Pure host arithmetic (m4ri_amd_plan_levels; tests/test_host_logic.py pins the table).
 double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
-  const int64_t mm = m >> L, ll = (l / (64ll << L)) * 64, nn = (n / (64ll << L)) * 64;
+  // (an unsplit product has no strips: the leaf takes any l and n as they are)
+  const int64_t mm = m >> L, ll = L ? (l / (64ll << L)) * 64 : l, nn = L ? (n / (64ll << L)) * 64 : n;
   if (mm == 0 || ll == 0 || nn == 0) return 1e30;
   constexpr double UNIT = 2.43e-6, FIXED = 4.5, BW = 5.3e12, LAUNCH = 4e-6, CUS = 256.0;
   auto leaf = [&](int64_t pm, int64_t pl, int64_t pn, double count) {  // `count` products of one shape in one launch
@@ -415,7 +416,7 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
     const double units = (double)((pl + 31) / 32) + FIXED;
     if (tiles > CUS) {
       const double full = std::floor(tiles / CUS), fr = tiles / CUS - full;
-      return (full + (fr > 0 ? std::min(1.0, 1.2 * fr + 0.1) : 0.0)) * units * UNIT + 20e-6;
+      return (full + (fr > 0 ? std::min(1.0, fr + 0.05 + 20.0 / units) : 0.0)) * units * UNIT + 20e-6;
     }
     return tiles * units / CUS * UNIT * 1.08 + 45e-6;  // (+ the pack, the split's reduce pass)
   };
@@ -431,7 +432,7 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   for (int d = 0; d < L - fuse; ++d) factor += r(d) + r(d + 1);
   if (L > 0) factor += r(L - fuse) + r(L);
   double bytes = (sa + sb + sc) * factor;
-  if (L < 2) bytes += 2.0 * sa * r(L);                                // the separate pack pass of A
+  if (L < 2 || (mm % 32) != 0 || (words_of(ll) % 16) != 0) bytes += 2.0 * sa * r(L);  // the separate pack pass of A: no fused form below two levels or for such leaves
   if (fuse == 4 && (words_of(nn) % 32) != 0) bytes += sc * (r(L) + 1);  // atomic up pass: zeroed output, children folded by read-modify-write
   const int launches = 3 * ((L - fuse > 0 ? L - fuse : 0) + (L > 0 ? 1 : 0)) + 1;
   t += bytes / BW + launches * LAUNCH;
@@ -443,18 +444,62 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   return t;
 }
 
+// depth of ONE product of these dimensions by the model (cutoff == 0)
+int model_levels(int64_t m, int64_t l, int64_t n, double *seconds) {
+  int L = 0;
+  // every depth whose leaves keep a whole tile of rows (half-filled tiles cost whole ones: 16384 x 65536 x 65536 takes 8.6 ms with
+  // leaves of 4096 rows and 12.3 ms with 2048); a deeper one has to win by 1 %
+  // ... and 1024 inner bits and columns: below that no shape of the sweeps gained (65536 x 4096 x 65536 with leaves of 512 inner
+  // bits: 3.02 against 2.67 ms), and the model is not trusted where per-launch constants decide
+  double best = depth_model_seconds(m, l, n, 0);
+  for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M && (l >> d) >= 1024 && (n >> d) >= 1024; ++d) {
+    const double t = depth_model_seconds(m, l, n, d);
+    if (t < 0.99 * best) { best = t; L = d; }
+  }
+  if (seconds) *seconds = best;
+  return L;
+}
+
+// Rows in blocks.  The leaf's tile is 4096 rows, so a depth is only worth its passes when m / 2^L is (close to) a multiple of 4096:
+// 65664 = 65536 + 128 rows ran ONE level (39.7 ms against 27.5 for 65536^3), 36864 = 32768 + 4096 one level (7.1 ms).  Rows, unlike
+// inner bits and columns, can be cut anywhere without a reduction: C's rows [r0, r1) = A's rows [r0, r1) * B.  So the engine cuts
+// m into blocks of k * 4096 * 2^L rows, largest first, each at its own depth (the rest recursively), when the model says the sum is
+// 7 % cheaper than the best single product; B's down pass is repeated per block, which the model counts.
+struct RowBlock { int64_t rows; int levels; };
+double plan_row_blocks(int64_t m, int64_t l, int64_t n, std::vector<RowBlock> &out, int depth = 0) {
+  double t1 = 0;
+  const int L1 = model_levels(m, l, n, &t1);
+  std::vector<RowBlock> best{{m, L1}};
+  double best_t = t1;
+  static const bool off = getenv("M4RI_AMD_ROW_BLOCKS") && getenv("M4RI_AMD_ROW_BLOCKS")[0] == '0';  // developer switch: one product
+  if (!off && depth < 6) {
+    for (int d = 1; d <= MAX_LEVELS; ++d) {
+      const int64_t unit = (int64_t)DEFAULT_CUTOFF_M << d, k = m / unit;
+      if (k < 1) break;
+      const int64_t rows = k * unit;
+      if (rows == m) continue;
+      double tb = 0;
+      const int Lb = model_levels(rows, l, n, &tb);
+      if (Lb < d) continue;  // the block would not use the depth it was cut for
+      std::vector<RowBlock> rest;
+      const double t = tb + plan_row_blocks(m - rows, l, n, rest, depth + 1);
+      if (t < 0.93 * best_t) {  // 7 %: on ragged shapes the model flatters the blocks by up to 8 points (profiles/r04_row_blocks_sweep.log)
+        best_t = t;
+        best.assign(1, RowBlock{rows, Lb});
+        best.insert(best.end(), rest.begin(), rest.end());
+      }
+    }
+  }
+  out = best;
+  return best_t;
+}
+
 int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   int L = 0;
   if (cutoff == 0) {
-    // every depth whose leaves keep a whole tile of rows (half-filled tiles cost whole ones: 16384 x 65536 x 65536 takes 8.6 ms with
-    // leaves of 4096 rows and 12.3 ms with 2048) and at least one word of inner bits and columns; a deeper one has to win by 1 %
-    // ... and 1024 inner bits and columns: below that no shape of the sweeps gained (65536 x 4096 x 65536 with leaves of 512 inner
-    // bits: 3.02 against 2.67 ms), and the model is not trusted where per-launch constants decide
-    double best = depth_model_seconds(m, l, n, 0);
-    for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M && (l >> d) >= 1024 && (n >> d) >= 1024; ++d) {
-      const double t = depth_model_seconds(m, l, n, d);
-      if (t < 0.99 * best) { best = t; L = d; }
-    }
+    std::vector<RowBlock> blocks;  // the depth of the first (largest) block of rows: what the stats of a call report
+    plan_row_blocks(m, l, n, blocks);
+    L = blocks.empty() ? 0 : blocks[0].levels;
   } else {
     // the reference's rule: recurse until one dimension is "closer to cutoff than to its half"
     int64_t a = m, b = l, c = n;
@@ -725,12 +770,20 @@ size_t df_words(const Engine *e, int64_t m, int64_t l, int64_t n, int L, double 
 int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int cutoff) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
   if (m == 0 || n == 0) return 0;
-  const int L = plan_levels(m, l, n, cutoff);
+  // the engine's own plan may cut the rows into blocks, each at its depth (plan_row_blocks); a caller's cutoff or the developer's
+  // M4RI_AMD_LEVELS mean one product at that depth
+  std::vector<RowBlock> blocks;
+  if (cutoff == 0 && !getenv("M4RI_AMD_LEVELS")) plan_row_blocks(m, l, n, blocks);
+  if (blocks.empty()) blocks.push_back(RowBlock{m, plan_levels(m, l, n, cutoff)});
+  for (RowBlock &b : blocks)  // every level halves l and n on word boundaries and m on rows: need a non-empty even block
+    while (b.levels > 0 && ((b.rows >> b.levels) == 0 || (l / (64ll << b.levels)) == 0 || (n / (64ll << b.levels)) == 0)) --b.levels;
+  const int L = blocks[0].levels;
   e->stats.levels = L;
   // depth-first levels (workspace larger than the device has left) take their temporaries from a grow-only stack
   // sized here, before the first launch: product() itself never allocates, frees or synchronises
   const double budget = workspace_budget(e);
-  const size_t need   = df_words(e, m, l, n, L, budget);
+  size_t need = 0;
+  for (const RowBlock &b : blocks) { const size_t w = df_words(e, b.rows, l, n, b.levels, budget); if (w > need) need = w; }
   if (need > e->df_cap) {
     HIPTRY(hipDeviceSynchronize());
     if (e->df_pool) HIPTRY(hipFree(e->df_pool));
@@ -738,8 +791,13 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
     HIPTRY(hipMalloc(reinterpret_cast<void **>(&e->df_pool), need * sizeof(word)));
     e->df_cap = need;
   }
-  e->df_used = 0;
-  return product(e, st, C, A, B, add, L, budget);
+  int64_t r0 = 0;
+  for (const RowBlock &b : blocks) {  // one after the other on the stream: they share the workspace
+    e->df_used = 0;
+    if (int rc = product(e, st, dview(C, r0, 0, b.rows, C.ncols), dview(A, r0, 0, b.rows, A.ncols), B, add, b.levels, budget)) return rc;
+    r0 += b.rows;
+  }
+  return 0;
 }
 
 void reset_stats(Engine *e) {
@@ -840,6 +898,22 @@ int m4ri_amd_fill_rows_dev(word *M, int64_t stride, int64_t row0, int64_t rows, 
 
 int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols, void *stream) {
   return (int)gf2_launch_mask_tail((hipStream_t)stream, M, stride, rows, ncols);
+}
+
+double m4ri_amd_model_seconds(int64_t m, int64_t l, int64_t n, int levels) {
+  if (m <= 0 || l <= 0 || n <= 0 || levels < 0 || levels > MAX_LEVELS) return 0.0;
+  return depth_model_seconds(m, l, n, levels);
+}
+
+int m4ri_amd_plan_row_blocks(int64_t m, int64_t l, int64_t n, int64_t *rows, int *levels, int cap) {
+  if (m <= 0 || l <= 0 || n <= 0) return 0;
+  std::vector<RowBlock> blocks;
+  plan_row_blocks(m, l, n, blocks);
+  for (size_t i = 0; i < blocks.size() && (int)i < cap; ++i) {
+    if (rows) rows[i] = blocks[i].rows;
+    if (levels) levels[i] = blocks[i].levels;
+  }
+  return (int)blocks.size();
 }
 
 int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {  // pure host logic: no device needed

@@ -411,6 +411,31 @@ def test_four_level_fused_passes(oracle, m, l, n, cutoff, add, strided):
         m4ri_amd.set_max_fuse(old)
 
 
+@pytest.mark.parametrize("m,l,n,add", [
+    (33000, 33000, 33000, False),              # 32768 rows at three levels + 232 rows unsplit; 33000 = 64 * 512 + 232: strips on the inner dimension and the columns
+    (20480, 20480, 20480, True),               # 16384 rows at two levels + 4096 rows unsplit, accumulating onto C
+])
+def test_rows_in_blocks_match_one_product(oracle, m, l, n, add):
+    """The engine's own plan cuts rows that do not tile into blocks, each a product of its own at its own depth (engine.hip
+    plan_row_blocks); a caller's cutoff means ONE product by the reference's rule.  Same bits, and Freivalds' identity against the
+    oracle's thin products."""
+    plan = m4ri_amd.plan_row_blocks(m, l, n)
+    assert len(plan) == 2 and plan[0][0] in (16384, 32768) and plan[0][1] >= 2 and sum(r for r, _ in plan) == m
+    A, B, C0 = dev_random(m, l, 131), dev_random(l, n, 132), dev_random(m, n, 133)
+    wl, w = (l + 63) // 64, (n + 63) // 64
+    C = C0.clone()
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add)
+    assert m4ri_amd.get_stats().levels == plan[0][1]
+    D = C0.clone()
+    m4ri_amd.mul_dev(D.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add, cutoff=8192)
+    torch.cuda.synchronize()
+    assert torch.equal(C, D)
+    hC = to_host(C, m, n)
+    if add:   # C0 + A*B: fold C0 back out before the identity
+        hC.rows()[:, :] ^= to_host(C0, m, n).rows()
+    assert freivalds(oracle, to_host(A, m, l), to_host(B, l, n), hC, m, l, n, 79)
+
+
 def test_randomized_shapes_windows_cutoffs(oracle):
     """Seeded fuzz through the C ABI: random shapes, cutoffs, mul/addmul, operands and results that are
     windows of larger parents (column offsets on word boundaries, mzd.c:161), checked word for word

@@ -47,12 +47,34 @@ def test_reference_default_cutoff_depths_of_the_survey():
     ((131072, 8192, 131072), 2), ((131072, 16384, 131072), 3), ((262144, 8192, 32768), 2), ((131072, 8192, 8192), 2),   # short inner dimension, long rows: leaves of 2048 inner bits pay
     ((32768, 4096, 32768), 0), ((131072, 4096, 131072), 0),                                                          # ... leaves of 1024 do not
     ((16384, 65536, 65536), 2), ((16384, 16384, 65536), 2),                                                          # leaves keep a whole 4096-row tile
-    ((100003, 50021, 70017), 2), ((16421, 16453, 16523), 0), ((50000, 12000, 90000), 0),                             # ragged: the strips cost more than a level saves
-    ((24576, 24576, 24576), 1), ((40960, 40960, 40960), 1), ((49152, 49152, 49152), 2), ((57344, 57344, 57344), 3),  # rows in whole tiles
+    ((16421, 16453, 16523), 0), ((50000, 12000, 90000), 0),                                                          # ragged: the strips cost more than a level saves
+    ((24576, 24576, 24576), 1), ((49152, 49152, 49152), 2), ((57344, 57344, 57344), 3),                              # rows in whole tiles
     ((70000, 524288, 512), 0), ((65536, 65536, 1024), 0), ((1100, 1290, 1411), 0),
 ])
 def test_engine_default_depth(shape, levels):
     assert m4ri_amd.plan_levels(*shape, 0) == levels
+
+
+@pytest.mark.parametrize("shape,blocks", [   # rows that do not tile: the largest block of k * 4096 * 2^L rows at its own depth, the rest after it
+    ((65664, 65664, 65664), [(65536, 4), (128, 0)]),            # 29.9 ms; the best single product takes 38.4 (profiles/r04_row_blocks_sweep.log)
+    ((69632, 65536, 65536), [(65536, 4), (4096, 0)]),           # 29.9 against 37.7
+    ((36864, 36864, 36864), [(32768, 2), (4096, 0)]),           # 6.23 against 6.90
+    ((40960, 40960, 40960), [(32768, 3), (8192, 1)]),           # 8.51 against 9.02
+    ((100003, 50021, 70017), [(98304, 3), (1699, 0)]),          # 41.3 against 47.8
+    ((70000, 70000, 70000), [(65536, 3), (4464, 0)]),           # 41.0 against 45.5
+    ((20480, 20480, 20480), [(16384, 2), (4096, 0)]),           # 1.22 against 1.45
+    ((33000, 33000, 33000), [(32768, 3), (232, 0)]),            # 5.24 against 5.62
+    ((73728, 16384, 65536), [(65536, 3), (8192, 1)]),           # 9.33 against 9.80
+    ((66000, 66000, 66000), [(65536, 4), (464, 0)]),            # 31.2 against 40.1
+    ((20480, 65536, 65536), [(16384, 2), (4096, 0)]),           # 10.6 against 11.8
+    ((69632, 8192, 131072), [(65536, 2), (4096, 0)]),           # 9.45 against 10.3
+    ((65536, 65536, 65536), [(65536, 4)]), ((49152, 49152, 49152), [(49152, 2)]), ((45000, 45000, 45000), [(45000, 2)]),   # one product stays one product
+    ((50000, 12000, 90000), [(50000, 0)]), ((34000, 20000, 20000), [(34000, 0)]),   # blocks measured 10 and 16 % slower: a separate pack pass, strips twice
+])
+def test_engine_row_blocks(shape, blocks):
+    got = m4ri_amd.plan_row_blocks(*shape)
+    assert got == blocks and sum(r for r, _ in got) == shape[0]
+    assert m4ri_amd.plan_levels(*shape, 0) == blocks[0][1]
 
 
 def test_engine_default_depth_properties():
@@ -66,6 +88,12 @@ def test_engine_default_depth_properties():
         assert 0 <= L <= 6
         if L:
             assert (m >> L) >= 4096 and (l >> L) >= 1024 and (n >> L) >= 1024, (m, l, n, L)
+        blocks = m4ri_amd.plan_row_blocks(m, l, n)
+        assert sum(r for r, _ in blocks) == m and all(r > 0 for r, _ in blocks) and blocks[0][1] == L
+        for r, lv in blocks[:-1]:      # every block but the last is whole tiles of rows at its depth
+            assert lv >= 1 and r % (4096 << 1) == 0, (m, l, n, blocks)
+        for r, lv in blocks:
+            assert lv == 0 or (r >> lv) >= 4096
     for k in range(14, 19):
         assert m4ri_amd.plan_levels(1 << k, 1 << k, 1 << k, 0) == k - 12
 

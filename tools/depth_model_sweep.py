@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Time of one device-resident product at EVERY Strassen depth the shape has (M4RI_AMD_LEVELS forces it), next to the depth the engine
-picks by itself: the data the depth rule of engine.hip plan_levels is checked against.  usage: depth_model_sweep.py [m,l,n ...]"""
+"""Time of one device-resident product at EVERY Strassen depth the shape has (M4RI_AMD_LEVELS forces ONE product at that depth), next
+to the plan the engine makes by itself (rows in blocks, each at its depth: engine.hip plan_row_blocks): the data the engine's time
+model is checked against.  usage: depth_model_sweep.py [m,l,n ...]   (`*` = the depth of the plan's first block)"""
 import os
 import sys
 import time
@@ -30,7 +31,13 @@ for (m, l, n) in shapes:
     m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wl, B.data_ptr(), wn, m, l, n, False, 0)
     torch.cuda.synchronize()
     auto = m4ri_amd.get_stats().levels
-    out, sums, seen = [], [], set()
+    t = time.perf_counter()
+    for _ in range(reps):
+        m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wl, B.data_ptr(), wn, m, l, n, False, 0)
+    torch.cuda.synchronize()
+    plan = m4ri_amd.plan_row_blocks(m, l, n)
+    out = [f"engine's plan {'+'.join(f'{r}@L{lv}' for r, lv in plan)} {(time.perf_counter() - t) / reps * 1e3:8.3f} ms"]
+    sums, seen = [int(C.sum().item())], set()
     for L in range(0, 6):
         os.environ["M4RI_AMD_LEVELS"] = str(L)
         try:
