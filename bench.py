@@ -1092,6 +1092,8 @@ def main():
                          + ("" if not multi else " (slab-cyclic over the ranks)" if args.layout == "distributed" else " of rank 0; C gathered to rank 0"),
                 "per_rank_product": per_rank_product,
                 "strassen_levels": int(stats.levels),
+                # the engine's own plan for the per-rank product: rows in blocks [rows, levels], largest first (one block = one product)
+                "row_blocks": ([list(b) for b in m4ri_amd.plan_row_blocks(*per_rank_product)] if args.workload != "leaf16384" and not args.cutoff else None),
                 "leaf_shape": [int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n)],
                 "leaf_products_per_rank": int(stats.leaf_products),
                 "workspace_GiB": stats.workspace_bytes / 2 ** 30,
