@@ -1082,7 +1082,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": (f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves"
+                "workload": (f"mzd_mul {M}x{L}x{N} (not a BASELINE.json configuration): Strassen-Winograd over M4RM leaves"
+                             if args.workload == "mul" and (M, L, N) != (65536, 65536, 65536) else
+                             f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves"
                              if args.workload == "mul" else
                              f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4])" if args.workload == "rect131072"
                              else f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])"),
