@@ -473,17 +473,35 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
   } else {
     egi = (int)((m + ((m / 4 + 4095) / 4096) * 4096 - 1) / (((m / 4 + 4095) / 4096) * 4096)); egj = 1; egk = 1;
   }
+  // cut number i of `parts` through `total`: on the coarsest grid of unit * 2^j (j <= 5) that moves it by at most 8 % of a part, else
+  // on whole tiles of rows / whole words
+  auto coarse_cut = [](int64_t total, int parts, int i, int64_t unit0, int64_t prev, bool rows) -> int64_t {
+    const int64_t target = total * i / parts, fine = rows ? ((target + 4095) / 4096) * 4096 : (target / 64) * 64;
+    for (int j = 5; j >= 1; --j) {
+      const int64_t unit = unit0 << j, c = ((target + unit / 2) / unit) * unit;
+      const int64_t off = c > target ? c - target : target - c;
+      if (c > prev && c < total && off * 100 <= 8 * (total / parts)) return c;
+    }
+    return fine;
+  };
   if (n >= 16384 || nenv >= 2) {
-    for (int i = 0; i < egi; ++i) rcut.push_back(((m * i / egi + 4095) / 4096) * 4096);
+    // rows are cut on the coarsest grid of 4096 * 2^j rows that moves the cut by at most 8 % of a block: the engine gives a block of
+    // k * 4096 * 2^L rows its full Strassen depth (engine.hip plan_row_blocks) -- 65664 rows cut 32768 + 32896, not 36864 + 28800
+    rcut.push_back(0);
+    for (int i = 1; i < egi; ++i) rcut.push_back(coarse_cut(m, egi, i, 4096, rcut.back(), true));
     rcut.push_back(m);
   } else {
     const int64_t srows = ((m / 4 + 4095) / 4096) * 4096;
     for (int64_t r = 0; r < m; r += srows) rcut.push_back(r);
     rcut.push_back(m);
   }
-  for (int j = 0; j < egj; ++j) ccut.push_back((n * j / egj / 64) * 64);
+  // columns and inner bits likewise, on 1024 * 2^j bits (whole words at every Strassen level the block will use): no strips in the
+  // blocks before the last
+  ccut.push_back(0);
+  for (int j = 1; j < egj; ++j) ccut.push_back(coarse_cut(n, egj, j, 1024, ccut.back(), false));
   ccut.push_back(n);
-  for (int k = 0; k < egk; ++k) kcut.push_back((l * k / egk / 64) * 64);
+  kcut.push_back(0);
+  for (int k = 1; k < egk; ++k) kcut.push_back(coarse_cut(l, egk, k, 1024, kcut.back(), false));
   kcut.push_back(l);
   const int gi = (int)rcut.size() - 1, gj = (int)ccut.size() - 1, gk = (int)kcut.size() - 1;
   int dev = 0;

@@ -22,7 +22,8 @@ def _gpu():
 
 
 @pytest.mark.parametrize("m,l,n", [(16384, 1000, 900), (16384 + 37, 2000, 1500), (20000, 257, 4100), (40000, 640, 640), (16385, 64, 1),
-                                   (16384, 300, 16384), (20001, 700, 17000 + 13), (16500, 64, 30000)])   # n >= 16384: the 2 x 2 grid
+                                   (16384, 300, 16384), (20001, 700, 17000 + 13), (16500, 64, 30000),
+                                   (33000, 300, 16384 + 1)])   # n >= 16384: the 2 x 2 grid; 33000 rows cut at 16384 (the coarse grid), 20001 at 12288
 def test_pipelined_products_match_oracle(oracle, m, l, n):
     A, B = Mzd.random(m, l, 1), Mzd.random(l, n, 2)
     want = oracle.mul(None, A, B, 0)
