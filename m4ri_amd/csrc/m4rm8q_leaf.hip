@@ -56,10 +56,10 @@
 #endif
 // rows of A held ahead by the gather-only waves (the builders hold K8_AR = 16)
 #ifndef K8Q_AR_OTHER
-#define K8Q_AR_OTHER 16
+#define K8Q_AR_OTHER 32  // a whole stage ahead: the same on full tiles, a little better on partly filled ones (their rows live on these waves)
 #endif
 #ifndef K8Q_PD_OTHER
-#define K8Q_PD_OTHER 1  // 2 and 3 fit in the gather-only waves' registers and measure the same
+#define K8Q_PD_OTHER 1  // 2 and 3 fit in the gather-only waves' registers and measure the same, on full and on partly filled tiles
 #endif
 
 namespace {
@@ -144,7 +144,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   const int w0   = tile_n * K8_TW + c * 2;  // this lane's two words of the row
   const bool v0  = w0 < p.wn;
   const bool v1  = (w0 + 1) < p.wn;
-  const int row0 = tile_m * K8_R + rgrp * RG;
+  // the gather-only waves (4..7) own the FIRST 2048 rows of the tile, the builder waves the last: the rows of a partly filled tile then
+  // do not share their waves' issue slots with the table building (a tile of at most 2048 rows: 1.80 instead of 2.10 us per stage;
+  // same box, alternating builds: 464 x 66000 x 66000 2.34 -> 2.07 ms, 2048 x 65536 x 65536 2.10 -> 1.80 ms, full tiles unchanged --
+  // profiles/r04_leaf_partial_tiles_variants.log).  Such a tile stays issue-bound on its one gather wave per SIMD (32 rows x 4
+  // gathers = ~520 instructions a stage), not LDS-bound: a deeper gather pipeline (K8Q_PD_OTHER 2, 3), the A dwords further ahead and
+  // builder waves with four stages of B rows ahead all measured the same.  Bits 1..2 of the row group, which set `rot`, are untouched.
+  const int rowg = rgrp ^ 64;        // row group of the TILE this lane owns
+  const int row0 = tile_m * K8_R + rowg * RG;
   const uint32_t a_qs   = (uint32_t)p.apk_stride * 4u;  // bytes between chunks of the packed A (m_pad rows)
   const uint32_t b_rs   = (uint32_t)p.b_stride * 8u;
   const uint32_t a_lane = (uint32_t)row0 * 4u;
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   };
   if (q_begin < q_end) {
     // a wave owns 512 consecutive rows of the tile; in the last row tile some waves own only padding
-    const bool active  = !(K8Q_EXP & 2) && __builtin_amdgcn_readfirstlane(tile_m * K8_R + (tid >> 6) * (16 * RG)) < p.m;
+    const bool active  = !(K8Q_EXP & 2) && __builtin_amdgcn_readfirstlane(tile_m * K8_R + ((tid >> 6) ^ 4) * (16 * RG)) < p.m;
     const bool builder = __builtin_amdgcn_readfirstlane(tid >> 8) == K8Q_BUILDER_HALF;
     if (builder) { if (active) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
     else         { if (active) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void m4rm8q_kernel(const LeafArgs p) 
   // into this workgroup's own dense slab; gf2_launch_reduce_partials folds the slabs into C.
   const bool to_slab = !XOR_OUT && p.mode == 2;
   if (v0 || to_slab) {
-    word *cp         = to_slab ? p.Cpart + (int64_t)slab * LEAF_PART_WORDS + (int64_t)rgrp * RG * K8_TW + c * 2
+    word *cp         = to_slab ? p.Cpart + (int64_t)slab * LEAF_PART_WORDS + (int64_t)rowg * RG * K8_TW + c * 2
                                : Cb + (int64_t)row0 * p.c_stride + w0;
     const int64_t cst = to_slab ? (int64_t)K8_TW : p.c_stride;
     const int rows    = to_slab ? RG : ((p.m - row0) < RG ? (p.m - row0) : RG);  // may be <= 0
