@@ -395,8 +395,9 @@ bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strass
 // Rounds 1 - 4a split "while every half keeps 4096 rows, inner bits and columns".  That rule is right for cubes and wrong by up to
 // 13 % where one dimension is short and the others long (131072 x 8192 x 131072 wants leaves of 1024 inner bits: 18.3 against
 // 20.3 ms), and it knows nothing of what the strips of a ragged shape cost.  The depth is now the minimum of a small model of the
-// schedule's time, checked against every depth of 27 shapes (tools/depth_model_sweep.py, profiles/r04_depth_model_sweep.log:
-// the sum of the regrets against the best measured depth fell from 81 % to 11 %, no shape worse than 6 %):
+// schedule's time, checked against every depth of 64 shapes (tools/depth_model_sweep.py, profiles/r04_depth_model_sweep.log,
+// r04_depth_model_validation.log, r04_row_blocks_sweep*.log: on the first 27 the sum of the regrets against the best measured depth
+// fell from 81 % to 11 %; over all 64 the plan is within 2.7 % of the best alternative known, a 12288^3 excepted at 7.9 %):
 //   leaf launch  7^L products in tiles of 4096 rows x 512 columns (a partly filled tile costs a whole one), 256 tiles per round,
 //                a tile takes (inner bits / 32 + 4.5) stages of 2.43 us; a last partial round costs its fill + 0.05 + 20 stages
 //                (it runs split); launches of at most one round run split all over the chip at 1.08 of ideal + 45 us
