@@ -179,8 +179,23 @@ struct LeafKind { int gen; int rg; int rows; double rate; };
 const LeafKind LEAF_KINDS[4] = {{4, 32, 4096, 6.7}, {1, 32, 1024, 4.1}, {1, 24, 768, 3.4}, {1, 16, 512, 2.8}};
 constexpr int LEAF_KIND_FALLBACK = 1;  // generation 1, 1024 rows: needs no packed A
 
-LeafKind pick_leaf(int64_t m) {
+LeafKind pick_leaf(int64_t m, int64_t l, int64_t n) {
   static const int forced_gen = getenv("M4RI_AMD_LEAF_GEN") ? atoi(getenv("M4RI_AMD_LEAF_GEN")) : 0;  // developer override
+  // A few rows against a LARGE B -- the last block of a rows-in-blocks plan, a thin strip -- is generation 1's: its stage is lighter
+  // (a partly filled generation-4 tile is bound by the issue of its one gather wave per SIMD: 1.8 us a stage whatever the rows) and
+  // with 16384 columns or more its 2048-column tiles and the inner split fill the chip by themselves.  profiles/r04_thin_products_by_leaf_generation.log:
+  // 464 x 66000 x 66000 2.08 -> 0.96 ms, 848 x 50000 x 50000 1.10 -> 0.74, 232 x 33000 x 33000 0.58 -> 0.24, 464 x 16384 x 16384 0.143 -> 0.124;
+  // 1000 x 16384 x 16384 (0.150 vs 0.188), 464 x 65536 x 4096, 1024 x 1024 x 65536 and everything from ~1300 rows on stay with generation 4.
+  if (!forced_gen && n >= 16384 && ((m <= 512 && (double)l * (double)n >= 268435456.0) || (m <= 1024 && (double)l * (double)n >= 1073741824.0))) {
+    LeafKind best = LEAF_KINDS[LEAF_KIND_FALLBACK];
+    double best_cost = 1e300;
+    for (const LeafKind &k : LEAF_KINDS) {
+      if (k.gen != 1) continue;
+      const double cost = (double)(((m + k.rows - 1) / k.rows) * k.rows) / k.rate;
+      if (cost < best_cost) { best_cost = cost; best = k; }
+    }
+    return best;
+  }
   // Generation 4 from 192 rows on, however few of its 4096 tile rows that fills: its waves that own only padding skip their
   // gathers, so a short tile costs the LDS array its real rows, and its 512-column tiles put four times as many
   // workgroups on the chip as the 2048-column tiles of generation 1 (single products: 1024 x 1024 x 65536 70.8 vs 140.7 us,
@@ -221,7 +236,7 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   // 32-bit byte offsets inside one operand (raw buffer addressing)
   if ((uint64_t)m * (uint64_t)as * 8 >= (1ull << 32) || (uint64_t)l * (uint64_t)bs * 8 >= (1ull << 32))
     return (int)hipErrorInvalidValue;
-  LeafKind kind      = pick_leaf(m);
+  LeafKind kind      = pick_leaf(m, l, n);
   const int64_t wn   = words_of(n);
   const int64_t tw   = kind.gen == 4 ? 8 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
@@ -413,6 +428,9 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   constexpr double UNIT = 2.43e-6, FIXED = 4.5, BW = 5.3e12, LAUNCH = 4e-6, CUS = 256.0;
   auto leaf = [&](int64_t pm, int64_t pl, int64_t pn, double count) {  // `count` products of one shape in one launch
     if (pm <= 0 || pl <= 0 || pn <= 0) return 0.0;
+    const double ln = (double)pl * (double)pn;
+    if (count == 1 && pn >= 16384 && ((pm <= 512 && ln >= 268435456.0) || (pm <= 1024 && ln >= 1073741824.0)))
+      return 45e-6 + ln * (pm <= 512 ? 2.1e-13 : 3.2e-13);  // a few rows against a large B: generation 1 (pick_leaf)
     const double tiles = count * (double)((pm + 4095) / 4096) * (double)((words_of(pn) + 7) / 8);
     const double units = (double)((pl + 31) / 32) + FIXED;
     if (tiles > CUS) {
@@ -465,7 +483,7 @@ int model_levels(int64_t m, int64_t l, int64_t n, double *seconds) {
 // 65664 = 65536 + 128 rows ran ONE level (39.7 ms against 27.5 for 65536^3), 36864 = 32768 + 4096 one level (7.1 ms).  Rows, unlike
 // inner bits and columns, can be cut anywhere without a reduction: C's rows [r0, r1) = A's rows [r0, r1) * B.  So the engine cuts
 // m into blocks of k * 4096 * 2^L rows, largest first, each at its own depth (the rest recursively), when the model says the sum is
-// 7 % cheaper than the best single product; B's down pass is repeated per block, which the model counts.
+// 8 % cheaper than the best single product; B's down pass is repeated per block, which the model counts.
 struct RowBlock { int64_t rows; int levels; };
 double plan_row_blocks(int64_t m, int64_t l, int64_t n, std::vector<RowBlock> &out, int depth = 0) {
   double t1 = 0;
@@ -484,7 +502,7 @@ double plan_row_blocks(int64_t m, int64_t l, int64_t n, std::vector<RowBlock> &o
       if (Lb < d) continue;  // the block would not use the depth it was cut for
       std::vector<RowBlock> rest;
       const double t = tb + plan_row_blocks(m - rows, l, n, rest, depth + 1);
-      if (t < 0.93 * best_t) {  // 7 %: on ragged shapes the model flatters the blocks by up to 8 points (profiles/r04_row_blocks_sweep.log)
+      if (t < 0.92 * best_t) {  // 8 %: on ragged shapes the model flatters the blocks by up to 8 points (profiles/r04_row_blocks_sweep.log)
         best_t = t;
         best.assign(1, RowBlock{rows, Lb});
         best.insert(best.end(), rest.begin(), rest.end());
@@ -528,7 +546,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   auto materialised = [&](int d) { return d <= L - fuse || d == L; };
   // With a fused last pass and a leaf that reads packed A, the pass writes the packed form itself:
   // the row-major A operands of the leaves are never materialised and the pack pass disappears.
-  const LeafKind leaf_kind = pick_leaf(m >> L);
+  const LeafKind leaf_kind = pick_leaf(m >> L, (l / (64ll << L)) * 64, (n / (64ll << L)) * 64);  // (the dimensions launch_leaf_one will see)
   bool prepack = false;
   if (fuse >= 2 && leaf_kind.gen == 4) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
