@@ -475,6 +475,26 @@ def test_randomized_shapes_windows_cutoffs(oracle):
         assert np.array_equal(got.buf, want.buf), (case, m, l, n, cutoff, add, Cp is not None)
 
 
+@pytest.mark.parametrize("m,l,n,gen", [
+    (464, 16384, 16384 + 37, 1),      # a few rows against a large B: generation 1 by shape (engine.hip pick_leaf)
+    (1000, 32768, 32768 + 64, 1),     # up to 1024 rows once l * n >= 2^30
+    (1000, 16384, 16384, 4),          # ... below that generation 4 keeps them
+    (464, 65536, 4096, 4),            # and with fewer than 16384 columns
+])
+def test_thin_products_pick_their_leaf_by_shape(oracle, m, l, n, gen):
+    hA, hB, hC = Mzd.random(m, l, 141), Mzd.random(l, n, 142), Mzd.random(m, n, 143)
+    wl, w = hA.rowstride, hB.rowstride
+    A = torch.from_numpy(hA.rows().view(np.int64).copy()).cuda()
+    B = torch.from_numpy(hB.rows().view(np.int64).copy()).cuda()
+    for add in (False, True):
+        C = torch.from_numpy(hC.rows().view(np.int64).copy()).cuda()
+        m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), wl, B.data_ptr(), w, m, l, n, add=add)
+        st = m4ri_amd.get_stats()
+        assert st.levels == 0 and st.leaf_gen == gen
+        want = oracle.addmul(hC.copy(), hA, hB, 0) if add else oracle.mul(None, hA, hB, 0)
+        assert to_host(C, m, n).equal(want), f"add={add}"
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("add", [False, True])
 def test_leaf_full_rounds_plus_split_tail_matches_plain_launch(add, ragged):
