@@ -284,6 +284,8 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
         if (c < best_cost * 0.99) { best_cost = c; tail_tiles = rem; tail_ksplit = (int)ks; }
       }
       if (tail_tiles) ksplit = 1;
+      static const int forced_tail = getenv("M4RI_AMD_TAIL_KSPLIT") ? atoi(getenv("M4RI_AMD_TAIL_KSPLIT")) : 0;  // developer: split the short last round this way
+      if (forced_tail > 0) { tail_tiles = forced_tail > 1 ? rem : 0; tail_ksplit = forced_tail; ksplit = 1; }
     }
   }
   if (kind.gen == 4) {  // the kernel rounds splits to whole stage pairs: work with the counts it will use
