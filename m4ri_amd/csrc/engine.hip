@@ -280,7 +280,11 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
       const int64_t rem = tiles % e->cus, full_rounds = tiles / e->cus;
       for (int64_t ks = 2; ks <= cap; ++ks) {
         const int64_t rounds = (rem * ks + e->cus - 1) / e->cus;
-        const double c = (double)full_rounds * ((double)stages + fixed) + (double)rounds * ((double)((stages + ks - 1) / ks) + fixed + split_cost(rem, ks));
+        // (the tail's slabs and their reduce pass once per launch, at half the price per slab of a launch that is split as a whole: with
+        // the calibration above 16384^3 -- 392 tiles, 1.53 rounds -- stayed unsplit at 0.673 ms where three splits of its 136-tile tail
+        // give 0.632; profiles/r04_leaf_split_model_ab.log holds the table of 48 shapes before and after: nothing else moves)
+        const double tail_cost = kind.gen == 4 ? ((double)LEAF_SPLIT_COST_BITS + 1.0 * (double)(rem * ks)) / (double)sbits : split_cost(rem, ks);
+        const double c = (double)full_rounds * ((double)stages + fixed) + (double)rounds * ((double)((stages + ks - 1) / ks) + fixed) + tail_cost;
         if (c < best_cost * 0.99) { best_cost = c; tail_tiles = rem; tail_ksplit = (int)ks; }
       }
       if (tail_tiles) ksplit = 1;
