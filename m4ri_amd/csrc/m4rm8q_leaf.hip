@@ -34,7 +34,8 @@
 //     inner dimension (ksplit); the engine uses both to run full rounds of 256 workgroups unsplit and
 //     only the short last round split.  Splits combine without atomics: mode 2 stores every
 //     (tile, split) into its own dense slab and gf2_launch_reduce_partials folds the slabs into C.
-//   * Waves whose 512 rows all lie below the matrix (last row tile of a ragged m) skip their gathers.
+//   * Waves whose 512 rows all lie below the matrix (last row tile of a ragged m) skip their gathers; the gather-only waves own
+//     the tile's FIRST 2048 rows, so a partly filled tile keeps its rows away from the table building (round 4).
 //
 // Everything else is generation 3's: C-stationary tile in VGPRs (128 dwords per lane), one
 // v_perm_b32 per lookup address, one v_bitop3_b32 per dword folds two lookups, Gray-code table
