@@ -123,16 +123,28 @@ def cpu_baseline(n_workload: int, budget_s: float = 75.0):
     A1, B1 = Mzd.init(4096, 4096), Mzd.init(4096, 4096)
     rnd(A1.ptr)
     rnd(B1.ptr)
-    ts = []
-    for _ in range(12):
+    # the reference's own stop rule (bench/benchmarking.c:502-603 with its defaults, benchmarking.c:81-91): at least 2 samples, at most
+    # 1000, until the 99 % confidence interval of the mean (Student's t) is within 1 % of the mean or 60 s have passed -- on wall time
+    # here (`-s 0`), capped at 10 s so that the default run stays short; one untimed warm-up first
+    from scipy import stats as _st
+    r = ref.L.mzd_mul(None, A1.ptr, B1.ptr, 0)
+    ref.L.mzd_free(r)
+    ts, t_start, ci_rel = [], time.perf_counter(), None
+    while len(ts) < 1000:
         t = time.perf_counter()
         r = ref.L.mzd_mul(None, A1.ptr, B1.ptr, 0)
         ts.append(time.perf_counter() - t)
         ref.L.mzd_free(r)
-    ts = ts[2:]
+        if len(ts) >= 2:
+            mean = sum(ts) / len(ts)
+            sd = (sum((x - mean) ** 2 for x in ts) / (len(ts) - 1)) ** 0.5
+            ci_rel = float(_st.t.ppf(0.995, len(ts) - 1)) * sd / len(ts) ** 0.5 / mean
+            if ci_rel <= 0.01 or time.perf_counter() - t_start > 10.0:
+                break
     out["config1"] = {"what": "bench_multiplication 4096 4096 4096: mzd_mul(NULL,A,B,0) incl. allocating C, srandom(17) + mzd_randomize inputs, "
-                              "sequential SSE2 build, 10 samples after 2 warm-ups (a fixed count in place of the reference's adaptive stop rule, "
-                              "bench/benchmarking.c:502-603: >= 2 samples until the 99 % CI is within 1 % of the mean)",
+                              "sequential SSE2 build; the reference's stop rule (bench/benchmarking.c:502-603): >= 2 samples until the 99 % "
+                              "confidence interval of the mean is within 1 % of it, on wall time, at most 1000 samples / 10 s",
+                      "samples": len(ts), "ci99_rel": ci_rel,
                       "seconds_mean": sum(ts) / len(ts), "seconds_min": min(ts), "bitops_per_sec": 4096 ** 3 / (sum(ts) / len(ts)), "cores": 1}
     # (2) the workload itself on all cores: mzd_mul_mp (OpenMP build), once, if a 16384^3 probe says it fits the budget
     omp = cpu_libs.reference(openmp=True, tag=tag) or cpu_libs.reference(openmp=True)
