@@ -123,6 +123,8 @@ struct Engine {
   hipEvent_t last_done    = nullptr;  // on ANOTHER stream first waits for this event (recorded after every product)
   bool have_last          = false;
   std::mutex mu;                      // one host thread at a time plans on this device's workspace; other devices do not wait
+  hipStream_t aux_stream = nullptr;   // second stream of the overlap experiment / the pipelined schedule
+  hipEvent_t aux_ev[2]   = {nullptr, nullptr};
 };
 
 std::mutex g_cfg_mu;  // the process-wide knobs (workspace budget, fuse depth)
@@ -336,7 +338,14 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  if (kind.gen == 4 && tail_tiles > 0) {
+  static const int exp_groups = getenv("M4RI_AMD_LEAF_GROUPS") ? atoi(getenv("M4RI_AMD_LEAF_GROUPS")) : 0;  // developer: the batch in this many launches
+  if (kind.gen == 4 && exp_groups > 1 && batch % exp_groups == 0 && ksplit == 1) {
+    for (int g = 0; g < exp_groups; ++g) {
+      LeafArgs part = a;
+      part.tile_base = (tiles / exp_groups) * g; part.tile_count = tiles / exp_groups;
+      HIPTRY(gf2_launch_m4rm8q(st, part, e->apk));
+    }
+  } else if (kind.gen == 4 && tail_tiles > 0) {
     LeafArgs head = a, tail = a;
     head.tile_base = 0; head.tile_count = tiles - tail_tiles;
     tail.tile_base = tiles - tail_tiles; tail.tile_count = tail_tiles;
@@ -628,6 +637,21 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     }
     d += step;
   }
+  // developer experiment (profiles/r05_overlap_power/): the three four-level passes once more on a second stream UNDER the leaf
+  // launch (same sources, same destinations, same values; the up pass reads half-written products and its output is overwritten
+  // by the real one) -- what the leaf loses to HBM-bound work beside it bounds what a pipelined schedule could win
+  static const int exp_overlap = getenv("M4RI_AMD_OVERLAP_EXP") ? atoi(getenv("M4RI_AMD_OVERLAP_EXP")) : 0;
+  const bool overlap_now = exp_overlap && L == 4 && fuse == 4 && prepack;
+  if (overlap_now) {
+    if (!e->aux_stream) { HIPTRY(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking)); HIPTRY(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPTRY(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming)); }
+    HIPTRY(hipEventRecord(e->aux_ev[0], st));
+    HIPTRY(hipStreamWaitEvent(e->aux_stream, e->aux_ev[0], 0));
+    const int64_t cm = m >> 4, cl = l >> 4, cn = n >> 4;
+    if (exp_overlap & 1) HIPTRY(gf2_launch_winograd_down4_pack(e->aux_stream, A.p, A.stride, 0, e->apk, 1, cm, cl / 64, 1));
+    if (exp_overlap & 2) HIPTRY(gf2_launch_winograd_down4(e->aux_stream, 1, B.p, B.stride, 0, Bl[4], 1, cl, cn / 64));
+    if (exp_overlap & 4) HIPTRY(gf2_launch_winograd_up4(e->aux_stream, 0, Pl[4], C.p, C.stride, 0, 1, cm, cn / 64));
+    HIPTRY(hipEventRecord(e->aux_ev[1], e->aux_stream));
+  }
   // all 7^L leaf products in one launch
   {
     const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = ipow7(L);
@@ -635,6 +659,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
                              ll * (ln / 64), lm, ll, ln, cnt, false, 0, prepack))
       return rc;
   }
+  if (overlap_now) HIPTRY(hipStreamWaitEvent(st, e->aux_ev[1], 0));
   // up passes: the fused pass at the bottom first (L -> L - fuse), then level d+1 -> d
   for (int d = L; d > 0;) {
     const int step    = d == L ? fuse : 1;
