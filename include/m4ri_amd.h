@@ -367,11 +367,15 @@ int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes);
    launches and download (28 ... 80 us whatever the size) stop paying: a product with m * l * n at or below the threshold whose
    matrices live in host memory is computed by the library's own host Method of Four Russians (small_host.cpp) on the calling
    thread -- on an initialised device, never instead of one: without a GPU the entry points still abort.  Default 2^26 (406^3);
-   0 sends every product to the GPU; returns the previous value, negative arguments only query.  m4ri_amd_small_product_count: how
+   0 sends every product to the GPU; returns the previous value, negative arguments only query.  The routine's own cost is bounded
+   as well (threshold / 320 row-word operations: degenerate shapes such as 1 x 1 x 2^26 go to the GPU whatever m * l * n says);
+   m4ri_amd_small_product_wanted is that rule (pure arithmetic, no GPU: 1 = the host routine would take this product).  The device
+   lock is released while the routine runs: small products of many threads run side by side.  m4ri_amd_small_product_count: how
    many products took that path.  m4ri_amd_small_mul_host is the routine itself: C (+)= A * B on host mzd_t (windows allowed, the
    bits outside C's columns kept); returns 0, or -1 on mismatched dimensions. */
 int64_t m4ri_amd_set_small_product_threshold(int64_t ops);
 int64_t m4ri_amd_small_product_count(void);
+int m4ri_amd_small_product_wanted(int64_t m, int64_t l, int64_t n);
 int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B, int add);
 
 /* Release the engine's workspace (device memory pool) and the host entry points' staging arena;
@@ -467,12 +471,32 @@ int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M);             /* every
 int m4ri_amd_dmat_download(const m4ri_amd_dmat *d, mzd_t *M);           /* a windowed M keeps the bits outside its columns */
 int m4ri_amd_dmat_convert(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src); /* dst <- src, any two layouts (ROWS -> REPLICATED = all-gather) */
 int m4ri_amd_dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant);
+/* The same on lane `lane` (0 or 1): every lane has its own streams, events and arenas on every device, and products of different
+ * lanes do not wait for each other -- two INDEPENDENT products (different C, neither C an operand of the other) issued
+ * alternately on lanes 0 and 1 keep two in flight: the operand and result transport of one under the multiplications of the
+ * other (on a device the multiplications themselves take turns: one engine workspace).  Everything that is not a product
+ * (fill, upload, convert, download) runs on lane 0 behind the last operation of EVERY lane, and the first product of a lane after
+ * such an operation waits for it.  m4ri_amd_dmat_mul == lane 0. */
+int m4ri_amd_dmat_mul_lane(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant, int lane);
 int m4ri_amd_multi_sync(void);
+/* First contact with DIFFERENT devices (the first call that configures the ranks): peer access is enabled pair by pair, then every
+ * ordered pair makes one 1 MiB copy behind one cross-device event wait and checks the data; a failure prints the pair and the HIP
+ * error and fails the call before any product is scheduled.  Pairs without peer access copy through pinned host memory instead
+ * (m4ri_amd_multi_stats.pairs_staged counts them).  Environment, for tests on one GPU: M4RI_AMD_SELFTEST_PAIRS=1 runs the self-test
+ * between ranks of one device too; M4RI_AMD_NO_PEER="all" | "i-j,k-l" treats these rank pairs as having no peer access.
+ * m4ri_amd_multi_pair_table is the pure rule (no GPU): staged[dst * world + src] from the ranks' devices, the ndev x ndev table
+ * can_access[d * ndev + e] (hipDeviceCanAccessPeer) and that hook. */
+void m4ri_amd_multi_pair_table(int world, const int *devices, int ndev, const int *can_access, const char *no_peer_spec, char *staged);
+/* The links, measured over the ranks' own link streams: `bytes` copied dst <- src for every ordered pair of ranks one at a time
+ * (pair_gbs[dst * W + src] in GB/s) and all pairs at once (*all_gbs: all bytes / wall time); staged[] as above; *same_device = 1 when
+ * ranks share a device (those pairs report the on-device copy rate).  all_gbs, staged, same_device may be NULL. */
+int m4ri_amd_multi_link_probe(int64_t bytes, double *pair_gbs, double *all_gbs, char *staged, int *same_device);
 /* what the most recent m4ri_amd_dmat_mul / m4ri_amd_mul_multi / mzd_mul_mp did */
 typedef struct m4ri_amd_multi_stats {
   int32_t world, variant, levels, sub_products; /* variant: M4RI_AMD_VARIANT_*; levels / sub_products: Strassen schedule   */
   int32_t chunks, overlap, converted;           /* row chunks per sub-product; slabs: gather under the first product;       */
-  int32_t reserved;                             /* operands converted to the schedule's layout first (0 on the fast path)   */
+  int32_t pairs_staged;                         /* operands converted to the schedule's layout first (0 on the fast path);  */
+                                                /* ordered rank pairs that copy through the host (no peer access)           */
   int64_t m, l, n;
   double link_bytes;                            /* bytes that crossed between ranks                                          */
 } m4ri_amd_multi_stats;

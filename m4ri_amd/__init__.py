@@ -76,7 +76,7 @@ class MultiStats(ctypes.Structure):
     """m4ri_amd_multi_stats."""
 
     _fields_ = [("world", ctypes.c_int32), ("variant", ctypes.c_int32), ("levels", ctypes.c_int32), ("sub_products", ctypes.c_int32),
-                ("chunks", ctypes.c_int32), ("overlap", ctypes.c_int32), ("converted", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("chunks", ctypes.c_int32), ("overlap", ctypes.c_int32), ("converted", ctypes.c_int32), ("pairs_staged", ctypes.c_int32),
                 ("m", ctypes.c_int64), ("l", ctypes.c_int64), ("n", ctypes.c_int64), ("link_bytes", ctypes.c_double)]
 
 
@@ -210,6 +210,7 @@ SYMBOLS = {
     "m4ri_amd_release_workspace": (None, []),
     "m4ri_amd_set_small_product_threshold": (_I64, [_I64]),
     "m4ri_amd_small_product_count": (_I64, []),
+    "m4ri_amd_small_product_wanted": (_I, [_I64, _I64, _I64]),
     "m4ri_amd_small_mul_host": (_I, [MzdPtr, MzdPtr, MzdPtr, _I]),
     "m4ri_amd_dmat_create": (_P, [_I64, _I64, _I]),
     "m4ri_amd_dmat_free": (None, [_P]),
@@ -220,7 +221,10 @@ SYMBOLS = {
     "m4ri_amd_dmat_download": (_I, [_P, MzdPtr]),
     "m4ri_amd_dmat_convert": (_I, [_P, _P]),
     "m4ri_amd_dmat_mul": (_I, [_P, _P, _P, _I, _I, _I]),
+    "m4ri_amd_dmat_mul_lane": (_I, [_P, _P, _P, _I, _I, _I, _I]),
     "m4ri_amd_multi_sync": (_I, []),
+    "m4ri_amd_multi_pair_table": (None, [_I, ctypes.POINTER(ctypes.c_int), _I, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_char_p]),
+    "m4ri_amd_multi_link_probe": (_I, [_I64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "m4ri_amd_multi_get_stats": (_I, [ctypes.POINTER(MultiStats)]),
     "m4ri_amd_multi_timeline": (_I, [_I, ctypes.POINTER(ctypes.c_double), _I]),
     "m4ri_amd_multi_default_variant": (_I, [_I, _I64, _I64, _I64]),
@@ -572,10 +576,41 @@ class Dmat:
         return self
 
 
-def dmat_mul(C: Dmat, A: Dmat, B: Dmat, add: bool = False, cutoff: int = 0, variant: int = VARIANT_AUTO) -> Dmat:
-    """C (+)= A*B on distributed operands; asynchronous (multi_sync)."""
-    _check(lib().m4ri_amd_dmat_mul(C.h, A.h, B.h, int(add), cutoff, variant), "m4ri_amd_dmat_mul")
+def dmat_mul(C: Dmat, A: Dmat, B: Dmat, add: bool = False, cutoff: int = 0, variant: int = VARIANT_AUTO, lane: int = 0) -> Dmat:
+    """C (+)= A*B on distributed operands; asynchronous (multi_sync).  lane 0 / 1: independent products issued alternately on the two
+    lanes keep two in flight (m4ri_amd_dmat_mul_lane)."""
+    if lane:
+        _check(lib().m4ri_amd_dmat_mul_lane(C.h, A.h, B.h, int(add), cutoff, variant, lane), "m4ri_amd_dmat_mul_lane")
+    else:
+        _check(lib().m4ri_amd_dmat_mul(C.h, A.h, B.h, int(add), cutoff, variant), "m4ri_amd_dmat_mul")
     return C
+
+
+def multi_pair_table(devices, can_access, no_peer: str = "") -> list:
+    """The pure rule behind the multi-device path's pair table (no GPU): staged[dst][src] = 1 where copies dst <- src go through the
+    host.  `can_access`: ndev x ndev nested lists (hipDeviceCanAccessPeer)."""
+    w, ndev = len(devices), len(can_access)
+    dev = (ctypes.c_int * w)(*devices)
+    can = (ctypes.c_int * (ndev * ndev))(*[int(x) for row in can_access for x in row])
+    out = ctypes.create_string_buffer(w * w)
+    lib().m4ri_amd_multi_pair_table(w, dev, ndev, can, no_peer.encode() if no_peer else None, out)
+    return [[out.raw[i * w + j] for j in range(w)] for i in range(w)]
+
+
+def multi_link_probe(nbytes: int = 256 << 20) -> dict:
+    """Every ordered pair of ranks copies `nbytes` one pair at a time, then all pairs at once (m4ri_amd_multi_link_probe)."""
+    w = len(get_devices())
+    pair = (ctypes.c_double * (w * w))()
+    allg, same = ctypes.c_double(0.0), ctypes.c_int(0)
+    staged = ctypes.create_string_buffer(w * w)
+    _check(lib().m4ri_amd_multi_link_probe(nbytes, pair, ctypes.byref(allg), staged, ctypes.byref(same)), "m4ri_amd_multi_link_probe")
+    rates = sorted(pair[i * w + j] for i in range(w) for j in range(w) if i != j)
+    return {"bytes_per_copy": nbytes, "pairs": len(rates), "gbs_per_direction_min": rates[0] if rates else None,
+            "gbs_per_direction_median": rates[len(rates) // 2] if rates else None, "gbs_per_direction_max": rates[-1] if rates else None,
+            "all_at_once_gbs": allg.value, "all_at_once_gbs_per_direction": allg.value / max(1, len(rates)),
+            "pair_gbs": [[round(pair[i * w + j], 2) for j in range(w)] for i in range(w)],
+            "peer_access": [[int(i == j or not staged.raw[i * w + j]) for j in range(w)] for i in range(w)],
+            "ranks_share_devices": bool(same.value)}
 
 
 def multi_sync() -> None:

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -211,10 +212,16 @@ struct Rank {
   std::vector<hipEvent_t> ev_lin, ev_lout;
   std::vector<char> lin_used, lout_used;  // this link stream has copies the next join has not collected yet
   // All events carry timestamps: they double as the marks of the per-phase timeline (m4ri_amd_multi_timeline)
-  hipEvent_t ev_start = nullptr, ev_down = nullptr, ev_gather = nullptr, ev_first = nullptr, ev_back = nullptr, ev_done = nullptr;
+  hipEvent_t ev_start = nullptr, ev_down = nullptr, ev_gather = nullptr, ev_first = nullptr, ev_back = nullptr;
+  // "my part of the operation is complete", double-buffered by the parity of the lane's operation count: operation k records slot
+  // k & 1 and waits for slot (k - 1) & 1 of every rank, which nobody re-records before operation k + 1 -- and that is only issued
+  // after every thread of operation k has returned (Pool::run).  With ONE event a rank whose thread was late waited for the
+  // CURRENT operation of the ranks that had already finished issuing (hipStreamWaitEvent takes the event's latest record): ranks
+  // serialised behind each other by thread timing
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
+  bool done_recorded[2] = {false, false};
   hipEvent_t ev_tl0 = nullptr, ev_tl1 = nullptr;  // first and last mark of the most recent PRODUCT (uploads, downloads, conversions leave them alone)
   std::vector<hipEvent_t> ev_in, ev_prod;  // per unit (round, row chunk) of the Strassen schedule
-  bool done_recorded = false;
   word *arena = nullptr;
   size_t cap  = 0;  // words
   word *buf[B_COUNT] = {};
@@ -222,12 +229,29 @@ struct Rank {
   // what the last operation recorded (for the timeline)
   int tl_units = 0;
   bool tl_strassen = false, tl_gathered = false, tl_valid = false;
+  // pairs without peer access (or with M4RI_AMD_NO_PEER set: the test hook) copy through this pinned bounce buffer, in order on the link stream
+  std::vector<word *> bounce;  // per stream slot: 0..W-1 inbound links, W..2W-1 outbound links, 2W the compute stream
+};
+
+// Two LANES of ranks over the same devices: each its own streams, events and arenas.  Lane 0 carries everything; lane 1 exists for
+// m4ri_amd_dmat_mul_lane, so that two independent products can be in flight -- the operand and result transport of one under the
+// multiplications of the other (the products themselves take turns on a device: one engine workspace, engine.hip).
+constexpr int NUM_LANES = 2;
+struct Lane {
+  std::vector<std::unique_ptr<Rank>> ranks;
+  int parity = 0;            // slot of ev_done the lane's NEXT operation records
+  uint64_t seen_excl = 0;    // the latest exclusive operation (any lane) this lane's work is ordered behind
 };
 
 std::mutex g_multi_mu;
 std::vector<int> g_devices;   // the devices products are spread over (an id may repeat: "virtual" ranks)
 bool g_devices_set = false;
-std::vector<std::unique_ptr<Rank>> g_ranks;
+Lane g_lane[NUM_LANES];
+std::vector<std::unique_ptr<Rank>> &g_ranks = g_lane[0].ranks;  // lane 0: the ranks every operation but a lane-1 product runs on
+uint64_t g_excl_id = 0;       // exclusive operations issued so far (everything but a product: uploads, fills, conversions, downloads)
+int g_excl_lane    = 0;       // the lane the latest one ran on
+std::vector<char> g_staged;   // W x W: copies dst rank <- src rank go through the host (no peer access between their devices, or the test hook)
+int g_pairs_staged = 0;
 uint64_t g_config_gen = 1;    // bumped whenever the ranks are rebuilt: distributed matrices of an older configuration are dead
 int64_t g_threshold = 16384;  // smallest min(m, l, n) mzd_mul_mp spreads over several devices
 int g_variant = 0;            // 0 automatic, 1 row slabs, 2 Strassen sub-products (m4ri_amd_set_multi_variant)
@@ -345,9 +369,8 @@ void default_devices() {
   }
 }
 
-void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks empty
-  g_pool.shutdown();
-  for (auto &rp : g_ranks) {
+void drop_lane(Lane &L) {  // streams, events, arenas and bounce buffers of every rank of a lane
+  for (auto &rp : L.ranks) {
     Rank &r = *rp;
     (void)hipSetDevice(r.device);
     if (r.st) (void)hipStreamSynchronize(r.st);
@@ -375,15 +398,178 @@ void drop_ranks() {  // streams, events and arenas of every rank; leaves g_ranks
       }
     }
     if (r.arena) (void)hipFree(r.arena);
+    for (word *b : r.bounce)
+      if (b) (void)hipHostFree(b);
     for (hipStream_t s : {r.st, r.ci, r.co})
       if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {r.ev_start, r.ev_down, r.ev_gather, r.ev_first, r.ev_back, r.ev_done, r.ev_tl0, r.ev_tl1})
+    for (hipEvent_t e : {r.ev_start, r.ev_down, r.ev_gather, r.ev_first, r.ev_back, r.ev_done[0], r.ev_done[1], r.ev_tl0, r.ev_tl1})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_prod) (void)hipEventDestroy(e);
   }
-  g_ranks.clear();
+  L.ranks.clear();
+  L.parity = 0;
+  L.seen_excl = 0;
+}
+
+void drop_ranks() {  // every lane; leaves g_ranks empty
+  g_pool.shutdown();
+  for (Lane &L : g_lane) drop_lane(L);
+  g_staged.clear();
+  g_pairs_staged = 0;
   ++g_config_gen;
+}
+
+int build_lane(Lane &L) {  // one Rank per configured device: its streams and events
+  for (size_t i = 0; i < g_devices.size(); ++i) {
+    L.ranks.emplace_back(new Rank());
+    Rank &r  = *L.ranks.back();
+    r.device = g_devices[i];
+    HIPTRY(m4ri_amd_init(r.device));  // binds the device + creates its engine
+    HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+    HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
+    HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
+    // M4RI_AMD_LINK_STREAMS=n caps the link streams per direction (peer k uses stream k % n; default: one per peer): a knob for
+    // boxes whose runtime maps many streams onto few hardware queues
+    static const int link_cap = getenv("M4RI_AMD_LINK_STREAMS") ? atoi(getenv("M4RI_AMD_LINK_STREAMS")) : 0;
+    for (size_t k = 0; k < g_devices.size(); ++k) {
+      hipStream_t a = nullptr, b = nullptr;
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (link_cap > 0 && k >= (size_t)link_cap) {  // share the stream (and its event) of peer k % n
+        r.lin.push_back(r.lin[k % (size_t)link_cap]);
+        r.lout.push_back(r.lout[k % (size_t)link_cap]);
+        r.ev_lin.push_back(r.ev_lin[k % (size_t)link_cap]);
+        r.ev_lout.push_back(r.ev_lout[k % (size_t)link_cap]);
+        continue;
+      }
+      HIPTRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+      r.lin.push_back(a);
+      HIPTRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+      r.lout.push_back(b);
+      HIPTRY(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+      r.ev_lin.push_back(ea);
+      HIPTRY(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+      r.ev_lout.push_back(eb);
+    }
+    r.lin_used.assign(g_devices.size(), 0);
+    r.lout_used.assign(g_devices.size(), 0);
+    r.bounce.assign(2 * g_devices.size() + 1, nullptr);
+    for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done[0], &r.ev_done[1], &r.ev_tl0, &r.ev_tl1}) HIPTRY(hipEventCreate(e));
+  }
+  return 0;
+}
+
+// Which ordered pairs of ranks copy through the host: pure arithmetic (m4ri_amd_multi_pair_table exports it for the CPU tests).
+// can[d * ndev + e] != 0: device d may map device e's memory (hipDeviceCanAccessPeer).  `spec` is the test hook M4RI_AMD_NO_PEER:
+// "all", or a list "i-j,k-l" of RANK pairs (both directions).  Ranks on one device always copy directly.
+void pair_table(int W, const int *dev, int ndev, const int *can, const char *spec, char *staged) {
+  for (int i = 0; i < W; ++i)
+    for (int j = 0; j < W; ++j) {
+      const int di = dev[i], dj = dev[j];
+      staged[i * W + j] = (di != dj && di >= 0 && dj >= 0 && di < ndev && dj < ndev && !can[di * ndev + dj]) ? 1 : 0;
+    }
+  if (!spec || !*spec) return;
+  if (!strcmp(spec, "all")) {
+    for (int i = 0; i < W; ++i)
+      for (int j = 0; j < W; ++j) staged[i * W + j] = i != j;
+    return;
+  }
+  for (const char *q = spec; *q;) {
+    char *end = nullptr;
+    const long a = strtol(q, &end, 10);
+    if (end == q || *end != '-') break;
+    q = end + 1;
+    const long b = strtol(q, &end, 10);
+    if (end == q) break;
+    if (a >= 0 && a < W && b >= 0 && b < W && a != b) staged[a * W + b] = staged[b * W + a] = 1;
+    q = (*end == ',') ? end + 1 : end;
+  }
+}
+
+int copy_words(Rank &R, int me, int slot, word *dst, const word *src, int src_rank, int src_dev, int64_t words, hipStream_t s);
+
+// First contact with a set of DIFFERENT devices: peer access, then one small copy and one cross-device event wait per ordered pair
+// -- the two things ranks sharing one GPU never exercise -- so that a node whose links or runtime refuse them fails HERE, with the
+// pair and the HIP error named, before any product is scheduled.  (M4RI_AMD_SELFTEST_PAIRS=1 runs it between ranks of one device too.)
+int setup_pairs() {
+  const int W = (int)g_ranks.size();
+  int ndev = 0;
+  HIPTRY(hipGetDeviceCount(&ndev));
+  std::vector<int> can((size_t)ndev * (size_t)ndev, 1), dev((size_t)W);
+  for (int i = 0; i < W; ++i) dev[(size_t)i] = g_ranks[(size_t)i]->device;
+  for (int d = 0; d < ndev; ++d)
+    for (int e = 0; e < ndev; ++e) {
+      int c = 1;
+      if (d != e && hipDeviceCanAccessPeer(&c, d, e) != hipSuccess) c = 0;
+      can[(size_t)d * ndev + e] = c;
+    }
+  g_staged.assign((size_t)W * (size_t)W, 0);
+  pair_table(W, dev.data(), ndev, can.data(), getenv("M4RI_AMD_NO_PEER"), g_staged.data());
+  g_pairs_staged = 0;
+  for (char c : g_staged) g_pairs_staged += c ? 1 : 0;
+  bool distinct = false;
+  for (int i = 0; i < W; ++i) {
+    Rank &r = *g_ranks[(size_t)i];
+    HIPTRY(hipSetDevice(r.device));
+    for (int k = 0; k < W; ++k) {  // direct xGMI copies between every pair that allows them
+      const int other = g_ranks[(size_t)k]->device;
+      if (other == r.device) continue;
+      distinct = true;
+      if (!can[(size_t)r.device * ndev + other]) continue;
+      const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+        fprintf(stderr, "m4ri_amd: hipDeviceEnablePeerAccess(device %d -> device %d) failed: %s\n", r.device, other, hipGetErrorString(e));
+        return (int)e;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  const bool forced = getenv("M4RI_AMD_SELFTEST_PAIRS") && atoi(getenv("M4RI_AMD_SELFTEST_PAIRS")) != 0;
+  if (!distinct && !forced) return 0;
+  constexpr int64_t WORDS = 1 << 17;  // 1 MiB
+  std::vector<word *> srcb((size_t)W, nullptr), dstb((size_t)W, nullptr);
+  std::vector<word> host((size_t)WORDS);
+  int rc = 0, bad_i = -1, bad_j = -1;
+  const char *what = "";
+  auto fail = [&](int i, int j, const char *w, hipError_t e) { rc = e == hipSuccess ? (int)hipErrorUnknown : (int)e; bad_i = i; bad_j = j; what = w; };
+  for (int i = 0; i < W && !rc; ++i) {
+    Rank &r = *g_ranks[(size_t)i];
+    hipError_t e = hipSetDevice(r.device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&srcb[(size_t)i]), WORDS * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dstb[(size_t)i]), WORDS * 8);
+    if (e != hipSuccess) fail(i, i, "hipMalloc", e);
+  }
+  for (int i = 0; i < W && !rc; ++i)
+    for (int j = 0; j < W && !rc; ++j) {
+      Rank &D = *g_ranks[(size_t)i], &S = *g_ranks[(size_t)j];
+      if (i == j || (D.device == S.device && !forced)) continue;
+      const int pattern = 0x11 * ((i * W + j) % 13 + 1);
+      hipError_t e = hipSetDevice(S.device);
+      if (e == hipSuccess) e = hipMemsetAsync(srcb[(size_t)j], pattern, WORDS * 8, S.st);
+      if (e == hipSuccess) e = hipEventRecord(S.ev_start, S.st);
+      if (e != hipSuccess) { fail(i, j, "fill on the source device", e); break; }
+      e = hipSetDevice(D.device);
+      if (e == hipSuccess) e = hipStreamWaitEvent(D.st, S.ev_start, 0);  // the cross-device wait every schedule relies on
+      if (e != hipSuccess) { fail(i, j, "hipStreamWaitEvent on another device's event", e); break; }
+      if (int c = copy_words(D, i, 2 * W, dstb[(size_t)i], srcb[(size_t)j], j, S.device, WORDS, D.st)) { fail(i, j, g_staged[(size_t)i * W + j] ? "host-staged copy" : "hipMemcpyPeerAsync", (hipError_t)c); break; }
+      e = hipMemcpyAsync(host.data(), dstb[(size_t)i], WORDS * 8, hipMemcpyDeviceToHost, D.st);
+      if (e == hipSuccess) e = hipStreamSynchronize(D.st);
+      if (e != hipSuccess) { fail(i, j, "copy / synchronise", e); break; }
+      word want = 0;
+      memset(&want, pattern, 8);
+      for (int64_t k = 0; k < WORDS; k += 4097)
+        if (host[(size_t)k] != want) { fail(i, j, "the copied data is wrong", hipErrorUnknown); break; }
+    }
+  for (int i = 0; i < W; ++i) {
+    (void)hipSetDevice(g_ranks[(size_t)i]->device);
+    if (srcb[(size_t)i]) (void)hipFree(srcb[(size_t)i]);
+    if (dstb[(size_t)i]) (void)hipFree(dstb[(size_t)i]);
+  }
+  if (rc)
+    fprintf(stderr, "m4ri_amd: multi-device self-test FAILED for rank %d (device %d) <- rank %d (device %d): %s: %s (hipError %d); no product was scheduled\n",
+            bad_i, bad_i >= 0 ? g_ranks[(size_t)bad_i]->device : -1, bad_j, bad_j >= 0 ? g_ranks[(size_t)bad_j]->device : -1, what,
+            hipGetErrorString((hipError_t)rc), rc);
+  return rc;
 }
 
 int ensure_ranks() {
@@ -398,54 +584,21 @@ int ensure_ranks() {
   drop_ranks();
   // a failure half way must not leave ranks that LOOK configured nor another current device behind: on any error
   // everything made so far is dropped and the caller's device restored
-  auto build = [&]() -> int {
-    for (size_t i = 0; i < g_devices.size(); ++i) {
-      g_ranks.emplace_back(new Rank());
-      Rank &r  = *g_ranks.back();
-      r.device = g_devices[i];
-      HIPTRY(m4ri_amd_init(r.device));  // binds the device + creates its engine
-      HIPTRY(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
-      HIPTRY(hipStreamCreateWithFlags(&r.ci, hipStreamNonBlocking));
-      HIPTRY(hipStreamCreateWithFlags(&r.co, hipStreamNonBlocking));
-      // M4RI_AMD_LINK_STREAMS=n caps the link streams per direction (peer k uses stream k % n; default: one per peer): a knob for
-      // boxes whose runtime maps many streams onto few hardware queues
-      static const int link_cap = getenv("M4RI_AMD_LINK_STREAMS") ? atoi(getenv("M4RI_AMD_LINK_STREAMS")) : 0;
-      for (size_t k = 0; k < g_devices.size(); ++k) {
-        hipStream_t a = nullptr, b = nullptr;
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (link_cap > 0 && k >= (size_t)link_cap) {  // share the stream (and its event) of peer k % n
-          r.lin.push_back(r.lin[k % (size_t)link_cap]);
-          r.lout.push_back(r.lout[k % (size_t)link_cap]);
-          r.ev_lin.push_back(r.ev_lin[k % (size_t)link_cap]);
-          r.ev_lout.push_back(r.ev_lout[k % (size_t)link_cap]);
-          continue;
-        }
-        HIPTRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-        r.lin.push_back(a);
-        HIPTRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
-        r.lout.push_back(b);
-        HIPTRY(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-        r.ev_lin.push_back(ea);
-        HIPTRY(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
-        r.ev_lout.push_back(eb);
-      }
-      r.lin_used.assign(g_devices.size(), 0);
-      r.lout_used.assign(g_devices.size(), 0);
-      for (hipEvent_t *e : {&r.ev_start, &r.ev_down, &r.ev_gather, &r.ev_first, &r.ev_back, &r.ev_done, &r.ev_tl0, &r.ev_tl1}) HIPTRY(hipEventCreate(e));
-      for (size_t k = 0; k < g_devices.size(); ++k) {  // direct xGMI copies between every pair
-        const int other = g_devices[k];
-        int can         = 0;
-        if (other != r.device && hipDeviceCanAccessPeer(&can, r.device, other) == hipSuccess && can) {
-          const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
-          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return (int)e;
-          (void)hipGetLastError();
-        }
-      }
-    }
-    return g_pool.start((int)g_ranks.size());
-  };
-  const int rc = build();
+  int rc = build_lane(g_lane[0]);
+  if (!rc) rc = setup_pairs();
+  if (!rc) rc = g_pool.start((int)g_ranks.size());
   if (rc) drop_ranks();
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
+int ensure_lane(int lane) {  // lane 1 is made on first use
+  if (lane == 0 || g_lane[lane].ranks.size() == g_ranks.size()) return 0;
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  drop_lane(g_lane[lane]);
+  const int rc = build_lane(g_lane[lane]);
+  if (rc) drop_lane(g_lane[lane]);
   (void)hipSetDevice(cur);
   return rc;
 }
@@ -456,11 +609,24 @@ int unit_events(Rank &r, size_t n) {
   return 0;
 }
 
-// device-to-device copy of `words` words, between ranks (peer copy over the link of the pair) or inside a device
-int copy_words(word *dst, int dst_dev, const word *src, int src_dev, int64_t words, hipStream_t s) {
+// device-to-device copy of `words` words into rank `me` (which owns stream `s`; `slot` names that stream: 0..W-1 its inbound link
+// streams, W..2W-1 the outbound ones, 2W the compute stream) from rank `src_rank`: inside a device, over the link of the pair, or --
+// pairs without peer access -- through the slot's pinned bounce buffer, D2H then H2D in order on the stream
+constexpr int64_t BOUNCE_WORDS = 1 << 21;  // 16 MiB
+int copy_words(Rank &R, int me, int slot, word *dst, const word *src, int src_rank, int src_dev, int64_t words, hipStream_t s) {
   if (words <= 0) return 0;
-  if (dst_dev == src_dev) return (int)hipMemcpyAsync(dst, src, (size_t)words * 8, hipMemcpyDeviceToDevice, s);
-  return (int)hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, (size_t)words * 8, s);
+  if (R.device == src_dev && !(me != src_rank && !g_staged.empty() && g_staged[(size_t)me * g_ranks.size() + (size_t)src_rank]))
+    return (int)hipMemcpyAsync(dst, src, (size_t)words * 8, hipMemcpyDeviceToDevice, s);
+  if (g_staged.empty() || !g_staged[(size_t)me * g_ranks.size() + (size_t)src_rank]) return (int)hipMemcpyPeerAsync(dst, R.device, src, src_dev, (size_t)words * 8, s);
+  if ((size_t)slot >= R.bounce.size()) return (int)hipErrorInvalidValue;
+  if (!R.bounce[(size_t)slot]) HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&R.bounce[(size_t)slot]), (size_t)BOUNCE_WORDS * 8, hipHostMallocDefault));
+  word *b = R.bounce[(size_t)slot];
+  for (int64_t o = 0; o < words; o += BOUNCE_WORDS) {
+    const int64_t k = (words - o) < BOUNCE_WORDS ? (words - o) : BOUNCE_WORDS;
+    HIPTRY(hipMemcpyAsync(b, src + o, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+    HIPTRY(hipMemcpyAsync(dst + o, b, (size_t)k * 8, hipMemcpyHostToDevice, s));
+  }
+  return 0;
 }
 
 // ---- layouts ---------------------------------------------------------------------------------------
@@ -561,11 +727,28 @@ void dmat_delete(m4ri_amd_dmat *d) {
   delete d;
 }
 
-// every operation starts behind the previous operation of EVERY rank (their reads of what it will overwrite, their writes of
-// what it will read) and ends with ev_done on the compute stream; the copy streams start behind ev_start
-int op_begin(Rank &R) {
-  for (auto &other : g_ranks)
-    if (other->done_recorded) HIPTRY(hipStreamWaitEvent(R.st, other->ev_done, 0));
+// Every operation of a lane starts behind the lane's previous operation on EVERY rank (their reads of what it will overwrite, their
+// writes of what it will read) and ends with ev_done on the compute stream; the copy streams start behind ev_start.  Across lanes:
+// products do not wait for each other (the caller of m4ri_amd_dmat_mul_lane promises independent results); everything else
+// ("exclusive": uploads, fills, conversions, downloads) waits for the last operation of every lane, and the first operation of a lane
+// after an exclusive one elsewhere waits for that lane.  begin_op / end_op run on the issuing thread (g_multi_mu held) around
+// Pool::run; op_begin / op_end on the ranks' threads in between.
+struct OpCtx { int lane; bool cross; };
+
+OpCtx begin_op(int lane, bool exclusive) {
+  Lane &L = g_lane[lane];
+  OpCtx c{lane, exclusive || (g_excl_id > L.seen_excl && g_excl_lane != lane)};
+  if (exclusive) { ++g_excl_id; g_excl_lane = lane; }
+  L.seen_excl = g_excl_id;
+  return c;
+}
+int op_begin(Rank &R, const OpCtx &c) {
+  for (int x = 0; x < NUM_LANES; ++x) {
+    if (x != c.lane && !c.cross) continue;
+    const int prev = g_lane[x].parity ^ 1;  // what the lane's latest operation recorded (its threads have all returned)
+    for (auto &other : g_lane[x].ranks)
+      if (other->done_recorded[prev]) HIPTRY(hipStreamWaitEvent(R.st, other->ev_done[prev], 0));
+  }
   HIPTRY(hipEventRecord(R.ev_start, R.st));
   HIPTRY(hipStreamWaitEvent(R.ci, R.ev_start, 0));
   HIPTRY(hipStreamWaitEvent(R.co, R.ev_start, 0));
@@ -587,13 +770,22 @@ int join_links(Rank &R, bool inbound) {
     }
   return 0;
 }
-int op_end(Rank &R) {
-  HIPTRY(hipEventRecord(R.ev_done, R.st));
+int op_end(Rank &R, const OpCtx &c) {
+  HIPTRY(hipEventRecord(R.ev_done[g_lane[c.lane].parity], R.st));
   return 0;
 }
-// after the pool has joined: from now on ev_done of every rank is a recorded event
-void ops_joined() {
-  for (auto &r : g_ranks) r->done_recorded = true;
+// after the pool has joined: the slot the operation recorded is now every rank's "previous operation"
+void end_op(const OpCtx &c) {
+  Lane &L = g_lane[c.lane];
+  for (auto &r : L.ranks) r->done_recorded[L.parity] = true;
+  L.parity ^= 1;
+}
+// one operation: every rank's thread runs f(rank)
+int run_op(int lane, bool exclusive, const std::function<int(int, const OpCtx &)> &f) {
+  const OpCtx c = begin_op(lane, exclusive);
+  const int rc  = g_pool.run([&](int me) { return f(me, c); });
+  end_op(c);
+  return rc;
 }
 
 int carve(Rank &r, const int64_t *words) {
@@ -602,8 +794,10 @@ int carve(Rank &r, const int64_t *words) {
   if (need > r.cap) {
     // the old arena goes away: OTHER ranks may still be pulling slabs out of it (their part of the previous operation, on their
     // devices), so everybody's previous operation has to be over, not just this device's
-    for (auto &other : g_ranks)
-      if (other->done_recorded) HIPTRY(hipEventSynchronize(other->ev_done));
+    for (Lane &L : g_lane)
+      for (auto &other : L.ranks)
+        for (int k = 0; k < 2; ++k)
+          if (other->done_recorded[k]) HIPTRY(hipEventSynchronize(other->ev_done[k]));
     HIPTRY(hipDeviceSynchronize());
     if (r.arena) HIPTRY(hipFree(r.arena));
     r.arena = nullptr; r.cap = 0;
@@ -616,10 +810,10 @@ int carve(Rank &r, const int64_t *words) {
 }
 
 // ---- redistribution: dst <- src, any two layouts of one shape (also the all-gather: ROWS -> REPLICATED) --------------
-int redistribute_rank(const m4ri_amd_dmat *dst, const m4ri_amd_dmat *src, int me) {
-  Rank &R = *g_ranks[(size_t)me];
+int redistribute_rank(const m4ri_amd_dmat *dst, const m4ri_amd_dmat *src, int me, const OpCtx &ctx) {
+  Rank &R = *g_lane[ctx.lane].ranks[(size_t)me];
   RTRY(hipSetDevice(R.device));
-  RTRY(op_begin(R));
+  RTRY(op_begin(R, ctx));
   const int W = dst->world;
   Run dr[4], sr[4];
   const int nd = runs_of(dst->layout, W, me, dst->rows, dr);
@@ -632,21 +826,19 @@ int redistribute_rank(const m4ri_amd_dmat *dst, const m4ri_amd_dmat *src, int me
         const int64_t lo = dr[i].g0 > sr[j].g0 ? dr[i].g0 : sr[j].g0;
         const int64_t hi = (dr[i].g0 + dr[i].rows) < (sr[j].g0 + sr[j].rows) ? (dr[i].g0 + dr[i].rows) : (sr[j].g0 + sr[j].rows);
         if (hi <= lo) continue;
-        RTRY(copy_words(dst->local[(size_t)me] + (dr[i].l0 + lo - dr[i].g0) * dst->stride, R.device,
-                        src->local[(size_t)s] + (sr[j].l0 + lo - sr[j].g0) * src->stride, src->device[(size_t)s], (hi - lo) * dst->stride, R.st));
+        RTRY(copy_words(R, me, 2 * W, dst->local[(size_t)me] + (dr[i].l0 + lo - dr[i].g0) * dst->stride,
+                        src->local[(size_t)s] + (sr[j].l0 + lo - sr[j].g0) * src->stride, s, src->device[(size_t)s], (hi - lo) * dst->stride, R.st));
       }
       if (src->layout == M4RI_AMD_LAYOUT_REPLICATED) break;  // the first holder had everything
     }
   }
-  return op_end(R);
+  return op_end(R, ctx);
 }
 
 int redistribute(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src) {
   if (!alive(dst) || !alive(src) || dst->rows != src->rows || dst->ncols != src->ncols) return (int)hipErrorInvalidValue;
   if (dst == src) return 0;
-  const int rc = g_pool.run([&](int me) { return redistribute_rank(dst, src, me); });
-  ops_joined();
-  return rc;
+  return run_op(0, true, [&](int me, const OpCtx &ctx) { return redistribute_rank(dst, src, me, ctx); });
 }
 
 // ---- schedule 1: row slabs -----------------------------------------------------------------------------
@@ -658,8 +850,8 @@ struct SlabOp {
   bool overlap;
 };
 
-int slabs_rank(const SlabOp &op, int me) {
-  Rank &R = *g_ranks[(size_t)me];
+int slabs_rank(const SlabOp &op, int me, const OpCtx &ctx) {
+  Rank &R = *g_lane[ctx.lane].ranks[(size_t)me];
   RTRY(hipSetDevice(R.device));
   const int W      = op.A->world;
   const int64_t l  = op.A->ncols, n = op.B->ncols, m = op.A->rows;
@@ -670,7 +862,7 @@ int slabs_rank(const SlabOp &op, int me) {
   const bool gathered = op.B->layout == M4RI_AMD_LAYOUT_ROWS;
   if (gathered) words[B_GATHER] = (int64_t)W * kb * sbw;
   RTRY(carve(R, words));
-  RTRY(op_begin(R));
+  RTRY(op_begin(R, ctx));
   RTRY(hipEventRecord(R.ev_tl0, R.st));
   R.tl_valid = false;
   word *Cme = op.C->local[(size_t)me];
@@ -682,7 +874,7 @@ int slabs_rank(const SlabOp &op, int me) {
     RTRY(hipEventRecord(R.ev_gather, R.ci));
     RTRY(hipEventRecord(R.ev_tl1, R.st));
     R.tl_valid = true;
-    return op_end(R);
+    return op_end(R, ctx);
   }
   word *Bfull      = R.buf[B_GATHER];
   const int64_t k0 = kb * me < l ? kb * me : l, k1 = (k0 + kb) < l ? (k0 + kb) : l;  // my rows of B
@@ -692,7 +884,7 @@ int slabs_rank(const SlabOp &op, int me) {
     const int s      = (me + k) % W;
     const int64_t g0 = kb * s < l ? kb * s : l, g1 = (g0 + kb) < l ? (g0 + kb) : l;
     if (g1 > g0) {
-      RTRY(copy_words(Bfull + g0 * sbw, R.device, op.B->local[(size_t)s], op.B->device[(size_t)s], (g1 - g0) * sbw, R.lin[(size_t)s]));
+      RTRY(copy_words(R, me, s, Bfull + g0 * sbw, op.B->local[(size_t)s], s, op.B->device[(size_t)s], (g1 - g0) * sbw, R.lin[(size_t)s]));
       R.lin_used[(size_t)s] = 1;
     }
   }
@@ -723,7 +915,7 @@ int slabs_rank(const SlabOp &op, int me) {
   }
   RTRY(hipEventRecord(R.ev_tl1, R.st));
   R.tl_valid = true;
-  return op_end(R);
+  return op_end(R, ctx);
 }
 
 // ---- schedule 2: the sub-products of the top Strassen-Winograd level(s) ------------------------------------------
@@ -740,8 +932,9 @@ void chunk_of(const StrassenOp &op, int c, int *lo, int *hi) {
   *hi = op.p.world * (c + 1) / op.chunks;
 }
 
-int strassen_rank(const StrassenOp &op, int me) {
-  Rank &R = *g_ranks[(size_t)me];
+int strassen_rank(const StrassenOp &op, int me, const OpCtx &ctx) {
+  std::vector<std::unique_ptr<Rank>> &ranks = g_lane[ctx.lane].ranks;
+  Rank &R = *ranks[(size_t)me];
   RTRY(hipSetDevice(R.device));
   const m4ri_amd_shard_plan &p = op.p;
   const int W = p.world, nch = op.chunks, rounds = (p.nprod + W - 1) / W;
@@ -754,7 +947,7 @@ int strassen_rank(const StrassenOp &op, int me) {
   words[B_PROD]    = m4ri_amd_shard_buffer_words(&p, me, M4RI_AMD_SHARD_BUF_PROD);
   RTRY(carve(R, words));
   RTRY(unit_events(R, (size_t)rounds * (size_t)nch));
-  RTRY(op_begin(R));
+  RTRY(op_begin(R, ctx));
   RTRY(hipEventRecord(R.ev_tl0, R.st));
   R.tl_valid = false;
   R.tl_strassen = true; R.tl_gathered = false; R.tl_units = 0;
@@ -770,14 +963,14 @@ int strassen_rank(const StrassenOp &op, int me) {
     m4ri_amd_shard_piece pc;
     m4ri_amd_shard_piece_of(&p, side, j, r, &pc);
     if (pc.words == 0) return 0;
-    Rank &H = *g_ranks[(size_t)r];
+    Rank &H = *ranks[(size_t)r];
     if (!waited[r]) {
       if (int e = wait_flag(H.flag_down, op.seq)) return e;
       HIPTRY(hipStreamWaitEvent(R.lin[(size_t)r], H.ev_down, 0));
       waited[r] = true;
     }
     R.lin_used[(size_t)r] = 1;
-    return copy_words(R.buf[side ? B_OPER_B : B_OPER_A] + pc.owner_off, R.device, H.buf[side ? B_CHILD_B : B_CHILD_A] + pc.holder_off, H.device, pc.words,
+    return copy_words(R, me, r, R.buf[side ? B_OPER_B : B_OPER_A] + pc.owner_off, H.buf[side ? B_CHILD_B : B_CHILD_A] + pc.holder_off, r, H.device, pc.words,
                       R.lin[(size_t)r]);
   };
   int units = 0;
@@ -814,11 +1007,11 @@ int strassen_rank(const StrassenOp &op, int me) {
     m4ri_amd_shard_piece pc;
     m4ri_amd_shard_piece_of(&p, 2, j, me, &pc);
     if (pc.words == 0) continue;
-    Rank &O     = *g_ranks[(size_t)pc.owner];
+    Rank &O     = *ranks[(size_t)pc.owner];
     const int u = (j / W) * nch + myc;
     RTRY(wait_flag(O.flag_prod, op.seq * 4096 + u + 1));
     RTRY(hipStreamWaitEvent(R.lout[(size_t)pc.owner], O.ev_prod[(size_t)u], 0));
-    RTRY(copy_words(R.buf[B_SLABS_P] + pc.holder_off, R.device, O.buf[B_PROD] + pc.owner_off, O.device, pc.words, R.lout[(size_t)pc.owner]));
+    RTRY(copy_words(R, me, W + pc.owner, R.buf[B_SLABS_P] + pc.holder_off, O.buf[B_PROD] + pc.owner_off, pc.owner, O.device, pc.words, R.lout[(size_t)pc.owner]));
     R.lout_used[(size_t)pc.owner] = 1;
   }
   RTRY(join_links(R, false));
@@ -827,7 +1020,7 @@ int strassen_rank(const StrassenOp &op, int me) {
   RTRY(m4ri_amd_shard_up_dev(&p, me, R.buf[B_SLABS_P], op.C->local[(size_t)me], op.C->stride, op.add, R.st));
   RTRY(hipEventRecord(R.ev_tl1, R.st));
   R.tl_valid = true;
-  return op_end(R);
+  return op_end(R, ctx);
 }
 
 // the plan of a product on CYCLIC-v operands: every dimension padded to 256 bits (the layouts' own padding)
@@ -857,7 +1050,7 @@ int auto_levels(int world, int64_t m, int64_t l, int64_t n) {
 
 // C (+)= A*B on distributed operands (g_multi_mu held).  Operands in another layout than the schedule's are converted
 // through temporaries (correct, not fast: keep matrices in the layout m4ri_amd_multi_layout_for names).
-int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant) {
+int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant, int lane = 0) {
   if (!alive(C) || !alive(A) || !alive(B) || A->ncols != B->rows || C->rows != A->rows || C->ncols != B->ncols || cutoff < 0 || C == A || C == B)
     return (int)hipErrorInvalidValue;
   const int W = (int)g_ranks.size();
@@ -901,6 +1094,7 @@ int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, i
   g_mstats = m4ri_amd_multi_stats{};
   g_mstats.world = W; g_mstats.variant = variant; g_mstats.m = m; g_mstats.l = l; g_mstats.n = n;
   g_mstats.converted = (tA ? 1 : 0) + (tB ? 1 : 0) + (tC ? 1 : 0);
+  g_mstats.pairs_staged = g_pairs_staged;
   int rc = 0;
   ++g_seq;
   if (m == 0 || n == 0) {
@@ -913,8 +1107,7 @@ int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, i
     op.overlap = b->layout == M4RI_AMD_LAYOUT_ROWS && kb % 64 == 0 && W <= 4 && W > 1 && l > 0;
     g_mstats.overlap    = op.overlap ? 1 : 0;
     g_mstats.link_bytes = b->layout == M4RI_AMD_LAYOUT_ROWS ? 8.0 * (double)b->stride * (double)l * (double)(W - 1) : 0.0;
-    rc = g_pool.run([&](int me) { return slabs_rank(op, me); });
-    ops_joined();
+    rc = run_op(lane, false, [&](int me, const OpCtx &ctx) { return slabs_rank(op, me, ctx); });
   } else {
     StrassenOp op{c, a, b, {}, add, cutoff, 1, g_seq};
     plan_for(&op.p, W, m, l, n, layout_levels(want));
@@ -932,8 +1125,7 @@ int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, i
           if (pc.holder != pc.owner) moved += 8.0 * (double)pc.words;
         }
     g_mstats.link_bytes = moved;
-    rc = g_pool.run([&](int me) { return strassen_rank(op, me); });
-    ops_joined();
+    rc = run_op(lane, false, [&](int me, const OpCtx &ctx) { return strassen_rank(op, me, ctx); });
   }
   if (rc) return rc;
   if (tC) return redistribute(C, tC.get());  // (the temporaries are freed after a device synchronisation: dmat_delete)
@@ -944,7 +1136,8 @@ int sync_all() {
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
   int rc = 0;
-  for (auto &r : g_ranks) {
+  for (Lane &L : g_lane)
+  for (auto &r : L.ranks) {
     if (hipSetDevice(r->device) != hipSuccess) { rc = (int)hipErrorInvalidDevice; continue; }
     std::vector<hipStream_t> all = r->lin;
     all.insert(all.end(), r->lout.begin(), r->lout.end());
@@ -960,10 +1153,10 @@ int sync_all() {
 
 // ---- host matrices in and out ----------------------------------------------------------------------------
 // host rows of M -> the zero-padded local buffers: every device its own rows over its own PCIe link
-int upload_rank(m4ri_amd_dmat *d, const mzd_t *M, int me) {
-  Rank &R = *g_ranks[(size_t)me];
+int upload_rank(m4ri_amd_dmat *d, const mzd_t *M, int me, const OpCtx &ctx) {
+  Rank &R = *g_lane[ctx.lane].ranks[(size_t)me];
   RTRY(hipSetDevice(R.device));
-  RTRY(op_begin(R));
+  RTRY(op_begin(R, ctx));
   word *local = d->local[(size_t)me];
   if (d->lrows[(size_t)me] > 0) RTRY(hipMemsetAsync(local, 0, (size_t)d->lrows[(size_t)me] * (size_t)d->stride * 8, R.st));
   Run runs[4];
@@ -974,17 +1167,17 @@ int upload_rank(m4ri_amd_dmat *d, const mzd_t *M, int me) {
     // a window's last word carries its parent's neighbouring columns (mzd.h:117-123): zero them
     if (M->ncols % 64) RTRY(gf2_launch_mask_tail(R.st, local + runs[i].l0 * d->stride, d->stride, runs[i].rows, M->ncols));
   }
-  RTRY(op_end(R));
+  RTRY(op_end(R, ctx));
   RTRY(hipStreamSynchronize(R.st));  // the caller may free or change M as soon as this returns
   return 0;
 }
 
 // the local buffers -> host C, touching only the words and bits the reference would (mzd.h:117-123)
-int download_rank(const m4ri_amd_dmat *d, mzd_t *C, int me, bool all_ranks) {
-  Rank &R = *g_ranks[(size_t)me];
+int download_rank(const m4ri_amd_dmat *d, mzd_t *C, int me, bool all_ranks, const OpCtx &ctx) {
+  Rank &R = *g_lane[ctx.lane].ranks[(size_t)me];
   RTRY(hipSetDevice(R.device));
-  RTRY(op_begin(R));
-  RTRY(op_end(R));
+  RTRY(op_begin(R, ctx));
+  RTRY(op_end(R, ctx));
   if (C->width == 0) return 0;
   if (d->layout == M4RI_AMD_LAYOUT_REPLICATED && !all_ranks && me != 0) return 0;
   const bool dangerous = (C->flags & FLAG_WINDOW) && (C->ncols % 64 != 0);
@@ -1047,17 +1240,12 @@ int mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int add, int cutoff, int
   if (!dA || !dB || !dC) return (int)hipErrorOutOfMemory;
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
-  int rc = g_pool.run([&](int me) -> int {
-    if (int e = upload_rank(dA, A, me)) return e;
-    if (int e = upload_rank(dB, B, me)) return e;
-    return add ? upload_rank(dC, C, me) : 0;
-  });
-  ops_joined();
+  // (three operations, not one with three parts: an operation records ev_done once, and the next part's op_begin has to see it)
+  int rc = run_op(0, true, [&](int me, const OpCtx &ctx) { return upload_rank(dA, A, me, ctx); });
+  if (!rc) rc = run_op(0, true, [&](int me, const OpCtx &ctx) { return upload_rank(dB, B, me, ctx); });
+  if (!rc && add) rc = run_op(0, true, [&](int me, const OpCtx &ctx) { return upload_rank(dC, C, me, ctx); });
   if (!rc) rc = dmat_mul(dC, dA, dB, add, cutoff, variant);
-  if (!rc) {
-    rc = g_pool.run([&](int me) { return download_rank(dC, C, me, true); });
-    ops_joined();
-  }
+  if (!rc) rc = run_op(0, true, [&](int me, const OpCtx &ctx) { return download_rank(dC, C, me, true, ctx); });
   (void)hipSetDevice(cur);
   return rc;
 }
@@ -1159,18 +1347,16 @@ int m4ri_amd_dmat_local(const m4ri_amd_dmat *d, int rank, word **data, int64_t *
 int m4ri_amd_dmat_fill(m4ri_amd_dmat *d, uint64_t seed) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
   if (!alive(d)) return (int)hipErrorInvalidValue;
-  const int rc = g_pool.run([&](int me) -> int {
+  return run_op(0, true, [&](int me, const OpCtx &ctx) -> int {
     Rank &R = *g_ranks[(size_t)me];
     RTRY(hipSetDevice(R.device));
-    RTRY(op_begin(R));
+    RTRY(op_begin(R, ctx));
     Run runs[4];
     const int nr = runs_of(d->layout, d->world, me, d->rows, runs);
     for (int i = 0; i < nr; ++i)
       RTRY(m4ri_amd_fill_rows_dev(d->local[(size_t)me] + runs[i].l0 * d->stride, d->stride, runs[i].g0, runs[i].rows, d->ncols, seed, R.st));
-    return op_end(R);
+    return op_end(R, ctx);
   });
-  ops_joined();
-  return rc;
 }
 
 int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M) {
@@ -1178,8 +1364,7 @@ int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M) {
   if (!alive(d) || !M || M->nrows != d->rows || M->ncols != d->ncols) return (int)hipErrorInvalidValue;
   int cur = 0;
   HIPTRY(hipGetDevice(&cur));
-  const int rc = g_pool.run([&](int me) { return upload_rank(d, M, me); });
-  ops_joined();
+  const int rc = run_op(0, true, [&](int me, const OpCtx &ctx) { return upload_rank(d, M, me, ctx); });
   (void)hipSetDevice(cur);
   return rc;
 }
@@ -1187,9 +1372,7 @@ int m4ri_amd_dmat_upload(m4ri_amd_dmat *d, const mzd_t *M) {
 int m4ri_amd_dmat_download(const m4ri_amd_dmat *d, mzd_t *M) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
   if (!alive(d) || !M || M->nrows != d->rows || M->ncols != d->ncols) return (int)hipErrorInvalidValue;
-  const int rc = g_pool.run([&](int me) { return download_rank(d, M, me, true); });
-  ops_joined();
-  return rc;
+  return run_op(0, true, [&](int me, const OpCtx &ctx) { return download_rank(d, M, me, true, ctx); });
 }
 
 int m4ri_amd_dmat_convert(m4ri_amd_dmat *dst, const m4ri_amd_dmat *src) {
@@ -1207,9 +1390,102 @@ int m4ri_amd_dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_d
   return rc;
 }
 
+int m4ri_amd_dmat_mul_lane(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, int add, int cutoff, int variant, int lane) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (variant < 0 || variant > M4RI_AMD_VARIANT_STRASSEN || lane < 0 || lane >= NUM_LANES) return (int)hipErrorInvalidValue;
+  if (!alive(C)) return (int)hipErrorInvalidValue;
+  if (int rc = ensure_lane(lane)) return rc;
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  const int rc = dmat_mul(C, A, B, add, cutoff, variant, lane);
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
 int m4ri_amd_multi_sync(void) {
   std::lock_guard<std::mutex> lk(g_multi_mu);
   return sync_all();
+}
+
+void m4ri_amd_multi_pair_table(int world, const int *devices, int ndev, const int *can_access, const char *no_peer_spec, char *staged) {
+  if (world <= 0 || !devices || !staged || (ndev > 0 && !can_access)) return;
+  pair_table(world, devices, ndev, can_access, no_peer_spec, staged);
+}
+
+// What the links between the configured ranks give, measured: `bytes` copied dst <- src for every ordered pair of ranks, one pair at a
+// time (pair_gbs[dst * W + src], GB/s, 0 on the diagonal) and then all pairs at once (*all_gbs = the sum of all bytes over the wall
+// time); staged[dst * W + src] = 1 where the pair has no peer access and copies go through the host.  Ranks sharing a device report
+// the on-device copy rate (*same_device = 1 if any pair does).  Uses the ranks' own link streams: exactly the path the schedules use.
+int m4ri_amd_multi_link_probe(int64_t bytes, double *pair_gbs, double *all_gbs, char *staged, int *same_device) {
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  if (bytes < 8 || !pair_gbs) return (int)hipErrorInvalidValue;
+  if (int rc = ensure_ranks()) return rc;
+  if (int rc = sync_all()) return rc;
+  const int W = (int)g_ranks.size();
+  const int64_t words = bytes / 8;
+  int cur = 0;
+  HIPTRY(hipGetDevice(&cur));
+  std::vector<word *> src((size_t)W, nullptr), dst((size_t)W * (size_t)W, nullptr);
+  int rc = 0;
+  auto cleanup = [&]() {
+    for (int i = 0; i < W; ++i) {
+      (void)hipSetDevice(g_ranks[(size_t)i]->device);
+      if (src[(size_t)i]) (void)hipFree(src[(size_t)i]);
+      for (int j = 0; j < W; ++j)
+        if (dst[(size_t)i * W + j]) (void)hipFree(dst[(size_t)i * W + j]);
+    }
+    (void)hipSetDevice(cur);
+  };
+  bool shared = false;
+  for (int i = 0; i < W && !rc; ++i) {
+    Rank &R = *g_ranks[(size_t)i];
+    rc = (int)hipSetDevice(R.device);
+    if (!rc) rc = (int)hipMalloc(reinterpret_cast<void **>(&src[(size_t)i]), (size_t)words * 8);
+    if (!rc) rc = (int)hipMemset(src[(size_t)i], 0x3c, (size_t)words * 8);
+    for (int j = 0; j < W && !rc; ++j) {
+      if (j == i) continue;
+      shared = shared || g_ranks[(size_t)j]->device == R.device;
+      rc = (int)hipMalloc(reinterpret_cast<void **>(&dst[(size_t)i * W + j]), (size_t)words * 8);
+    }
+    if (!rc) rc = (int)hipDeviceSynchronize();
+  }
+  if (rc) { cleanup(); return rc; }
+  for (int i = 0; i < W * W; ++i) pair_gbs[i] = 0.0;
+  for (auto &r : g_ranks) r->tl_valid = false;  // (the probe borrows the timeline's first and last mark)
+  auto one = [&](int i, int j) -> int {  // rank i pulls from rank j on its inbound link stream
+    Rank &R = *g_ranks[(size_t)i];
+    HIPTRY(hipSetDevice(R.device));
+    return copy_words(R, i, j, dst[(size_t)i * W + j], src[(size_t)j], j, g_ranks[(size_t)j]->device, words, R.lin[(size_t)j]);
+  };
+  for (int i = 0; i < W && !rc; ++i)
+    for (int j = 0; j < W && !rc; ++j) {
+      if (i == j) continue;
+      Rank &R = *g_ranks[(size_t)i];
+      rc = one(i, j);  // warm-up: first touch of the pair (mappings, the bounce buffer)
+      if (!rc) rc = (int)hipStreamSynchronize(R.lin[(size_t)j]);
+      if (!rc) rc = (int)hipEventRecord(R.ev_tl0, R.lin[(size_t)j]);
+      if (!rc) rc = one(i, j);
+      if (!rc) rc = (int)hipEventRecord(R.ev_tl1, R.lin[(size_t)j]);
+      if (!rc) rc = (int)hipEventSynchronize(R.ev_tl1);
+      float ms = 0;
+      if (!rc) rc = (int)hipEventElapsedTime(&ms, R.ev_tl0, R.ev_tl1);
+      if (!rc && ms > 0) pair_gbs[(size_t)i * W + j] = (double)bytes / ((double)ms * 1e-3) / 1e9;
+    }
+  if (!rc && all_gbs) {
+    *all_gbs = 0.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    for (int i = 0; i < W && !rc; ++i)
+      for (int k = 1; k < W && !rc; ++k) rc = one(i, (i + k) % W);
+    if (!rc) rc = sync_all();
+    const double dt = now() - t0;
+    if (!rc && dt > 0) *all_gbs = (double)bytes * (double)W * (double)(W - 1) / dt / 1e9;
+  }
+  if (staged)
+    for (int i = 0; i < W * W; ++i) staged[i] = g_staged.empty() ? 0 : g_staged[(size_t)i];
+  if (same_device) *same_device = shared ? 1 : 0;
+  cleanup();
+  return rc;
 }
 
 int m4ri_amd_multi_get_stats(m4ri_amd_multi_stats *out) {

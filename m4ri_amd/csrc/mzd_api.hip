@@ -216,7 +216,14 @@ void late_begin(LateC &lc, rci_t r, rci_t c) {
   const size_t bytes = (size_t)r * (size_t)C->rowstride * 8, len = big_len(bytes);
   if (void *p = g_big_cache.take(len)) {
     C->data = static_cast<word *>(p);
-    if (C->rowstride != C->width) zero_with_threads(static_cast<char *>(p), bytes);
+    // M4RI_AMD_POISON_RESULT=1 (tests/test_gpu_host_pipeline.py): the parked block is filled with a pattern first, so that a run path
+    // that failed to write some valid word of the result would show -- the check behind "taken as it is" 
+    static const bool poison = getenv("M4RI_AMD_POISON_RESULT") && atoi(getenv("M4RI_AMD_POISON_RESULT")) != 0;
+    if (poison) {
+      std::memset(p, 0xA5, bytes);
+      if (C->rowstride != C->width)
+        for (rci_t i = 0; i < r; ++i) C->data[(int64_t)i * C->rowstride + C->width] = 0;
+    } else if (C->rowstride != C->width) zero_with_threads(static_cast<char *>(p), bytes);
     return;
   }
   char *base = static_cast<char *>(big_map(len));
@@ -408,6 +415,11 @@ struct Pin {
 };
 std::list<Pin> g_pins;  // a list: entries stay where they are while other threads pin and unpin (g_pin_mu guards the walk and the edits)
 
+// Locking rule of the table: g_pin_mu guards the walk and the edits of the LIST; the lock of the device a pin lives on
+// (g_dev_mu[pin.device]) guards the ENTRY -- its device copy, its dev_newer flag, its removal.  A product holds that lock for its
+// whole duration (it runs on the pin's device or dies, operand()), so whoever changes or removes a pin takes the PIN'S device lock,
+// not the lock of whatever device its own thread happens to have current (PinLock).  A Pin* from find_pin is therefore valid for as
+// long as the caller holds the lock of the device the pin is on.
 Pin *find_pin(const mzd_t *M) {
   if (!M || !M->data) return nullptr;
   std::lock_guard<std::mutex> pl(g_pin_mu);
@@ -415,6 +427,39 @@ Pin *find_pin(const mzd_t *M) {
     if (M->data >= p.hbase && M->data < p.hbase + p.words && M->rowstride == p.rowstride) return &p;
   return nullptr;
 }
+
+int pin_device(const mzd_t *M) {  // the device M's pinned parent lives on, -1 when there is none (read under the list's lock)
+  if (!M || !M->data) return -1;
+  std::lock_guard<std::mutex> pl(g_pin_mu);
+  for (Pin &p : g_pins)
+    if (M->data >= p.hbase && M->data < p.hbase + p.words && M->rowstride == p.rowstride) return p.device;
+  return -1;
+}
+
+// the pin of M with the lock of ITS device held and that device current (restored on the way out); p == nullptr: not pinned
+struct PinLock {
+  std::unique_lock<std::mutex> lk;
+  Pin *p   = nullptr;
+  int prev = -1;
+  explicit PinLock(const mzd_t *M) {
+    for (int tries = 0; tries < 64; ++tries) {
+      const int d = pin_device(M);
+      if (d < 0 || d >= ARENA_DEVICES) return;
+      lk = std::unique_lock<std::mutex>(g_dev_mu[d]);
+      Pin *q = find_pin(M);
+      if (q && q->device == d) {
+        p = q;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) HIPDIE(hipSetDevice(d));
+        return;
+      }
+      lk.unlock();  // unpinned, or re-pinned elsewhere, between the look and the lock: look again
+    }
+  }
+  ~PinLock() {
+    if (p && prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+  }
+};
 
 // device view of a host operand: inside its pinned parent, or a staged upload (copy == false: space only)
 DevMat operand(const mzd_t *M, bool copy, Pin **pin_out = nullptr) {
@@ -450,6 +495,20 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 // crossover against the reference on the GPU box, profiles/r04_crossover_cpu_gpu.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
 std::atomic<int64_t> g_small_threshold{getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 26)};
 std::atomic<int64_t> g_small_count{0};  // products that took the host path
+
+// Does a product of these dimensions go to the host routine?  m * l * n at most the threshold AND the routine's own cost -- row
+// operations of W(n) words: m * l / 2 below 16 rows (one row of B per set bit), else (l / K) * (2^K + m) with its K = 4 / 8 -- at
+// most threshold / 320 word operations (2^26 / 320 = 209715, ~65 us at the 3 words/ns it runs at: the measured crossover against
+// the 30 ... 65 us a call through the GPU costs whatever its size, profiles/r04_crossover_cpu_gpu.log).  The second bound is what
+// keeps degenerate shapes -- 1 x 1 x 2^26, 2^26 x 1 x 1 -- away from a single-threaded loop.
+bool small_product_wanted(int64_t m, int64_t l, int64_t n, int64_t threshold) {
+  if (threshold <= 0 || m <= 0 || n <= 0) return false;
+  if ((double)m * (double)l * (double)n > (double)threshold) return false;
+  const double wn = (double)((n + 63) / 64);
+  const int K     = m < 224 ? 4 : 8;
+  const double ops = m < 16 ? 0.5 * (double)m * (double)l * wn : (double)((l + K - 1) / K) * (double)((1 << K) + m) * wn;
+  return ops + (double)m * wn <= (double)threshold / 320.0;
+}
 std::atomic<size_t> g_pipeline_min_bytes{(size_t)64 << 20};  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];
 
@@ -670,7 +729,8 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
   Pin *pinC = late ? nullptr : find_pin(C);
   // products the launch / PCIe floor of a call would dominate: this library's own host Four Russians (small_host.cpp), on an
   // initialised device and only for matrices that live in host memory (a pinned operand is already on the GPU)
-  if (!late && !pinC && g_small_threshold.load() > 0 && (double)cm * (double)A->ncols * (double)cn <= (double)g_small_threshold.load() && !find_pin(A) && !find_pin(B)) {
+  if (!late && !pinC && small_product_wanted(cm, A->ncols, cn, g_small_threshold.load()) && !find_pin(A) && !find_pin(B)) {
+    lk.lk.unlock();  // the routine needs no device state: small products of many threads run side by side
     if (m4ri_amd_small_mul_host(C, A, B, add ? 1 : 0)) die("m4ri_amd: small product failed (internal error)\n");
     g_small_count += 1;
     return C;
@@ -938,16 +998,14 @@ mzd_t *_mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k, int clear)
 }
 
 int64_t m4ri_amd_set_small_product_threshold(int64_t ops) {
-  ApiLock lk;
   const int64_t old = g_small_threshold;
   if (ops >= 0) g_small_threshold = ops;
   return old;
 }
 
-int64_t m4ri_amd_small_product_count(void) {
-  ApiLock lk;
-  return g_small_count;
-}
+int64_t m4ri_amd_small_product_count(void) { return g_small_count; }
+
+int m4ri_amd_small_product_wanted(int64_t m, int64_t l, int64_t n) { return small_product_wanted(m, l, n, g_small_threshold.load()) ? 1 : 0; }
 
 // A + B + C bytes from which the host entry points pipeline a product over row slabs (0: never); returns the previous value
 int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes) {
@@ -1394,17 +1452,20 @@ void m4ri_amd_result_free(mzd_t *A) {
 
 // ---- part 3: residency ----------------------------------------------------------------------------
 int m4ri_amd_pin(mzd_t *M) {
-  ApiLock lk;
   if (!M || (M->flags & FLAG_WINDOW)) return -1;  // pin the owner of the block; windows into it follow
-  if (Pin *old = find_pin(M)) {
-    if (old->owner == M && old->hbase == M->data && old->nrows == M->nrows && old->ncols == M->ncols) return 0;
-    // a matrix freed without unpin left this entry behind and the allocator reused its address: the
-    // device copy belongs to a dead matrix -- drop it (without a download) and pin M afresh
-    (void)hipFree(old->dbase);
-    std::lock_guard<std::mutex> pl(g_pin_mu);
-    for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
-      if (&*it == old) { g_pins.erase(it); break; }
+  {
+    PinLock old(M);  // (the lock of the device the OLD entry is on, which need not be this thread's)
+    if (old.p) {
+      if (old.p->owner == M && old.p->hbase == M->data && old.p->nrows == M->nrows && old.p->ncols == M->ncols) return 0;
+      // a matrix freed without unpin left this entry behind and the allocator reused its address: the
+      // device copy belongs to a dead matrix -- drop it (without a download) and pin M afresh
+      (void)hipFree(old.p->dbase);
+      std::lock_guard<std::mutex> pl(g_pin_mu);
+      for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
+        if (&*it == old.p) { g_pins.erase(it); break; }
+    }
   }
+  ApiLock lk;
   if (M->nrows == 0 || M->ncols == 0 || !M->data) return -1;
   int dev = 0;
   HIPDIE(hipGetDevice(&dev));
@@ -1417,45 +1478,43 @@ int m4ri_amd_pin(mzd_t *M) {
   pin_upload(p);
   {
     std::lock_guard<std::mutex> pl(g_pin_mu);
+    for (Pin &q : g_pins)  // another thread pinned the same block in the meantime: keep theirs
+      if (M->data >= q.hbase && M->data < q.hbase + q.words && M->rowstride == q.rowstride) { (void)hipFree(p.dbase); return 0; }
     g_pins.push_back(p);
   }
   return 0;
 }
 
 int m4ri_amd_sync(mzd_t *M) {
-  ApiLock lk;
-  Pin *p = find_pin(M);
-  if (!p) return -1;
-  pin_download(*p);
+  PinLock pl(M);
+  if (!pl.p) return -1;
+  pin_download(*pl.p);
   return 0;
 }
 
 int m4ri_amd_host_modified(mzd_t *M) {
-  ApiLock lk;
-  Pin *p = find_pin(M);
-  if (!p) return -1;
-  pin_upload(*p);
+  PinLock pl(M);
+  if (!pl.p) return -1;
+  pin_upload(*pl.p);
   return 0;
 }
 
 int m4ri_amd_unpin(mzd_t *M) {
-  ApiLock lk;
-  Pin *p = find_pin(M);
-  if (!p) return -1;
-  pin_download(*p);
-  HIPDIE(hipFree(p->dbase));
+  PinLock pl(M);  // the lock of the pin's device: no product that reads or writes the copy is in flight
+  if (!pl.p) return -1;
+  pin_download(*pl.p);
+  HIPDIE(hipFree(pl.p->dbase));
   {
-    std::lock_guard<std::mutex> pl(g_pin_mu);
+    std::lock_guard<std::mutex> gl(g_pin_mu);
     for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
-      if (&*it == p) { g_pins.erase(it); break; }
+      if (&*it == pl.p) { g_pins.erase(it); break; }
   }
   return 0;
 }
 
 int m4ri_amd_is_pinned(const mzd_t *M) {
-  ApiLock lk;
-  Pin *p = find_pin(M);
-  return p ? (p->dev_newer ? 2 : 1) : 0;
+  PinLock pl(M);
+  return pl.p ? (pl.p->dev_newer ? 2 : 1) : 0;
 }
 
 int gf2_multi_wanted(int64_t m, int64_t l, int64_t n);  // multi.hip

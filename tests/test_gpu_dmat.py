@@ -205,3 +205,104 @@ def test_a_matrix_of_an_older_device_list_is_refused_not_used():
     assert m4ri_amd.lib().m4ri_amd_dmat_mul(e.h, d.h, d.h, 0, 0, 0) != 0
     d.free()
     e.free()
+
+
+@pytest.mark.parametrize("lay", [m4ri_amd.LAYOUT_ROWS, m4ri_amd.LAYOUT_CYCLIC1, m4ri_amd.LAYOUT_CYCLIC2])
+def test_two_products_in_flight_on_two_lanes(oracle, lay):
+    """m4ri_amd_dmat_mul_lane: independent products issued alternately on lanes 0 and 1 (own streams, events, arenas per lane, the
+    inputs shared) -- every result bit for bit the oracle's, whatever runs under what; operations that are not products (upload,
+    download) order themselves behind both lanes."""
+    m4ri_amd.set_devices([0] * 4)
+    m, l, n = 2048, 1536, 2304
+    mats = [(Mzd.random(m, l, 30 + k), Mzd.random(l, n, 40 + k)) for k in range(4)]
+    want = [oracle.mul(None, a, b, 0) for a, b in mats]
+    dA = [Dmat(m, l, lay).upload(a) for a, _ in mats]
+    dB = [Dmat(l, n, lay).upload(b) for _, b in mats]
+    dC = [Dmat(m, n, lay) for _ in mats]
+    for rep in range(3):                      # the same buffers again: events and arenas of both lanes are reused
+        for k in range(4):
+            m4ri_amd.dmat_mul(dC[k], dA[k], dB[k], lane=k & 1)
+        for k in range(4):
+            assert dC[k].download().equal(want[k]), (lay, rep, k)
+    # a new operand uploaded while products are in flight on both lanes, then used on lane 1 first
+    A2 = Mzd.random(m, l, 77)
+    m4ri_amd.dmat_mul(dC[0], dA[0], dB[0], lane=0)
+    m4ri_amd.dmat_mul(dC[1], dA[1], dB[1], lane=1)
+    dA[2].upload(A2)
+    m4ri_amd.dmat_mul(dC[2], dA[2], dB[2], lane=1)
+    m4ri_amd.dmat_mul(dC[3], dA[2], dB[3], lane=0)
+    assert dC[2].download().equal(oracle.mul(None, A2, mats[2][1], 0)) and dC[3].download().equal(oracle.mul(None, A2, mats[3][1], 0))
+    assert dC[0].download().equal(want[0]) and dC[1].download().equal(want[1])
+    # accumulate onto the result of the other lane: C2 += A*B after C2 = ... on lane 1 (same C: the caller orders them with a sync)
+    m4ri_amd.multi_sync()
+    m4ri_amd.dmat_mul(dC[2], dA[0], dB[0], add=True, lane=0)
+    assert dC[2].download().equal(oracle.addmul(oracle.mul(None, A2, mats[2][1], 0), mats[0][0], mats[0][1], 0))
+    for d in dA + dB + dC:
+        d.free()
+
+
+def test_lanes_at_a_baseline_shape_match_the_single_gpu_product():
+    """Two 32768^3 products in flight on 8 ranks (Strassen schedule, two row chunks each) against the one-GPU engine."""
+    m4ri_amd.set_devices([0] * 8)
+    n, w = 32768, 32768 // 64
+    lay = m4ri_amd.LAYOUT_CYCLIC1
+    dA, dB = Dmat(n, n, lay).fill(3), Dmat(n, n, lay).fill(4)
+    dC = [Dmat(n, n, lay), Dmat(n, n, lay)]
+    for k in range(6):
+        m4ri_amd.dmat_mul(dC[k & 1], dA, dB, lane=k & 1)
+    A = torch.empty((n, w), dtype=torch.int64, device="cuda")
+    B, C = torch.empty_like(A), torch.empty_like(A)
+    m4ri_amd.fill_dev(A.data_ptr(), w, n, n, 3)
+    m4ri_amd.fill_dev(B.data_ptr(), w, n, n, 4)
+    m4ri_amd.multi_sync()
+    m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n, False, 0)
+    torch.cuda.synchronize()
+    want = C.cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(dC[k].download().valid_words().view(np.int64), want), k
+    for d in [dA, dB] + dC:
+        d.free()
+    m4ri_amd.lib().m4ri_amd_release_workspace()
+
+
+@pytest.mark.parametrize("spec,staged", [("all", 12), ("0-2,1-3", 4)])
+def test_pairs_without_peer_access_copy_through_the_host_and_say_so(oracle, monkeypatch, spec, staged):
+    """The injected "no peer access" flag (M4RI_AMD_NO_PEER) sends those pairs' copies through pinned host memory: still bit-exact in
+    every schedule, and the stats count the pairs.  M4RI_AMD_SELFTEST_PAIRS=1 makes the first-contact self-test (one small copy behind
+    one cross-rank event wait per ordered pair) run between ranks of ONE device too: it must pass before any product is scheduled."""
+    monkeypatch.setenv("M4RI_AMD_NO_PEER", spec)
+    monkeypatch.setenv("M4RI_AMD_SELFTEST_PAIRS", "1")
+    m4ri_amd.set_devices([0] * 3)            # another device list first: the ranks are rebuilt under the new environment
+    Dmat(64, 64, m4ri_amd.LAYOUT_ROWS).free()
+    m4ri_amd.set_devices([0] * 4)
+    try:
+        for lay, variant in ((m4ri_amd.LAYOUT_ROWS, m4ri_amd.VARIANT_SLABS), (m4ri_amd.LAYOUT_CYCLIC1, m4ri_amd.VARIANT_STRASSEN),
+                             (m4ri_amd.LAYOUT_CYCLIC2, m4ri_amd.VARIANT_STRASSEN)):
+            m, l, n = 3000, 2048, 2500
+            A, B = Mzd.random(m, l, 61), Mzd.random(l, n, 62)
+            dA, dB, dC = Dmat(m, l, lay).upload(A), Dmat(l, n, lay).upload(B), Dmat(m, n, lay)
+            m4ri_amd.dmat_mul(dC, dA, dB)
+            st = m4ri_amd.multi_stats()
+            assert (st.variant, st.pairs_staged) == (variant, staged), (st.variant, st.pairs_staged)
+            want = oracle.mul(None, A, B, 0)
+            assert dC.download().equal(want), (spec, lay)
+            e = Dmat(m, n, m4ri_amd.LAYOUT_REPLICATED).convert_from(dC)     # the all-gather through the same copies
+            assert e.download().equal(want)
+            m4ri_amd.dmat_mul(dC, dA, dB, lane=1)
+            assert dC.download().equal(want), (spec, lay, "lane 1")
+            for d in (dA, dB, dC, e):
+                d.free()
+        probe = m4ri_amd.multi_link_probe(8 << 20)
+        assert sum(1 - x for row in probe["peer_access"] for x in row) == staged
+    finally:
+        monkeypatch.delenv("M4RI_AMD_NO_PEER")
+        monkeypatch.delenv("M4RI_AMD_SELFTEST_PAIRS")
+        m4ri_amd.set_devices([0] * 3)
+        Dmat(64, 64, m4ri_amd.LAYOUT_ROWS).free()
+
+
+def test_link_probe_reports_every_ordered_pair():
+    m4ri_amd.set_devices([0] * 4)
+    p = m4ri_amd.multi_link_probe(32 << 20)
+    assert p["pairs"] == 12 and p["ranks_share_devices"] is True and p["gbs_per_direction_min"] > 1.0 and p["all_at_once_gbs"] > 1.0
+    assert all(p["pair_gbs"][i][i] == 0 for i in range(4)) and all(all(row) for row in p["peer_access"])

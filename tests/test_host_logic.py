@@ -139,3 +139,26 @@ def test_layout_runs_partition_the_rows(layout, world):
                         seen[g] += 1
         assert total == rows and (seen is None or set(seen) == {1}), (layout, world, rows)
     assert m4ri_amd.layout_runs(m4ri_amd.LAYOUT_REPLICATED, world, world - 1, 77) == [(0, 77, 0)]
+
+
+def test_pair_table_of_the_multi_device_path():
+    """Which ordered rank pairs copy through the host (m4ri_amd_multi_pair_table, the rule ensure_ranks applies before the first
+    product): pairs whose DEVICES have no peer access, plus the test hook's rank pairs; ranks sharing a device copy directly."""
+    full = [[1] * 4 for _ in range(4)]
+    assert m4ri_amd.multi_pair_table([0, 1, 2, 3], full) == [[0] * 4 for _ in range(4)]
+    # device 1 cannot map device 3 (one direction only): exactly the pair rank(dev 1) <- rank(dev 3)
+    can = [row[:] for row in full]
+    can[1][3] = 0
+    t = m4ri_amd.multi_pair_table([0, 1, 2, 3], can)
+    assert t[1][3] == 1 and sum(map(sum, t)) == 1
+    # eight ranks on four devices, two per device: the device pair (1, 3) is four rank pairs; same-device ranks stay direct
+    t = m4ri_amd.multi_pair_table([0, 0, 1, 1, 2, 2, 3, 3], can)
+    assert sorted((i, j) for i in range(8) for j in range(8) if t[i][j]) == [(2, 6), (2, 7), (3, 6), (3, 7)]
+    # the hook: "all" = every pair but the diagonal, a list = those rank pairs in both directions; junk and out-of-range entries are ignored
+    assert sum(map(sum, m4ri_amd.multi_pair_table([0] * 4, [[1]], "all"))) == 12
+    t = m4ri_amd.multi_pair_table([0] * 4, [[1]], "0-2,1-3")
+    assert sorted((i, j) for i in range(4) for j in range(4) if t[i][j]) == [(0, 2), (1, 3), (2, 0), (3, 1)]
+    assert sum(map(sum, m4ri_amd.multi_pair_table([0] * 4, [[1]], "0-9,2-2,x"))) == 0
+    # no access anywhere: every pair of different devices
+    t = m4ri_amd.multi_pair_table([0, 1, 2], [[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    assert t == [[0, 1, 1], [1, 0, 1], [1, 1, 0]]
