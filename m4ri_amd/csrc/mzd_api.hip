@@ -577,6 +577,14 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     for (int j = 0; j < gj; ++j) need += dev_words(K(k), Cc(j));
   for (int i = 0; i < gi; ++i)
     for (int j = 0; j < gj; ++j) need += dev_words(R(i), Cc(j));
+  // M4RI_AMD_PIPE_W7=1: the top level as Strassen-Winograd over the 2 x 2 x 2 grid (7 block products instead of 8) when the halves are
+  // equal and whole -- the schedule below.  Built on the round-4 review's suggestion, bit-exact, and measured SLOWER than the 8 classical
+  // block products (65536^3: 44.6 against 41.7 ms, same box, alternating; profiles/r05_host_pipeline_timeline_65536.log): its third
+  // product needs seven of the eight quadrants, which the PCIe link delivers at 16.8 ms at the earliest, while the classical order
+  // never waits.  It stays an option for hosts with a faster link, not the default.
+  static const bool w7_on = getenv("M4RI_AMD_PIPE_W7") && atoi(getenv("M4RI_AMD_PIPE_W7")) == 1;
+  const bool w7 = w7_on && !add && gi == 2 && gj == 2 && gk == 2 && R(0) == R(1) && K(0) == K(1) && Cc(0) == Cc(1) && K(0) % 64 == 0 && Cc(0) % 64 == 0;
+  if (w7) need += dev_words(R(0), K(0)) + dev_words(K(0), Cc(0)) + dev_words(R(0), Cc(0));
   arena_reserve(need);
   auto block_of = [&](const mzd_t *M, int64_t r0, int64_t r1, int64_t c0, int64_t c1) {  // mzd_init_window, mzd.c:159-177
     mzd_t S = *M;
@@ -637,14 +645,18 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
   // while the next operands travel up (PCIe is full duplex: 53 GiB/s each way on this box, tools/pcie_probe_2d.py).
   std::mutex dl_mu;
   std::condition_variable dl_cv;
-  int issued = 0;  // blocks of C whose `done` event exists
+  int issued = 0;  // entries of dl_order whose `done` event exists
+  std::vector<int> dl_order((size_t)nt);  // the blocks of C in the order they complete
+  for (int t = 0; t < nt; ++t) dl_order[(size_t)t] = t;
+  if (w7) { dl_order[1] = 3; dl_order[2] = 1; dl_order[3] = 2; }  // C11, C22, C12, C21
   std::thread downloader([&]() {
     HIPDIE(hipSetDevice(dev));
-    for (int t = 0; t < nt; ++t) {
+    for (int q = 0; q < nt; ++q) {
       {
         std::unique_lock<std::mutex> lk(dl_mu);
-        dl_cv.wait(lk, [&] { return issued > t; });
+        dl_cv.wait(lk, [&] { return issued > q; });
       }
+      const int t = dl_order[(size_t)q];
       HIPDIE(hipEventSynchronize(done[(size_t)t]));
       mzd_t S = c_block(t / gj, t % gj);
       const double t0 = trace ? now_ms() : 0;
@@ -658,15 +670,88 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     HIPDIE(hipEventSynchronize(tr_base));
     tr_base_ms = now_ms();
   }
+  auto block_done = [&](int t) {  // block t of C is complete once everything issued on the compute stream so far has run: tell the downloader
+    ev(done[(size_t)t]);
+    HIPDIE(hipEventRecord(done[(size_t)t], cs));
+    {
+      std::lock_guard<std::mutex> lk(dl_mu);
+      issued += 1;
+    }
+    dl_cv.notify_one();
+  };
   // products in the order (block of C, inner slice); the uploads of step s + 1 are issued right after product s
-  const int steps = nt * gk;
+  const int steps = w7 ? 0 : nt * gk;
   auto need_for = [&](int s) {
     const int t = s / gk, k = s % gk;
     upload_a(t / gj, k);
     upload_b(k, t % gj);
     prepare_c(t);
   };
-  need_for(0);
+  if (w7) {
+    // Strassen-Winograd at the top (strassen.c:111-150 in the product form of engine.hip: A-side [A11, A12, S4, A22, S1, S2, S3], B-side
+    // [B11, B21, B22, T4, T1, T2, T3]; P0 goes to all four quadrants, P1 to C11, P2 to C12, P3 to C21, P4 to C12 and C22, P5 to all but
+    // C11, P6 to C21 and C22), in the order the quadrants ARRIVE: P0 and P1 need one quadrant of each operand, P6 seven of the eight,
+    // the rest all.  The quadrants of C accumulate on the device (single-target products as addmul straight into their quadrant, the
+    // others through one temporary), and each is downloaded when its last term has landed: C11 after P1, C22 after P5, C12 after P2,
+    // C21 after P3.  The operand sums are chains in two temporaries: X = S3, S1, S2 (+= A11), S4 (+= A12); Y = T3, T1, T2 (+= B22), T4 (+= B21).
+    const int64_t hm = R(0), hl = K(0), hn = Cc(0);
+    DevMat X, Y, P;
+    dev_alloc(X, hm, hl);
+    dev_alloc(Y, hl, hn);
+    dev_alloc(P, hm, hn);
+    for (int t = 0; t < 4; ++t) prepare_c(t);
+    auto qa = [&](int i, int k) -> const DevMat & { return dA[(size_t)i * gk + k]; };
+    auto qb = [&](int k, int j) -> const DevMat & { return dB[(size_t)k * gj + j]; };
+    auto wait_a = [&](int i, int k) { HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i * gk + k], 0)); };
+    auto wait_b = [&](int k, int j) { HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)k * gj + j], 0)); };
+    auto xor3 = [&](const DevMat &D, const DevMat &U, const DevMat &V, int64_t rows, int64_t ncols) {
+      HIPDIE(m4ri_amd_xor_dev(D.p, D.stride, U.p, U.stride, V.p, V.stride, rows, ncols, cs));
+    };
+    int pno = 0;
+    auto product = [&](const DevMat &c, const DevMat &a, const DevMat &b, bool acc) {
+      if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p0.push_back(e); }
+      HIPDIE(m4ri_amd_mul_dev(c.p, c.stride, a.p, a.stride, b.p, b.stride, hm, hl, hn, acc ? 1 : 0, cutoff, cs));
+      if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p1.push_back(e); }
+      ++pno;
+    };
+    const size_t cq_bytes = (size_t)hm * (size_t)dC[0].stride * 8;
+    for (int t = 0; t < 4; ++t) HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
+    upload_a(0, 0); upload_b(0, 0);                       // A11, B11
+    wait_a(0, 0); wait_b(0, 0);
+    product(dC[0], qa(0, 0), qb(0, 0), false);            // P0 -> C11, and the start of the other three
+    for (int t = 1; t < 4; ++t) HIPDIE(hipMemcpyAsync(dC[(size_t)t].p, dC[0].p, cq_bytes, hipMemcpyDeviceToDevice, cs));
+    upload_a(0, 1); upload_b(1, 0);                       // A12, B21
+    wait_a(0, 1); wait_b(1, 0);
+    product(dC[0], qa(0, 1), qb(1, 0), true);             // P1: C11 += A12 * B21
+    block_done(0);
+    upload_a(1, 0); upload_b(0, 1); upload_b(1, 1);       // A21, B12, B22
+    wait_a(1, 0); wait_b(0, 1); wait_b(1, 1);
+    xor3(X, qa(0, 0), qa(1, 0), hm, hl);                  // S3 = A11 + A21
+    xor3(Y, qb(1, 1), qb(0, 1), hl, hn);                  // T3 = B22 + B12
+    product(P, X, Y, false);                              // P6 -> C21, C22
+    xor3(dC[3], dC[3], P, hm, hn);
+    xor3(dC[2], dC[2], P, hm, hn);
+    upload_a(1, 1);                                       // A22
+    wait_a(1, 1);
+    xor3(X, qa(1, 0), qa(1, 1), hm, hl);                  // S1 = A21 + A22
+    xor3(Y, qb(0, 1), qb(0, 0), hl, hn);                  // T1 = B12 + B11
+    product(P, X, Y, false);                              // P4 -> C12, C22
+    xor3(dC[3], dC[3], P, hm, hn);
+    xor3(dC[1], dC[1], P, hm, hn);
+    xor3(X, X, qa(0, 0), hm, hl);                         // S2 = S1 + A11
+    xor3(Y, Y, qb(1, 1), hl, hn);                         // T2 = T1 + B22
+    product(P, X, Y, false);                              // P5 -> C12, C21, C22
+    xor3(dC[3], dC[3], P, hm, hn);
+    block_done(3);
+    xor3(dC[2], dC[2], P, hm, hn);
+    xor3(dC[1], dC[1], P, hm, hn);
+    xor3(X, X, qa(0, 1), hm, hl);                         // S4 = S2 + A12
+    product(dC[1], X, qb(1, 1), true);                    // P2: C12 += S4 * B22
+    block_done(1);
+    xor3(Y, Y, qb(1, 0), hl, hn);                         // T4 = T2 + B21
+    product(dC[2], qa(1, 1), Y, true);                    // P3: C21 += A22 * T4
+    block_done(2);
+  } else need_for(0);
   for (int s = 0; s < steps; ++s) {
     const int t = s / gk, k = s % gk, i = t / gj, j = t % gj;
     HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i * gk + k], 0));
@@ -676,15 +761,7 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p0.push_back(e); }
     HIPDIE(m4ri_amd_mul_dev(dC[(size_t)t].p, dC[(size_t)t].stride, a.p, a.stride, b.p, b.stride, R(i), K(k), Cc(j), (add || k > 0) ? 1 : 0, cutoff, cs));
     if (trace) { hipEvent_t e; HIPDIE(hipEventCreate(&e)); HIPDIE(hipEventRecord(e, cs)); tr_p1.push_back(e); }
-    if (k == gk - 1) {
-      ev(done[(size_t)t]);
-      HIPDIE(hipEventRecord(done[(size_t)t], cs));
-      {
-        std::lock_guard<std::mutex> lk(dl_mu);
-        issued = t + 1;
-      }
-      dl_cv.notify_one();
-    }
+    if (k == gk - 1) block_done(t);
     if (s + 1 < steps) need_for(s + 1);  // overlaps product s
   }
   downloader.join();
@@ -695,14 +772,15 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
       float a = 0, b = 0;
       HIPDIE(hipEventElapsedTime(&a, tr_base, tr_p0[s]));
       HIPDIE(hipEventElapsedTime(&b, tr_base, tr_p1[s]));
-      marks.push_back({'P', (int)s / gk, (int)s % gk, tr_base_ms + a, tr_base_ms + b});
+      marks.push_back({'P', w7 ? (int)s : (int)s / gk, w7 ? 0 : (int)s % gk, tr_base_ms + a, tr_base_ms + b});
       (void)hipEventDestroy(tr_p0[s]);
       (void)hipEventDestroy(tr_p1[s]);
     }
     (void)hipEventDestroy(tr_base);
     std::sort(marks.begin(), marks.end(), [](const Mark &x, const Mark &y) { return x.t0 < y.t0; });
-    fprintf(stderr, "m4ri_amd pipeline %lld x %lld x %lld, grid %d x %d x %d: %.2f ms (A/B = upload of block (i,k)/(k,j), P = product (block of C, slice), D = download)\n",
-            (long long)m, (long long)l, (long long)n, gi, gj, gk, t_end);
+    fprintf(stderr, "m4ri_amd pipeline %lld x %lld x %lld, grid %d x %d x %d%s: %.2f ms (A/B = upload of block (i,k)/(k,j), P = product (block of C, slice)%s, D = download)\n",
+            (long long)m, (long long)l, (long long)n, gi, gj, gk, w7 ? ", Strassen-Winograd at the top" : "", t_end,
+            w7 ? " -- here the seven in the order P0 P1 P6 P4 P5 P2 P3" : "");
     for (const Mark &k : marks) fprintf(stderr, "  %c(%d,%d) %8.2f .. %8.2f  (%6.2f ms)\n", k.what, k.a, k.b, k.t0, k.t1, k.t1 - k.t0);
   }
   for (auto *v : {&upA, &upB, &upC, &done})

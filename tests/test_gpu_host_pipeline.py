@@ -68,3 +68,100 @@ def test_pipelined_equals_one_shot_at_32768():
     finally:
         m4ri_amd.set_host_pipeline(old)
     assert piped.equal(whole)
+
+
+@pytest.mark.parametrize("m,l,n", [(16384, 640, 8192), (32768, 512, 16384), (2048, 512, 40000)])
+def test_a_reused_result_block_is_written_completely(oracle, m, l, n):
+    """mzd_mul(NULL, ...) takes a parked block of the same size back "as it is" (mzd_api.hip: late_begin) on the grounds that every
+    run path overwrites every valid word.  The check behind that sentence: in a child process with M4RI_AMD_POISON_RESULT=1 the
+    reused block is filled with a pattern first; the pipelined and the one-shot path must still return the oracle's bits (and
+    zero padding words)."""
+    import os
+    import subprocess
+    import sys
+    code = f'''
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+import m4ri_amd, cpu_libs
+from m4ri_amd.mzd import Mzd
+m4ri_amd.init(0)
+orc = cpu_libs.oracle()
+lib = m4ri_amd.lib()
+for pipeline in (1, 0):
+    m4ri_amd.set_host_pipeline(pipeline)
+    for rep in range(3):
+        A, B = Mzd.random({m}, {l}, 10 + rep), Mzd.random({l}, {n}, 20 + rep)
+        want = orc.mul(None, A, B, 0)
+        r = lib.mzd_mul(None, A.ptr, B.ptr, 0)          # the library's own allocator (no libm4ri in this process): fresh, then reused blocks
+        from m4ri_amd.mzd import from_struct_ptr
+        s = r.contents
+        raw = np.ctypeslib.as_array(s.data, shape=(s.nrows * s.rowstride,)).reshape(s.nrows, s.rowstride)
+        assert not raw[:, s.width:].any(), ("padding", pipeline, rep)
+        assert from_struct_ptr(r).equal(want), ("bits", pipeline, rep)
+        lib.m4ri_amd_result_free(r)                     # parks the block: the next product of this size takes it back
+print("poisoned blocks OK")
+'''
+    env = dict(os.environ, M4RI_AMD_POISON_RESULT="1", M4RI_AMD_SMALL_THRESHOLD="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "poisoned blocks OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _child(code, env_extra, timeout=900):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = f"import sys, json, hashlib, numpy as np\nsys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+    r = subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("w7", ["1", "0"])
+def test_winograd_at_the_top_of_the_block_pipeline(w7):
+    """The 2 x 2 x 2 block grid of the host pipeline run as Strassen-Winograd (7 block products in the order their quadrants arrive,
+    the quadrants of C accumulated on the device; mzd_api.hip run_pipelined) against the oracle, at sizes the oracle finishes in
+    seconds (the grid forced with M4RI_AMD_PIPE_GRID; by itself it is chosen from 65536^3 on; the schedule is opt-in, M4RI_AMD_PIPE_W7=1:
+    it measured slower than the 8 classical block products, which is what =0 and the default run): same bits.  Unequal halves and C += A*B keep the classical grid; C == NULL and C given both covered."""
+    code = '''
+import m4ri_amd, cpu_libs
+from m4ri_amd.mzd import Mzd
+m4ri_amd.init(0); m4ri_amd.set_host_pipeline(1); m4ri_amd.set_small_product_threshold(0)
+orc = cpu_libs.oracle()
+for (m, l, n) in [(8192, 2048, 2048), (16384, 4096, 8192), (8192, 1280, 1152), (8192 + 4096, 2048, 2048), (8192, 2048 + 64, 2048)]:
+    A, B = Mzd.random(m, l, 1), Mzd.random(l, n, 2)
+    want = orc.mul(None, A, B, 0)
+    assert m4ri_amd.mzd_mul(None, A, B, 0).equal(want), (m, l, n)
+    C = Mzd.random(m, n, 3)
+    assert m4ri_amd.mzd_mul(C, A, B, 0).equal(want), (m, l, n)
+    C0 = Mzd.random(m, n, 4)
+    assert m4ri_amd.mzd_addmul(C0.copy(), A, B, 0).equal(orc.addmul(C0.copy(), A, B, 0)), (m, l, n)
+print("ok")
+'''
+    out, err = _child(code, {"M4RI_AMD_PIPE_GRID": "2,2,2", "M4RI_AMD_PIPE_W7": w7, "M4RI_AMD_PIPE_TRACE": "1"})
+    assert "ok" in out
+    assert ("Strassen-Winograd at the top" in err) == (w7 == "1")          # the schedule really ran (equal halves), and the switch switches it off
+    assert "grid 2 x 2 x 2:" in err or w7 == "1"                          # unequal halves / addmul: the classical grid
+
+
+@pytest.mark.parametrize("w7", ["0", "1"])
+def test_config3_through_the_host_entry_point_matches_the_reference_sha256(w7):
+    """BASELINE.json configs[2] the way the reference's own bench calls it -- mzd_mul(NULL, A, B, 0) on host matrices, 65536^3, seeds
+    3, 4 -- through the block pipeline (the default 8 classical block products, and the optional Strassen-Winograd top level): the
+    SHA-256 of the real reference's product."""
+    code = '''
+import m4ri_amd
+from m4ri_amd.mzd import Mzd
+m4ri_amd.init(0)
+n = 65536
+A, B = Mzd.random(n, n, 3), Mzd.random(n, n, 4)
+C = m4ri_amd.mzd_mul(None, A, B, 0)
+print("sha", hashlib.sha256(C.masked().tobytes()).hexdigest())
+'''
+    import json
+    import os
+    out, err = _child(code, {"M4RI_AMD_PIPE_TRACE": "1", "M4RI_AMD_PIPE_W7": w7}, timeout=1500)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = [e["sha256"] for e in json.load(open(os.path.join(root, "tests", "golden", "sha256.json")))
+            if (e["op"], e["m"], e["l"], e["n"], e["seed_a"], e["seed_b"]) == ("mul", 65536, 65536, 65536, 3, 4) and not e.get("cutoff")]
+    assert want and ("sha " + want[0]) in out and ("Strassen-Winograd at the top" in err) == (w7 == "1")

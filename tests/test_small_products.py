@@ -72,7 +72,8 @@ def test_entry_points_take_the_host_routine_exactly_when_they_should(oracle):
             assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0))
             assert m4ri_amd.mzd_addmul(C0.copy(), A, B, 0).equal(oracle.addmul(C0.copy(), A, B, 0))
             assert m4ri_amd.mzd_mul_m4rm(None, A, B, 0).equal(oracle.mul(None, A, B, 0))
-            assert m4ri_amd.small_product_count() == before + 3, (m, l, n)
+            took = m4ri_amd.lib().m4ri_amd_small_product_wanted(m, l, n)   # 256^3 is m * l * n == 2^24 but over the routine's own cost bound: the GPU
+            assert took == (0 if (m, l, n) == (256, 256, 256) else 1) and m4ri_amd.small_product_count() == before + 3 * took, (m, l, n)
         A, B = Mzd.random(300, 300, 44), Mzd.random(300, 300, 45)        # 2.7e7 > 2^24: the GPU
         before = m4ri_amd.small_product_count()
         assert m4ri_amd.mzd_mul(None, A, B, 0).equal(oracle.mul(None, A, B, 0)) and m4ri_amd.small_product_count() == before
@@ -121,3 +122,45 @@ def test_host_routine_fuzz_shapes_and_windows(oracle):
             (oracle.addmul if add else oracle.mul)(wc, A.copy(), B.copy(), 0)
             m4ri_amd.small_mul_host(C, A, B, add)
             assert np.array_equal(Cp.buf, wp.buf), (case, m, l, n, add)
+
+
+def test_which_products_the_host_routine_takes_is_a_cost_rule():
+    """m * l * n alone sent 1 x 1 x 2^26 and 2^26 x 1 x 1 to a single-threaded loop: the rule now also bounds the
+    routine's own cost in row-word operations (pure arithmetic: m4ri_amd_small_product_wanted, default threshold 2^26)."""
+    old = m4ri_amd.set_small_product_threshold(1 << 26)
+    try:
+        w = m4ri_amd.lib().m4ri_amd_small_product_wanted
+        for shape in [(1, 1, 1), (64, 64, 64), (256, 256, 256), (384, 384, 384), (1000, 10, 20), (16, 4096, 16), (4096, 16, 64), (64, 64, 4096), (2048, 64, 64)]:
+            assert w(*shape) == 1, shape                 # the measured wins of profiles/r04_crossover_cpu_gpu.log stay on the host
+        for shape in [(1, 1, 1 << 26), (1 << 26, 1, 1), (1, 1 << 26, 1), (8, 8192, 1024), (512, 512, 512), (1 << 20, 8, 8), (100000, 1, 600)]:
+            assert w(*shape) == 0, shape                 # degenerate or simply too large: the GPU
+        assert w(0, 5, 5) == 0 and w(5, 0, 5) == 1       # an empty inner dimension is a clear of C: nothing to upload
+        m4ri_amd.set_small_product_threshold(0)
+        assert w(4, 4, 4) == 0
+    finally:
+        m4ri_amd.set_small_product_threshold(old)
+
+
+@pytest.mark.gpu
+def test_parity_at_the_default_threshold(oracle):
+    """One parity run with the routing a program under LD_PRELOAD gets (the session fixture forces every other test's products onto the
+    GPU): the reference's own shape lists through the entry points at the DEFAULT threshold, each product on the side the rule
+    names, every result the oracle's."""
+    assert m4ri_amd.lib().m4ri_amd_device_count() >= 1
+    m4ri_amd.init(0)
+    old = m4ri_amd.set_small_product_threshold(1 << 26)
+    try:
+        took_host = took_gpu = 0
+        for (m, l, n, k, cutoff) in shapes.MUL + shapes.EDGE + [(1, 1, 70000, 0, 0), (3000, 2, 3000, 0, 0)]:
+            A, B = Mzd.random(m, l, shapes.seed_of(m, l, n, 1)), Mzd.random(l, n, shapes.seed_of(m, l, n, 2))
+            before = m4ri_amd.small_product_count()
+            got = m4ri_amd.mzd_mul(None, A, B, cutoff)
+            assert got.equal(oracle.mul(None, A, B, 0)), (m, l, n)
+            host = m4ri_amd.small_product_count() - before
+            if m and n and l:
+                assert host == m4ri_amd.lib().m4ri_amd_small_product_wanted(m, l, n), (m, l, n, host)
+            took_host += host
+            took_gpu += 1 - host
+        assert took_host > 5 and took_gpu > 5, (took_host, took_gpu)
+    finally:
+        m4ri_amd.set_small_product_threshold(old)
