@@ -362,9 +362,7 @@ def main():
             return
         raise SystemExit(controller(args))
     peer = args.transport == "peer" and args.gpus > 1
-    world = args.gpus if peer else int(os.environ.get("WORLD_SIZE", "1"))
-    rank = 0 if peer else int(os.environ.get("RANK", "0"))
-    local_rank = 0 if peer else int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = (args.gpus, 0, 0) if peer else (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if world != args.gpus:  # never print an n_gpus the command did not ask for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
@@ -789,14 +787,10 @@ def main():
         traffic, traffic_detail = None, "not measured for this configuration"
         if not multi and args.workload == "mul" and not args.no_traffic:
             traffic, traffic_detail = measure_leaf_traffic(n, args.cutoff)
-        if args.workload == "leaf16384":
-            workload = f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])"
-        elif args.workload == "rect131072":
-            workload = f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4])"
-        elif (M, L, N) == (65536, 65536, 65536):
-            workload = f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves"
-        else:
-            workload = f"mzd_mul {M}x{L}x{N} (not a BASELINE.json configuration): Strassen-Winograd over M4RM leaves"
+        workload = (f"mzd_mul_m4rm {n}^3 leaf only (BASELINE.json configs[1])" if args.workload == "leaf16384" else
+                    f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4])" if args.workload == "rect131072" else
+                    f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves" if (M, L, N) == (65536, 65536, 65536) else
+                    f"mzd_mul {M}x{L}x{N} (not a BASELINE.json configuration): Strassen-Winograd over M4RM leaves")
         out = {
             "metric": "gf2_matmul_n3_equiv_bitops_per_sec", "value": value, "unit": "bit-op/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
