@@ -440,7 +440,7 @@ int pin_device(const mzd_t *M) {  // the device M's pinned parent lives on, -1 w
 struct PinLock {
   std::unique_lock<std::mutex> lk;
   Pin *p   = nullptr;
-  int prev = -1;
+  int prev = -1, dev = -1;  // the caller's current device, the pin's (kept here: unpin erases *p before this object goes)
   explicit PinLock(const mzd_t *M) {
     for (int tries = 0; tries < 64; ++tries) {
       const int d = pin_device(M);
@@ -448,7 +448,8 @@ struct PinLock {
       lk = std::unique_lock<std::mutex>(g_dev_mu[d]);
       Pin *q = find_pin(M);
       if (q && q->device == d) {
-        p = q;
+        p   = q;
+        dev = d;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != d) HIPDIE(hipSetDevice(d));
         return;
@@ -457,7 +458,7 @@ struct PinLock {
     }
   }
   ~PinLock() {
-    if (p && prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (p && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
   }
 };
 
@@ -646,9 +647,11 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
   std::mutex dl_mu;
   std::condition_variable dl_cv;
   int issued = 0;  // entries of dl_order whose `done` event exists
-  std::vector<int> dl_order((size_t)nt);  // the blocks of C in the order they complete
-  for (int t = 0; t < nt; ++t) dl_order[(size_t)t] = t;
-  if (w7) { dl_order[1] = 3; dl_order[2] = 1; dl_order[3] = 2; }  // C11, C22, C12, C21
+  std::vector<int> dl_order((size_t)nt);  // the blocks of C in the order they are computed (and complete)
+  // M4RI_AMD_PIPE_ORDER=c (developer): block columns of C outermost -- the first gi blocks need only the first block column of B
+  static const bool col_major = getenv("M4RI_AMD_PIPE_ORDER") && getenv("M4RI_AMD_PIPE_ORDER")[0] == 'c';
+  for (int q = 0; q < nt; ++q) dl_order[(size_t)q] = col_major ? (q % gi) * gj + (q / gi) : q;
+  if (w7) { dl_order[0] = 0; dl_order[1] = 3; dl_order[2] = 1; dl_order[3] = 2; }  // C11, C22, C12, C21
   std::thread downloader([&]() {
     HIPDIE(hipSetDevice(dev));
     for (int q = 0; q < nt; ++q) {
@@ -682,7 +685,7 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
   // products in the order (block of C, inner slice); the uploads of step s + 1 are issued right after product s
   const int steps = w7 ? 0 : nt * gk;
   auto need_for = [&](int s) {
-    const int t = s / gk, k = s % gk;
+    const int t = dl_order[(size_t)(s / gk)], k = s % gk;
     upload_a(t / gj, k);
     upload_b(k, t % gj);
     prepare_c(t);
@@ -753,7 +756,7 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
     block_done(2);
   } else need_for(0);
   for (int s = 0; s < steps; ++s) {
-    const int t = s / gk, k = s % gk, i = t / gj, j = t % gj;
+    const int t = dl_order[(size_t)(s / gk)], k = s % gk, i = t / gj, j = t % gj;
     HIPDIE(hipStreamWaitEvent(cs, upA[(size_t)i * gk + k], 0));
     HIPDIE(hipStreamWaitEvent(cs, upB[(size_t)k * gj + j], 0));
     HIPDIE(hipStreamWaitEvent(cs, upC[(size_t)t], 0));
@@ -772,7 +775,7 @@ bool run_pipelined(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, int cutof
       float a = 0, b = 0;
       HIPDIE(hipEventElapsedTime(&a, tr_base, tr_p0[s]));
       HIPDIE(hipEventElapsedTime(&b, tr_base, tr_p1[s]));
-      marks.push_back({'P', w7 ? (int)s : (int)s / gk, w7 ? 0 : (int)s % gk, tr_base_ms + a, tr_base_ms + b});
+      marks.push_back({'P', w7 ? (int)s : dl_order[s / (size_t)gk], w7 ? 0 : (int)s % gk, tr_base_ms + a, tr_base_ms + b});
       (void)hipEventDestroy(tr_p0[s]);
       (void)hipEventDestroy(tr_p1[s]);
     }

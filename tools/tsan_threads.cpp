@@ -71,8 +71,31 @@ int main(int argc, char **argv) {
         m4ri_amd_result_free(C); m4ri_amd_result_free(D); m4ri_amd_mzd_free(Z);
       }
     });
+  // round 5: a fifth thread keeps two products in flight on the two lanes of the distributed path while the others run (own distributed
+  // matrices: the lanes' rule), and a sixth asks about / syncs the pins of thread 2 and 3 from outside (the pin table's entries are
+  // guarded by the lock of the device the pin lives on, not by the caller's)
+  int bad_lane = 0;
+  th.emplace_back([&] {
+    if (m4ri_amd_init(0)) { bad_lane = 100; return; }
+    m4ri_amd_dmat *dA = m4ri_amd_dmat_create(shapes[1][0], shapes[1][1], M4RI_AMD_LAYOUT_CYCLIC1);
+    m4ri_amd_dmat *dB = m4ri_amd_dmat_create(shapes[1][1], shapes[1][2], M4RI_AMD_LAYOUT_CYCLIC1);
+    m4ri_amd_dmat *dC[2] = {m4ri_amd_dmat_create(shapes[1][0], shapes[1][2], M4RI_AMD_LAYOUT_CYCLIC1), m4ri_amd_dmat_create(shapes[1][0], shapes[1][2], M4RI_AMD_LAYOUT_CYCLIC1)};
+    if (!dA || !dB || !dC[0] || !dC[1] || m4ri_amd_dmat_upload(dA, A[1]) || m4ri_amd_dmat_upload(dB, B[1])) { bad_lane = 100; return; }
+    for (int r = 0; r < 2 * reps; ++r) bad_lane += m4ri_amd_dmat_mul_lane(dC[r & 1], dA, dB, 0, 0, 0, r & 1) != 0;
+    for (int k = 0; k < 2; ++k) {
+      mzd_t *H = m4ri_amd_mzd_init(shapes[1][0], shapes[1][2]);
+      bad_lane += m4ri_amd_dmat_download(dC[k], H) != 0 || !same(H, want[1]);
+      m4ri_amd_mzd_free(H);
+    }
+    m4ri_amd_dmat_free(dA); m4ri_amd_dmat_free(dB); m4ri_amd_dmat_free(dC[0]); m4ri_amd_dmat_free(dC[1]);
+  });
+  th.emplace_back([&] {
+    for (int r = 0; r < 200 * reps; ++r)
+      for (int i = 2; i < 4; ++i) { (void)m4ri_amd_is_pinned(A[i]); (void)m4ri_amd_is_pinned(B[i]); if (r % 16 == 0) (void)m4ri_amd_sync(B[i]); }
+  });
   for (auto &t : th) t.join();
-  int total = 0;
+  printf("lanes thread: %d mismatches\n", bad_lane);
+  int total = bad_lane;
   for (int i = 0; i < 4; ++i) { printf("thread %d: %d mismatches\n", i, bad[i]); total += bad[i]; }
   m4ri_amd_release_workspace();
   printf("%s\n", total ? "TSAN_THREADS FAILED" : "TSAN_THREADS results ok");
