@@ -46,6 +46,15 @@ hipError_t gf2_launch_winograd_up4(hipStream_t s, int acc, const word *prod, wor
 hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
+// scheme_passes.hip: four levels as two applications of a rank-R scheme for the 4 x 4 x 4 block product (R = 47: 2209 leaves, not 2401)
+int gf2_scheme444_rank(void);
+int gf2_scheme444_ok(int64_t a_rows, int64_t a_cw, int64_t b_rows, int64_t b_cw);
+hipError_t gf2_launch_scheme_down(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *child, int64_t nparents,
+                                  int64_t crows, int64_t cw);
+hipError_t gf2_launch_scheme_down_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4, int64_t nparents, int64_t crows,
+                                       int64_t cw);
+hipError_t gf2_launch_scheme_up(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs, int64_t nparents, int64_t crows,
+                                int64_t cw);
 int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
@@ -456,6 +465,10 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   };
   double p7 = 1;
   for (int d = 0; d < L; ++d) p7 *= 7;
+  // four fused levels run as two applications of the rank-R 4 x 4 x 4 scheme where the leaves allow it: R^2 products instead of 7^4
+  const bool scheme = L >= 4 && g_max_fuse >= 4 && mm >= 192 && gf2_scheme444_ok(mm, words_of(ll), ll, words_of(nn)) != 0;
+  const double srat = scheme ? (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank() / 2401.0 : 1.0;
+  p7 *= srat;
   double t = leaf(mm, ll, nn, p7);
   // passes over the even block
   const int64_t me = mm << L, le = ll << L, ne = nn << L;
@@ -464,7 +477,7 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   auto r = [](int d) { double x = 1; while (d-- > 0) x *= 1.75; return x; };
   double factor = 0;
   for (int d = 0; d < L - fuse; ++d) factor += r(d) + r(d + 1);
-  if (L > 0) factor += r(L - fuse) + r(L);
+  if (L > 0) factor += r(L - fuse) + r(L) * srat;
   double bytes = (sa + sb + sc) * factor;
   if (L < 2 || (mm % 32) != 0 || (words_of(ll) % 16) != 0) bytes += 2.0 * sa * r(L);  // the separate pack pass of A: no fused form below two levels or for such leaves
   if (fuse == 4 && (words_of(nn) % 32) != 0) bytes += sc * (r(L) + 1);  // atomic up pass: zeroed output, children folded by read-modify-write
@@ -562,8 +575,15 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // With a fused last pass and a leaf that reads packed A, the pass writes the packed form itself:
   // the row-major A operands of the leaves are never materialised and the pack pass disappears.
   const LeafKind leaf_kind = pick_leaf(m >> L, (l / (64ll << L)) * 64, (n / (64ll << L)) * 64);  // (the dimensions launch_leaf_one will see)
-  bool prepack = false;
-  if (fuse >= 2 && leaf_kind.gen == 4) {
+  // Four fused levels as TWO applications of the rank-R scheme for the 4 x 4 x 4 block product (scheme_passes.hip): R^2 leaves per
+  // ancestor of the fused pass instead of 7^4, packed A written by the pass itself.  Needs generation 4's packed A and leaf shapes the
+  // scheme kernels take; everything else keeps the Winograd passes.
+  const int64_t leaf_m = m >> L, leaf_l = l >> L, leaf_n = n >> L;
+  const bool scheme = fuse == 4 && leaf_kind.gen == 4 && gf2_scheme444_ok(leaf_m, leaf_l / 64, leaf_l, leaf_n / 64) != 0 &&
+                      (uint64_t)gf2_m4rm8_a4_words(leaf_m, leaf_l, 1) * 8 < (1ull << 32);
+  const int64_t leaves = scheme ? ipow7(L - 4) * (int64_t)gf2_scheme444_rank() * (int64_t)gf2_scheme444_rank() : ipow7(L);  // products of the leaf launch
+  bool prepack = scheme;
+  if (!scheme && fuse >= 2 && leaf_kind.gen == 4) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
     const int d0      = L - fuse;
     const word *pa    = d0 == 0 ? A.p : aligned16;  // deeper levels live in the 256-byte aligned workspace
@@ -578,7 +598,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
   for (int d = 1; d <= L; ++d) {
     if (!materialised(d)) continue;
-    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : ipow7(d);
     need += (prepack && d == L ? 0 : pad((size_t)cnt * md * wl)) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
   // C += A*B through a three-level up pass: the pass writes a temporary and one XOR pass folds it into
@@ -586,7 +606,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   const bool acc_via_tmp = add && fuse == 3 && L == 3;
   if (acc_via_tmp) need += pad((size_t)m * (n / 64));
   {
-    const size_t a7_bfs = packed_a_words(m >> L, l >> L, ipow7(L));
+    const size_t a7_bfs = packed_a_words(m >> L, l >> L, leaves);
     if (a7_bfs > a7_extra) a7_extra = a7_bfs;
   }
   a7_extra = pad(a7_extra);
@@ -595,10 +615,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   e->apk_words = a7_extra;
   e->part = ws_take(e, (size_t)PART_SLABS * LEAF_PART_WORDS);
   std::vector<word *> Al(L + 1, nullptr), Bl(L + 1, nullptr), Pl(L + 1, nullptr);
-  if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, ipow7(L))) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
+  if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, leaves)) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
   for (int d = 1; d <= L; ++d) {
     if (!materialised(d)) continue;
-    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = ipow7(d);
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : ipow7(d);
     if (!(prepack && d == L)) Al[d] = ws_take(e, (size_t)cnt * md * wl);
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
@@ -615,7 +635,12 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
     const int rot = leaf_kind.gen == 4 ? 1 : 0;  // the leaf's pre-rotated index bytes (pack mode)
-    if (step == 4) {  // four levels in one pass each way: the top one formed on the fly (aux_kernels.hip)
+    if (step == 4 && scheme) {  // two applications of the 4 x 4 x 4 scheme in one pass each way (scheme_passes.hip)
+      const double rr = (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank();
+      HIPTRY(gf2_launch_scheme_down_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_scheme_down(st, 1, pb, pbs, pbbs, Bl[d + 4], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (256.0 + rr) * ((double)cm * (cl / 64) + (double)cl * (cn / 64));
+    } else if (step == 4) {  // four levels in one pass each way: the top one formed on the fly (aux_kernels.hip)
       if (prepack) HIPTRY(gf2_launch_winograd_down4_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down4(st, 0, pa, pas, pabs, Al[d + 4], cnt, cm, cl / 64));
       HIPTRY(gf2_launch_winograd_down4(st, 1, pb, pbs, pbbs, Bl[d + 4], cnt, cl, cn / 64));
@@ -641,7 +666,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // launch (same sources, same destinations, same values; the up pass reads half-written products and its output is overwritten
   // by the real one) -- what the leaf loses to HBM-bound work beside it bounds what a pipelined schedule could win
   static const int exp_overlap = getenv("M4RI_AMD_OVERLAP_EXP") ? atoi(getenv("M4RI_AMD_OVERLAP_EXP")) : 0;
-  const bool overlap_now = exp_overlap && L == 4 && fuse == 4 && prepack;
+  const bool overlap_now = exp_overlap && L == 4 && fuse == 4 && prepack && !scheme;
   if (overlap_now) {
     if (!e->aux_stream) { HIPTRY(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking)); HIPTRY(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPTRY(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming)); }
     HIPTRY(hipEventRecord(e->aux_ev[0], st));
@@ -654,7 +679,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   }
   // all 7^L leaf products in one launch
   {
-    const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = ipow7(L);
+    const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = leaves;
     if (int rc = launch_leaf(e, st, Pl[L], ln / 64, lm * (ln / 64), Al[L], ll / 64, lm * (ll / 64), Bl[L], ln / 64,
                              ll * (ln / 64), lm, ll, ln, cnt, false, 0, prepack))
       return rc;
@@ -670,7 +695,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
     const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
-    if (step == 4) {
+    if (step == 4 && scheme) {
+      const double rr = (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank();
+      HIPTRY(gf2_launch_scheme_up(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (rr + (acc ? 512.0 : 256.0));
+    } else if (step == 4) {
       HIPTRY(gf2_launch_winograd_up4(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (2401.0 + 512.0 + (acc ? 0.0 : 256.0));  // products in, every word read + written once, the clear
     } else if (step == 3 && acc && acc_tmp) {

@@ -162,3 +162,25 @@ def test_pair_table_of_the_multi_device_path():
     # no access anywhere: every pair of different devices
     t = m4ri_amd.multi_pair_table([0, 1, 2], [[1, 0, 0], [0, 1, 0], [0, 0, 1]])
     assert t == [[0, 1, 1], [1, 0, 1], [1, 1, 0]]
+
+
+def test_the_4x4x4_scheme_is_a_scheme():
+    """m4ri_amd/csrc/scheme444.h (generated by tools/make_scheme_header.py from what tools/flipgraph_444.c found): R rank-one tensors (u, v, w)
+    over GF(2) that sum to the tensor of the 4 x 4 x 4 matrix product -- checked here against the definition, entry by entry, because every
+    product of four fused Strassen levels goes through this table (scheme_passes.hip).  R <= 49 (Strassen applied twice)."""
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "m4ri_amd", "csrc", "scheme444.h")).read()
+    R = int(re.search(r"#define SCHEME444_R (\d+)", text).group(1))
+    tabs = {name: [int(x, 16) for x in re.findall(r"0x([0-9a-f]{4})", re.search(rf"SCHEME444_{name}\[SCHEME444_R\] = \{{([^}}]*)\}}", text).group(1))] for name in "UVW"}
+    assert all(len(t) == R for t in tabs.values()) and 40 <= R <= 49 and all(x > 0 for t in tabs.values() for x in t)
+    U, V, W = (np.array(tabs[k], dtype=np.uint32) for k in "UVW")
+    bit = lambda a, k: ((a >> np.uint32(k)) & np.uint32(1)).astype(np.uint8)   # noqa: E731
+    for i in range(4):
+        for j in range(4):
+            for j2 in range(4):
+                for k in range(4):
+                    for i2 in range(4):
+                        for k2 in range(4):
+                            got = int((bit(U, 4 * i + j) & bit(V, 4 * j2 + k) & bit(W, 4 * i2 + k2)).sum() & 1)
+                            assert got == int(i == i2 and j == j2 and k == k2), (i, j, j2, k, i2, k2)

@@ -1,0 +1,256 @@
+// tools/flipgraph_444.c -- search for a bilinear scheme of rank < 49 for the 4 x 4 x 4 matrix product over GF(2) by a random walk
+// in the flip graph of matrix-multiplication schemes (the method of Kauers & Moosbauer, "Flip graphs for matrix multiplication", 2022;
+// that rank 47 exists over GF(2) was first found by AlphaTensor, Fawzi et al., Nature 2022).  Own code; developer tool: it produced the
+// coefficient table in m4ri_amd/csrc/scheme47.h, which tests/test_host_logic.py re-verifies against the definition of the product.
+//
+//   A scheme is a list of rank-one tensors (a, b, c), a over the 16 entries of A, b over those of B, c over those of C (16-bit masks), with
+//       sum_r a_r[i,j] b_r[j',k] c_r[i',k'] = [i = i'][j = j'][k = k']        (mod 2).
+//   flip:    two tensors that share a factor, (a, b, c) + (a, b', c') = (a, b + b', c) + (a, b', c + c')   (and the same with the roles permuted)
+//   reduce:  two tensors that share TWO factors merge: (a, b, c) + (a, b, c') = (a, b, c + c'); a zero factor deletes its tensor.
+// The walk starts from Strassen's algorithm applied twice (rank 49), flips at random, reduces whenever it can, restarts from the best
+// scheme after a path limit, and prints every scheme that beats the best rank so far.
+//
+//   gcc -O2 -pthread tools/flipgraph_444.c -o build/flipgraph_444
+//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit]
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define MAXR 64
+typedef struct { uint16_t f[3]; } Tri;
+typedef struct { Tri t[MAXR]; int r; } Scheme;
+
+static uint64_t rng_next(uint64_t *s) {  // splitmix64
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// entry (i, j) of a 4 x 4 matrix <-> bit 4 i + j
+static int verify(const Scheme *s) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int j2 = 0; j2 < 4; ++j2) for (int k = 0; k < 4; ++k)
+    for (int i2 = 0; i2 < 4; ++i2) for (int k2 = 0; k2 < 4; ++k2) {
+      int v = 0;
+      for (int r = 0; r < s->r; ++r)
+        v ^= ((s->t[r].f[0] >> (4 * i + j)) & 1) & ((s->t[r].f[1] >> (4 * j2 + k)) & 1) & ((s->t[r].f[2] >> (4 * i2 + k2)) & 1);
+      if (v != ((i == i2) && (j == j2) && (k == k2))) return 0;
+    }
+  return 1;
+}
+
+static void strassen_squared(Scheme *s) {
+  // Strassen over GF(2), entries of a 2 x 2 matrix as bits 2 i + j:  M1 = (A11+A22)(B11+B22) -> C11, C22;  M2 = (A21+A22) B11 -> C21, C22;
+  // M3 = A11 (B12+B22) -> C12, C22;  M4 = A22 (B21+B11) -> C11, C21;  M5 = (A11+A12) B22 -> C11, C12;  M6 = (A21+A11)(B11+B12) -> C22;
+  // M7 = (A12+A22)(B21+B22) -> C11
+  static const uint8_t S[7][3] = {{0x9, 0x9, 0x9}, {0xC, 0x1, 0xC}, {0x1, 0xA, 0xA}, {0x8, 0x5, 0x5}, {0x3, 0x8, 0x3}, {0x5, 0x3, 0x8}, {0xA, 0xC, 0x1}};
+  s->r = 0;
+  for (int u = 0; u < 7; ++u)
+    for (int v = 0; v < 7; ++v) {
+      Tri t;
+      for (int f = 0; f < 3; ++f) {
+        uint16_t m = 0;
+        for (int e1 = 0; e1 < 4; ++e1)
+          for (int e2 = 0; e2 < 4; ++e2)
+            if (((S[u][f] >> e1) & 1) && ((S[v][f] >> e2) & 1)) {
+              const int i = 2 * (e1 >> 1) + (e2 >> 1), j = 2 * (e1 & 1) + (e2 & 1);
+              m |= (uint16_t)1 << (4 * i + j);
+            }
+        t.f[f] = m;
+      }
+      s->t[s->r++] = t;
+    }
+}
+
+// remove tensors with a zero factor and merge tensors that share two factors, until nothing changes
+static void reduce(Scheme *s) {
+  for (int again = 1; again;) {
+    again = 0;
+    for (int i = 0; i < s->r; ++i)
+      if (!s->t[i].f[0] || !s->t[i].f[1] || !s->t[i].f[2]) { s->t[i] = s->t[--s->r]; again = 1; --i; }
+    for (int i = 0; i < s->r && !again; ++i)
+      for (int j = i + 1; j < s->r && !again; ++j)
+        for (int f = 0; f < 3; ++f) {
+          const int g = (f + 1) % 3, h = (f + 2) % 3;
+          if (s->t[i].f[g] == s->t[j].f[g] && s->t[i].f[h] == s->t[j].f[h]) {
+            s->t[i].f[f] ^= s->t[j].f[f];
+            s->t[j] = s->t[--s->r];
+            again = 1;
+            break;
+          }
+        }
+  }
+}
+
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static Scheme g_best;
+static volatile int g_stop = 0;
+static int g_target = 47;
+static double g_t0;
+static volatile uint64_t g_steps = 0;
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static void report(const Scheme *s, int thread, uint64_t steps) {
+  pthread_mutex_lock(&g_mu);
+  if (s->r < g_best.r && verify(s)) {
+    g_best = *s;
+    printf("# rank %d after %.1f s (thread %d, %llu flips)\n", s->r, now() - g_t0, thread, (unsigned long long)steps);
+    for (int r = 0; r < s->r; ++r) printf("{0x%04x, 0x%04x, 0x%04x},\n", s->t[r].f[0], s->t[r].f[1], s->t[r].f[2]);
+    fflush(stdout);
+    if (s->r <= g_target) g_stop = 1;
+  }
+  pthread_mutex_unlock(&g_mu);
+}
+
+static Scheme g_start;
+static uint64_t g_path_limit = 20000000;
+
+// one flip at random + the reductions it makes possible; returns 1 when something was flipped
+static int step(Scheme *cur, uint64_t *rng) {
+  const int i = (int)(rng_next(rng) % (uint64_t)cur->r), f = (int)(rng_next(rng) % 3);
+  int cand[MAXR], nc = 0;
+  for (int j = 0; j < cur->r; ++j)
+    if (j != i && cur->t[j].f[f] == cur->t[i].f[f]) cand[nc++] = j;
+  if (!nc) return 0;
+  const int j = cand[rng_next(rng) % (uint64_t)nc];
+  // (a, b, c) + (a, b', c') -> (a, b + b', c) + (a, b', c + c'), the two other factors in a random order
+  const int g = (rng_next(rng) & 1) ? (f + 1) % 3 : (f + 2) % 3, h = 3 - f - g;
+  cur->t[i].f[g] ^= cur->t[j].f[g];
+  cur->t[j].f[h] ^= cur->t[i].f[h];
+  int hit = !cur->t[i].f[g] || !cur->t[j].f[h];
+  for (int k = 0; k < cur->r && !hit; ++k) {   // did the flip create a pair that shares two factors?  (only pairs with i or j can be new)
+    if (k != i && (cur->t[k].f[0] == cur->t[i].f[0]) + (cur->t[k].f[1] == cur->t[i].f[1]) + (cur->t[k].f[2] == cur->t[i].f[2]) >= 2) hit = 1;
+    if (k != j && (cur->t[k].f[0] == cur->t[j].f[0]) + (cur->t[k].f[1] == cur->t[j].f[1]) + (cur->t[k].f[2] == cur->t[j].f[2]) >= 2) hit = 1;
+  }
+  if (hit) reduce(cur);
+  return 1;
+}
+
+// Pools by rank (the search strategy of the flip-graph paper): walks start from a random member of the pool of the working level L --
+// the lowest rank whose pool is full -- and run until they lose a rank (the reduced scheme joins the pool of its rank) or reach the path
+// limit; a quarter of the walks start from the best rank reached so far, however few schemes it has.  Breadth at every level is what
+// gets below the plateaus a single greedy path sticks on.
+#define POOL 256
+static Scheme g_pool[65][POOL];
+static int g_count[65];
+
+static int working_level(void) {   // the lowest rank whose pool is full; before any is (the start, a resumed checkpoint): the highest rank that has schemes
+  int lvl = 0;
+  for (int r = 64; r >= 1; --r)
+    if (g_count[r] >= POOL) lvl = r;
+  for (int r = 64; r >= 1 && !lvl; --r)
+    if (g_count[r]) lvl = r;
+  return lvl;
+}
+
+static void *walk(void *arg) {
+  const int id = (int)(intptr_t)arg;
+  uint64_t rng = 0x1234567ull * (uint64_t)(id + 1) + (uint64_t)time(NULL);
+  uint64_t steps = 0;
+  const uint64_t path_limit = g_path_limit;
+  while (!g_stop) {
+    Scheme cur;
+    pthread_mutex_lock(&g_mu);
+    int lvl = working_level();
+    if ((rng_next(&rng) & 3) == 0) lvl = g_best.r;
+    cur = g_pool[lvl][rng_next(&rng) % (uint64_t)(g_count[lvl] < POOL ? g_count[lvl] : POOL)];
+    pthread_mutex_unlock(&g_mu);
+    const int start_rank = cur.r;
+    uint64_t p = 0;
+    for (; p < path_limit && !g_stop && cur.r >= start_rank; ++p) step(&cur, &rng);
+    steps += p;
+    __sync_fetch_and_add(&g_steps, p);
+    if (cur.r < start_rank) {
+      if (cur.r < g_best.r) report(&cur, id, steps);
+      pthread_mutex_lock(&g_mu);
+      const int c = g_count[cur.r];
+      if (c < POOL) g_pool[cur.r][c] = cur; else g_pool[cur.r][rng_next(&rng) % POOL] = cur;
+      g_count[cur.r] = c + 1;
+      pthread_mutex_unlock(&g_mu);
+    }
+  }
+  return NULL;
+}
+
+static void standard(Scheme *s) {  // the definition: a_ij b_jk -> c_ik, rank 64
+  s->r = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int k = 0; k < 4; ++k) {
+    Tri t = {{(uint16_t)(1u << (4 * i + j)), (uint16_t)(1u << (4 * j + k)), (uint16_t)(1u << (4 * i + k))}};
+    s->t[s->r++] = t;
+  }
+}
+
+static void checkpoint(const char *path) {   // the pools of the three lowest ranks reached, one scheme per line (rank, then its tensors)
+  if (!path) return;
+  char tmp[512];
+  snprintf(tmp, sizeof tmp, "%s.tmp", path);
+  pthread_mutex_lock(&g_mu);
+  FILE *fo = fopen(tmp, "w");
+  if (fo) {
+    for (int r = g_best.r; r <= g_best.r + 2 && r <= 64; ++r)
+      for (int q = 0; q < (g_count[r] < POOL ? g_count[r] : POOL); ++q) {
+        fprintf(fo, "%d", r);
+        for (int t = 0; t < r; ++t) fprintf(fo, " %x %x %x", g_pool[r][q].t[t].f[0], g_pool[r][q].t[t].f[1], g_pool[r][q].t[t].f[2]);
+        fprintf(fo, "\n");
+      }
+    fclose(fo);
+    rename(tmp, path);
+  }
+  pthread_mutex_unlock(&g_mu);
+}
+
+int main(int argc, char **argv) {
+  const int threads = argc > 1 ? atoi(argv[1]) : 8;
+  const double seconds = argc > 2 ? atof(argv[2]) : 600.0;
+  g_target = argc > 3 ? atoi(argv[3]) : 47;
+  if (argc > 7) g_path_limit = strtoull(argv[7], NULL, 10);
+  if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
+  memset(g_count, 0, sizeof g_count);
+  if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
+  g_start = g_best;
+  g_pool[g_best.r][0] = g_best;
+  g_count[g_best.r] = 1;
+  if (argc > 6) {   // resume from a checkpoint
+    FILE *fi = fopen(argv[6], "r");
+    int r;
+    while (fi && fscanf(fi, "%d", &r) == 1 && r >= 1 && r <= 64) {
+      Scheme x;
+      x.r = r;
+      for (int t = 0; t < r; ++t) { unsigned a, b, c; if (fscanf(fi, "%x %x %x", &a, &b, &c) != 3) { r = 0; break; } x.t[t].f[0] = (uint16_t)a; x.t[t].f[1] = (uint16_t)b; x.t[t].f[2] = (uint16_t)c; }
+      if (!r || !verify(&x)) continue;
+      if (g_count[r] < POOL) g_pool[r][g_count[r]++] = x;
+      if (r < g_best.r) g_best = x;
+    }
+    if (fi) fclose(fi);
+    for (int r2 = g_best.r; r2 <= 64; ++r2) if (g_count[r2] && g_count[r2] < POOL && r2 > g_best.r + 2) g_count[r2] = 0;
+    printf("# resumed: best rank %d, pool of it %d\n", g_best.r, g_count[g_best.r]);
+  }
+  printf("# start: %s, rank %d, verified\n", (argc > 4 && argv[4][0] == 's') ? "Strassen squared" : "the standard algorithm", g_best.r);
+  fflush(stdout);
+  g_t0 = now();
+  pthread_t th[256];
+  for (int i = 0; i < threads && i < 256; ++i) pthread_create(&th[i], NULL, walk, (void *)(intptr_t)i);
+  for (double last = now(); !g_stop && now() - g_t0 < seconds;) {
+    struct timespec ts = {0, 200000000};
+    nanosleep(&ts, NULL);
+    if (now() - last > 120.0) {   // a checkpoint every two minutes, and where the pools stand
+      last = now();
+      checkpoint(argc > 5 ? argv[5] : NULL);
+      printf("# %.0f s: best %d, pools", now() - g_t0, g_best.r);
+      for (int r = g_best.r + 3; r >= g_best.r; --r) if (r <= 64) printf(" %d:%d", r, g_count[r]);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
+  g_stop = 1;
+  for (int i = 0; i < threads && i < 256; ++i) pthread_join(th[i], NULL);
+  checkpoint(argc > 5 ? argv[5] : NULL);
+  printf("# best rank %d, %.3g flips in all; pool sizes:", g_best.r, (double)g_steps);
+  for (int r = 64; r >= 40; --r) if (g_count[r]) printf(" %d:%d", r, g_count[r]);
+  printf("\n");
+  return g_best.r <= g_target ? 0 : 1;
+}
