@@ -870,6 +870,8 @@ def main():
                 "bytes_compulsory_per_rank": float(bytes_sched(pm, pl, pn, 0)) * nprod_rank,
                 "achieved": bs / (ms_per_step * 1e-3) / 1e9, "frac": frac,
                 "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
+                # four fused levels = two applications of a rank-R 4 x 4 x 4 scheme (R^2 leaves, not 7^4); bytes_sched stays the REFERENCE's schedule
+                "leaf_products_run": int(stats.leaf_products), "leaf_products_declared": 7 ** int(stats.levels) * nprod_rank,
                 "pass_pattern_peak": ceiling,
                 "north_star_60pct": bool(frac >= 0.6),
                 "note": "frac = unfused reference schedule bytes (15 quadrant adds/level, SURVEY.md 8(d)) of the rank's sub-product(s) over the measured step "

@@ -200,6 +200,60 @@ __global__ __launch_bounds__(SP_THREADS) void scheme_up_kernel(
   }
 }
 
+// The same pass with 32 positions per workgroup (64 KiB of LDS, TWO workgroups per CU: one's clear and write-out under the other's loads);
+// the two half-waves of a wave fold different top-level products, so the scatter into the coarse blocks is predicated per lane.
+template <bool ACC>
+__global__ __launch_bounds__(PK_THREADS) void scheme_up32_kernel(
+    const word *__restrict__ prod, int64_t p_bs, word *anc, int64_t o_stride, int64_t o_bs, int64_t crows, int64_t cw) {  // cw % 32 == 0
+  __shared__ unsigned long long g[256 * PK_POS];
+  const int tid = threadIdx.x, pp = tid & 31, hw = tid >> 5;
+  for (int k = tid; k < 256 * PK_POS; k += PK_THREADS) g[k] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * PK_POS + pp, pi = blockIdx.y;
+  const int64_t r = i / cw, w = i - r * cw;
+  const word *q0 = prod + pi * (int64_t)(R444 * R444) * p_bs + r * cw + w;
+  for (int r0 = 0; r0 < R444; r0 += 8) {
+    const int r1 = r0 + hw;
+    if (r1 >= R444) continue;   // (the last round's idle half-wave; no barrier inside the loop)
+    const word *q = q0 + (int64_t)r1 * R444 * p_bs;
+    word y[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) y[f] = 0;
+#pragma unroll
+    for (int g0 = 0; g0 < R444; g0 += 8) {
+      word v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (g0 + k < R444) v[k] = q[(int64_t)(g0 + k) * p_bs];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (g0 + k < R444) {
+          const uint16_t m = SCHEME444_W[g0 + k];
+#pragma unroll
+          for (int f = 0; f < 16; ++f)
+            if ((m >> f) & 1) y[f] ^= v[k];
+        }
+    }
+    const uint32_t mine = (uint32_t)c_W[r1];
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+      if (!((mine >> c) & 1)) continue;   // per half-wave: the wave's other half may take the branch
+      const int i1 = c >> 2, k1 = c & 3;
+#pragma unroll
+      for (int f = 0; f < 16; ++f) atomicXor(&g[((4 * i1 + (f >> 2)) * 16 + 4 * k1 + (f & 3)) * PK_POS + pp], (unsigned long long)y[f]);
+    }
+  }
+  __syncthreads();
+  word *o = anc + pi * o_bs + r * o_stride + w;
+#pragma unroll 4
+  for (int k = 0; k < 32; ++k) {
+    const int blk = k * 8 + hw;
+    word *oo      = o + (int64_t)(blk >> 4) * crows * o_stride + (int64_t)(blk & 15) * cw;
+    const word v  = g[blk * PK_POS + pp];
+    *oo           = ACC ? (*oo ^ v) : v;
+  }
+}
+
 bool g_tables_up[16] = {};
 
 hipError_t upload_tables() {  // the outer application's masks, once per device
@@ -261,6 +315,13 @@ extern "C" hipError_t gf2_launch_scheme_up(hipStream_t s, int acc, const word *p
   if (nparents * p_bs == 0) return hipSuccess;
   if (cw % SP_POS != 0 || nparents > 65535) return hipErrorInvalidValue;
   if (hipError_t e = upload_tables()) return e;
+  static const bool wide = getenv("M4RI_AMD_SCHEME_UP") && atoi(getenv("M4RI_AMD_SCHEME_UP")) == 64;   // developer: the 64-position form
+  if (!wide) {
+    const dim3 g32((unsigned)(p_bs / PK_POS), (unsigned)nparents);
+    if (acc) hipLaunchKernelGGL((scheme_up32_kernel<true>), g32, dim3(PK_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw);
+    else hipLaunchKernelGGL((scheme_up32_kernel<false>), g32, dim3(PK_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw);
+    return hipGetLastError();
+  }
   const dim3 g((unsigned)(p_bs / SP_POS), (unsigned)nparents);
   if (acc) hipLaunchKernelGGL((scheme_up_kernel<true>), g, dim3(SP_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw);
   else hipLaunchKernelGGL((scheme_up_kernel<false>), g, dim3(SP_THREADS), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw);

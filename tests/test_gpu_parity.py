@@ -411,6 +411,51 @@ def test_four_level_fused_passes(oracle, m, l, n, cutoff, add, strided):
         m4ri_amd.set_max_fuse(old)
 
 
+def _scheme_rank():
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "m4ri_amd", "csrc", "scheme444.h")).read()
+    return int(re.search(r"#define SCHEME444_R (\d+)", text).group(1))
+
+
+@pytest.mark.parametrize("m,l,n,add,strided", [(4096, 16384, 65536, False, False),     # leaves 256 x 1024 x 4096: the smallest the scheme passes take
+                                               (8192, 32768, 65536, True, True),       # accumulating into a wider parent; 32-word rows of A
+                                               (4096 + 512, 16384, 65536, False, False)])   # leaves of 288 rows: nine row groups of 32, partly filled tiles
+def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, add, strided):
+    """Four fused levels as two applications of the rank-R scheme for the 4 x 4 x 4 block product (scheme_passes.hip, scheme444.h; R^2 leaf
+    products per ancestor instead of 7^4) against the same product through three-level Winograd passes (max_fuse 3: another kernel family,
+    another number of leaves) -- identical bits -- and against the oracle through Freivalds' identity.  The stats say the scheme ran."""
+    hA, hB, hC = Mzd.random(m, l, 91), Mzd.random(l, n, 92), Mzd.random(m, n, 93)
+    pad = 4 if strided else 0
+    wa, wn = hA.rowstride + pad, hB.rowstride + pad
+
+    def dev(h, stride):
+        t = torch.full((h.nrows, stride), -1, dtype=torch.int64, device="cuda")
+        t[:, :h.rowstride] = torch.from_numpy(h.rows().view(np.int64).copy()).cuda()
+        return t
+    A, B, C0 = dev(hA, wa), dev(hB, wn), dev(hC, wn)
+    R = _scheme_rank()
+    out = {}
+    old = m4ri_amd.set_max_fuse(0)
+    try:
+        for fuse in (4, 3):
+            m4ri_amd.set_max_fuse(fuse)
+            C = C0.clone()
+            m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wa, B.data_ptr(), wn, m, l, n, add=add, cutoff=256)
+            st = m4ri_amd.get_stats()
+            assert st.levels == 4 and (st.leaf_m, st.leaf_l, st.leaf_n) == (m // 16, l // 16, n // 16)
+            assert st.leaf_products == (R * R if fuse == 4 else 2401), (fuse, st.leaf_products)
+            out[fuse] = C
+            assert bool((C[:, hC.rowstride:] == -1).all()), f"max_fuse={fuse}: words of the parent outside C were written"
+    finally:
+        m4ri_amd.set_max_fuse(old)
+    assert torch.equal(out[4], out[3])
+    got = Mzd(m, n)
+    got.rows()[:, :] = out[4][:, :hC.rowstride].cpu().numpy().view(np.uint64)
+    if add:   # C0 ^ A*B: check the product part
+        got.rows()[:, :] ^= hC.rows()
+    assert freivalds(oracle, hA, hB, got, m, l, n, 79)
+
+
 @pytest.mark.parametrize("m,l,n,add", [
     (33000, 33000, 33000, False),              # 32768 rows at three levels + 232 rows unsplit; 33000 = 64 * 512 + 232: strips on the inner dimension and the columns
     (20480, 20480, 20480, True),               # 16384 rows at two levels + 4096 rows unsplit, accumulating onto C

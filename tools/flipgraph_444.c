@@ -11,7 +11,7 @@
 // scheme after a path limit, and prints every scheme that beats the best rank so far.
 //
 //   gcc -O2 -pthread tools/flipgraph_444.c -o build/flipgraph_444
-//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit]
+//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit] [1 = with plus transitions]
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -108,6 +108,7 @@ static void report(const Scheme *s, int thread, uint64_t steps) {
 
 static Scheme g_start;
 static uint64_t g_path_limit = 20000000;
+static int g_plus = 0;
 
 // one flip at random + the reductions it makes possible; returns 1 when something was flipped
 static int step(Scheme *cur, uint64_t *rng) {
@@ -160,6 +161,21 @@ static void *walk(void *arg) {
     cur = g_pool[lvl][rng_next(&rng) % (uint64_t)(g_count[lvl] < POOL ? g_count[lvl] : POOL)];
     pthread_mutex_unlock(&g_mu);
     const int start_rank = cur.r;
+    // a third of the walks begin with a "plus transition" (Kauers & Moosbauer 2023): two tensors become three,
+    //   (a, b, c) + (a', b', c') = (a + a', b, c) + (a', b + b', c) + (a', b', c + c'),
+    // one rank up and into a part of the graph plain flips do not reach; the walk still has to come out BELOW the rank it started from
+    if (g_plus && cur.r < MAXR && cur.r >= 2 && rng_next(&rng) % 3 == 0) {
+      const int i = (int)(rng_next(&rng) % (uint64_t)cur.r);
+      int j = (int)(rng_next(&rng) % (uint64_t)(cur.r - 1));
+      if (j >= i) ++j;
+      const Tri a = cur.t[i], b = cur.t[j];
+      if (a.f[0] != b.f[0] && a.f[1] != b.f[1] && a.f[2] != b.f[2]) {
+        cur.t[i].f[0] = a.f[0] ^ b.f[0];
+        cur.t[j].f[2] = a.f[2] ^ b.f[2];
+        Tri n = {{b.f[0], (uint16_t)(a.f[1] ^ b.f[1]), a.f[2]}};
+        cur.t[cur.r++] = n;
+      }
+    }
     uint64_t p = 0;
     for (; p < path_limit && !g_stop && cur.r >= start_rank; ++p) step(&cur, &rng);
     steps += p;
@@ -208,6 +224,7 @@ int main(int argc, char **argv) {
   const double seconds = argc > 2 ? atof(argv[2]) : 600.0;
   g_target = argc > 3 ? atoi(argv[3]) : 47;
   if (argc > 7) g_path_limit = strtoull(argv[7], NULL, 10);
+  if (argc > 8) g_plus = atoi(argv[8]);
   if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
   memset(g_count, 0, sizeof g_count);
   if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
