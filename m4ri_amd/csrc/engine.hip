@@ -46,15 +46,17 @@ hipError_t gf2_launch_winograd_up4(hipStream_t s, int acc, const word *prod, wor
 hipError_t gf2_launch_winograd_down4_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4,
                                           int64_t nparents, int64_t crows, int64_t cw, int rot);
 hipError_t gf2_launch_m4rm8q(hipStream_t stream, LeafArgs a, word *a4_ws);
-// scheme_passes.hip: four levels as two applications of a rank-R scheme for the 4 x 4 x 4 block product (R = 47: 2209 leaves, not 2401)
+// scheme_passes.hip: 2, 3 or 4 fused levels whose last two are one application of a rank-R scheme for the 4 x 4 x 4 block product
+// (R < 49: R, 7 R or R^2 leaves per ancestor instead of 49, 343, 2401)
 int gf2_scheme444_rank(void);
-int gf2_scheme444_ok(int64_t a_rows, int64_t a_cw, int64_t b_rows, int64_t b_cw);
-hipError_t gf2_launch_scheme_down(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *child, int64_t nparents,
+int64_t gf2_scheme444_leaves(int levels);
+int gf2_scheme444_ok(int levels, int64_t a_rows, int64_t a_cw, int64_t b_rows, int64_t b_cw);
+hipError_t gf2_launch_scheme_down(hipStream_t s, int levels, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *child, int64_t nparents,
                                   int64_t crows, int64_t cw);
-hipError_t gf2_launch_scheme_down_pack(hipStream_t s, const word *anc, int64_t p_stride, int64_t p_bs, word *a4, int64_t nparents, int64_t crows,
-                                       int64_t cw);
-hipError_t gf2_launch_scheme_up(hipStream_t s, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs, int64_t nparents, int64_t crows,
-                                int64_t cw);
+hipError_t gf2_launch_scheme_down_pack(hipStream_t s, int levels, const word *anc, int64_t p_stride, int64_t p_bs, word *a4, int64_t nparents,
+                                       int64_t crows, int64_t cw);
+hipError_t gf2_launch_scheme_up(hipStream_t s, int levels, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs, int64_t nparents,
+                                int64_t crows, int64_t cw);
 int gf2_m4rm8q_effective_ksplit(int64_t l, int ksplit);
 int64_t gf2_m4rm8_a4_words(int64_t m, int64_t l, int64_t batch);
 hipError_t gf2_launch_winograd_down(hipStream_t s, int bside, const word *parent, int64_t p_stride,
@@ -428,6 +430,7 @@ int reserve_apk(Engine *e, size_t words) {
 }
 
 // ---- level planning ----------------------------------------------------------------------------
+int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strassen.c:39
 
 // ---- the engine's own depth: a time model -------------------------------------------------------------------------------
@@ -465,9 +468,10 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   };
   double p7 = 1;
   for (int d = 0; d < L; ++d) p7 *= 7;
-  // four fused levels run as two applications of the rank-R 4 x 4 x 4 scheme where the leaves allow it: R^2 products instead of 7^4
-  const bool scheme = L >= 4 && g_max_fuse >= 4 && mm >= 192 && gf2_scheme444_ok(mm, words_of(ll), ll, words_of(nn)) != 0;
-  const double srat = scheme ? (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank() / 2401.0 : 1.0;
+  // the fused bottom levels run through the rank-R 4 x 4 x 4 scheme where the leaves allow it: R, 7 R or R^2 products instead of 7^2, 7^3, 7^4
+  const int mfuse = L < g_max_fuse ? L : g_max_fuse;
+  const bool scheme = mfuse >= 2 && mm >= 192 && gf2_scheme444_ok(mfuse, mm, words_of(ll), ll, words_of(nn)) != 0;
+  const double srat = scheme ? (double)gf2_scheme444_leaves(mfuse) / (double)ipow7(mfuse) : 1.0;
   p7 *= srat;
   double t = leaf(mm, ll, nn, p7);
   // passes over the even block
@@ -561,7 +565,6 @@ int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
   return L;
 }
 
-int64_t ipow7(int d) { int64_t r = 1; while (d-- > 0) r *= 7; return r; }
 
 // breadth-first Strassen-Winograd on the even block: C (m x n) (+)= A (m x l) * B (l x n), with
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
@@ -579,9 +582,9 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // ancestor of the fused pass instead of 7^4, packed A written by the pass itself.  Needs generation 4's packed A and leaf shapes the
   // scheme kernels take; everything else keeps the Winograd passes.
   const int64_t leaf_m = m >> L, leaf_l = l >> L, leaf_n = n >> L;
-  const bool scheme = fuse == 4 && leaf_kind.gen == 4 && gf2_scheme444_ok(leaf_m, leaf_l / 64, leaf_l, leaf_n / 64) != 0 &&
+  const bool scheme = fuse >= 2 && leaf_kind.gen == 4 && gf2_scheme444_ok(fuse, leaf_m, leaf_l / 64, leaf_l, leaf_n / 64) != 0 &&
                       (uint64_t)gf2_m4rm8_a4_words(leaf_m, leaf_l, 1) * 8 < (1ull << 32);
-  const int64_t leaves = scheme ? ipow7(L - 4) * (int64_t)gf2_scheme444_rank() * (int64_t)gf2_scheme444_rank() : ipow7(L);  // products of the leaf launch
+  const int64_t leaves = scheme ? ipow7(L - fuse) * gf2_scheme444_leaves(fuse) : ipow7(L);  // products of the leaf launch
   bool prepack = scheme;
   if (!scheme && fuse >= 2 && leaf_kind.gen == 4) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
@@ -603,7 +606,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   }
   // C += A*B through a three-level up pass: the pass writes a temporary and one XOR pass folds it into
   // C (the accumulating three-level kernel needs > 256 registers per lane and runs at a quarter of the rate)
-  const bool acc_via_tmp = add && fuse == 3 && L == 3;
+  const bool acc_via_tmp = add && fuse == 3 && L == 3 && !scheme;
   if (acc_via_tmp) need += pad((size_t)m * (n / 64));
   {
     const size_t a7_bfs = packed_a_words(m >> L, l >> L, leaves);
@@ -635,11 +638,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const word *pb = d == 0 ? B.p : Bl[d];
     const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
     const int rot = leaf_kind.gen == 4 ? 1 : 0;  // the leaf's pre-rotated index bytes (pack mode)
-    if (step == 4 && scheme) {  // two applications of the 4 x 4 x 4 scheme in one pass each way (scheme_passes.hip)
-      const double rr = (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank();
-      HIPTRY(gf2_launch_scheme_down_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64));
-      HIPTRY(gf2_launch_scheme_down(st, 1, pb, pbs, pbbs, Bl[d + 4], cnt, cl, cn / 64));
-      e->stats.aux_bytes += 8.0 * cnt * (256.0 + rr) * ((double)cm * (cl / 64) + (double)cl * (cn / 64));
+    if (scheme && step == fuse && step >= 2) {  // the fused bottom levels through the 4 x 4 x 4 scheme, one pass each way (scheme_passes.hip)
+      const double rr = (double)gf2_scheme444_leaves(step), blocks = (double)(1 << (2 * step));
+      HIPTRY(gf2_launch_scheme_down_pack(st, step, pa, pas, pabs, e->apk, cnt, cm, cl / 64));
+      HIPTRY(gf2_launch_scheme_down(st, step, 1, pb, pbs, pbbs, Bl[d + step], cnt, cl, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (blocks + rr) * ((double)cm * (cl / 64) + (double)cl * (cn / 64));
     } else if (step == 4) {  // four levels in one pass each way: the top one formed on the fly (aux_kernels.hip)
       if (prepack) HIPTRY(gf2_launch_winograd_down4_pack(st, pa, pas, pabs, e->apk, cnt, cm, cl / 64, rot));
       else HIPTRY(gf2_launch_winograd_down4(st, 0, pa, pas, pabs, Al[d + 4], cnt, cm, cl / 64));
@@ -695,10 +698,10 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
     const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
-    if (step == 4 && scheme) {
-      const double rr = (double)gf2_scheme444_rank() * (double)gf2_scheme444_rank();
-      HIPTRY(gf2_launch_scheme_up(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
-      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (rr + (acc ? 512.0 : 256.0));
+    if (scheme && step == fuse && step >= 2) {
+      const double rr = (double)gf2_scheme444_leaves(step), blocks = (double)(1 << (2 * step));
+      HIPTRY(gf2_launch_scheme_up(st, step, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
+      e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (rr + (acc ? 2.0 : 1.0) * blocks);
     } else if (step == 4) {
       HIPTRY(gf2_launch_winograd_up4(st, acc, Pl[d], out, ostr, obs, cnt, cm, cn / 64));
       e->stats.aux_bytes += 8.0 * cnt * (double)cm * (cn / 64) * (2401.0 + 512.0 + (acc ? 0.0 : 256.0));  // products in, every word read + written once, the clear

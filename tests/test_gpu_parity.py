@@ -417,13 +417,20 @@ def _scheme_rank():
     return int(re.search(r"#define SCHEME444_R (\d+)", text).group(1))
 
 
-@pytest.mark.parametrize("m,l,n,add,strided", [(4096, 16384, 65536, False, False),     # leaves 256 x 1024 x 4096: the smallest the scheme passes take
-                                               (8192, 32768, 65536, True, True),       # accumulating into a wider parent; 32-word rows of A
-                                               (4096 + 512, 16384, 65536, False, False)])   # leaves of 288 rows: nine row groups of 32, partly filled tiles
-def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, add, strided):
-    """Four fused levels as two applications of the rank-R scheme for the 4 x 4 x 4 block product (scheme_passes.hip, scheme444.h; R^2 leaf
-    products per ancestor instead of 7^4) against the same product through three-level Winograd passes (max_fuse 3: another kernel family,
-    another number of leaves) -- identical bits -- and against the oracle through Freivalds' identity.  The stats say the scheme ran."""
+@pytest.mark.parametrize("m,l,n,levels,add,strided", [
+    (4096, 16384, 65536, 4, False, False),        # leaves 256 x 1024 x 4096: the smallest the scheme passes take; the scheme applied twice
+    (4096, 32768, 65536, 4, True, True),          # accumulating into a wider parent; 32-word rows of A
+    (4096 + 512, 16384, 65536, 4, False, False),  # leaves of 288 rows: nine row groups of 32, partly filled tiles
+    (2048, 8192, 32768, 3, False, False),         # three levels: one Winograd level over the scheme
+    (2048, 16384, 32768, 3, True, True),
+    (1024, 4096, 16384, 2, False, False),         # two levels: the scheme once
+    (1024, 8192, 16384, 2, True, True),
+    (8192, 32768, 131072, 5, False, False)])      # five levels: a single Winograd pass over seven ancestors of the four-level scheme pass
+def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, levels, add, strided):
+    """The fused bottom levels through the rank-R scheme for the 4 x 4 x 4 block product (scheme_passes.hip, scheme444.h: R, 7 R or R^2 leaf
+    products per ancestor instead of 7^2, 7^3, 7^4) against the same product through single-level Winograd passes (max_fuse 1: another
+    kernel family, another number of leaves) -- identical bits -- and against the oracle through Freivalds' identity.  The stats say the
+    scheme ran."""
     hA, hB, hC = Mzd.random(m, l, 91), Mzd.random(l, n, 92), Mzd.random(m, n, 93)
     pad = 4 if strided else 0
     wa, wn = hA.rowstride + pad, hB.rowstride + pad
@@ -434,21 +441,23 @@ def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, add, strided):
         return t
     A, B, C0 = dev(hA, wa), dev(hB, wn), dev(hC, wn)
     R = _scheme_rank()
+    fused = min(levels, 4)
+    want_leaves = 7 ** (levels - fused) * {2: R, 3: 7 * R, 4: R * R}[fused]
     out = {}
     old = m4ri_amd.set_max_fuse(0)
     try:
-        for fuse in (4, 3):
+        for fuse in (4, 1):
             m4ri_amd.set_max_fuse(fuse)
             C = C0.clone()
             m4ri_amd.mul_dev(C.data_ptr(), wn, A.data_ptr(), wa, B.data_ptr(), wn, m, l, n, add=add, cutoff=256)
             st = m4ri_amd.get_stats()
-            assert st.levels == 4 and (st.leaf_m, st.leaf_l, st.leaf_n) == (m // 16, l // 16, n // 16)
-            assert st.leaf_products == (R * R if fuse == 4 else 2401), (fuse, st.leaf_products)
+            assert st.levels == levels and (st.leaf_m, st.leaf_l, st.leaf_n) == (m >> levels, l >> levels, n >> levels)
+            assert st.leaf_products == (want_leaves if fuse == 4 else 7 ** levels), (fuse, st.leaf_products)
             out[fuse] = C
             assert bool((C[:, hC.rowstride:] == -1).all()), f"max_fuse={fuse}: words of the parent outside C were written"
     finally:
         m4ri_amd.set_max_fuse(old)
-    assert torch.equal(out[4], out[3])
+    assert torch.equal(out[4], out[1])
     got = Mzd(m, n)
     got.rows()[:, :] = out[4][:, :hC.rowstride].cpu().numpy().view(np.uint64)
     if add:   # C0 ^ A*B: check the product part

@@ -184,3 +184,22 @@ def test_the_4x4x4_scheme_is_a_scheme():
                         for k2 in range(4):
                             got = int((bit(U, 4 * i + j) & bit(V, 4 * j2 + k) & bit(W, 4 * i2 + k2)).sum() & 1)
                             assert got == int(i == i2 and j == j2 and k == k2), (i, j, j2, k, i2, k2)
+
+
+def test_the_winograd_level_over_the_scheme_is_a_scheme():
+    """The outer tables of the three-level scheme passes (scheme_passes.hip: make_tables, WG) are Winograd's level in the engine's order; as
+    rank-one tensors over the 2 x 2 quadrants they must sum to the tensor of the 2 x 2 block product."""
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "m4ri_amd", "csrc", "scheme_passes.hip")).read()
+    rows = re.search(r"constexpr uint16_t WG\[3\]\[7\] = \{\{([^}]*)\}, \{([^}]*)\}, \{([^}]*)\}\};", text).groups()
+    U, V, W = ([int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]+)", row)] for row in rows)
+    assert len(U) == len(V) == len(W) == 7
+    for i in range(2):
+        for j in range(2):
+            for j2 in range(2):
+                for k in range(2):
+                    for i2 in range(2):
+                        for k2 in range(2):
+                            got = sum((u >> (2 * i + j)) & (v >> (2 * j2 + k)) & (w >> (2 * i2 + k2)) & 1 for u, v, w in zip(U, V, W)) & 1
+                            assert got == int(i == i2 and j == j2 and k == k2)

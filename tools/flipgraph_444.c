@@ -108,7 +108,40 @@ static void report(const Scheme *s, int thread, uint64_t steps) {
 
 static Scheme g_start;
 static uint64_t g_path_limit = 20000000;
-static int g_plus = 0;
+static int g_plus = 0, g_general = 1;
+
+// The general reduction of the flip-graph paper: if among the tensors that share the factor `val` at position f the factors at another
+// position g are linearly DEPENDENT, t_k.g = sum_{i in S} t_i.g, then  val x t_k.g x t_k.h = sum_i val x t_i.g x t_k.h  folds into the others
+// (t_i.h += t_k.h) and t_k disappears: one rank less.  (Two tensors equal in two factors are the case |S| = 1.)  Returns 1 if it reduced.
+static int reduce_group(Scheme *s, int f, uint16_t val) {
+  int idx[MAXR], n = 0;
+  for (int i = 0; i < s->r; ++i)
+    if (s->t[i].f[f] == val) idx[n++] = i;
+  if (n < 2) return 0;
+  for (int gg = 1; gg <= 2; ++gg) {
+    const int g = (f + gg) % 3, h = 3 - f - g;
+    // Gaussian elimination over GF(2) on the vectors t.g, remembering which tensors each reduced vector is a sum of (bit masks over idx)
+    uint16_t basis[16];
+    uint64_t comb[16];
+    int nb = 0;
+    for (int k = 0; k < n; ++k) {
+      uint16_t v = s->t[idx[k]].f[g];
+      uint64_t c = (uint64_t)1 << k;
+      for (int b = 0; b < nb; ++b)
+        if ((v ^ basis[b]) < v) { v ^= basis[b]; c ^= comb[b]; }
+      if (v) {   // a new basis vector: keep the basis reduced from the top (each basis vector has a leading bit the later ones lack)
+        basis[nb] = v; comb[nb] = c; ++nb;
+        continue;
+      }
+      // dependent: the tensors in c (k among them) sum to zero at position g.  Drop tensor k: every other tensor of c takes its h factor
+      for (int q = 0; q < n; ++q)
+        if (q != k && ((c >> q) & 1)) s->t[idx[q]].f[h] ^= s->t[idx[k]].f[h];
+      s->t[idx[k]] = s->t[--s->r];
+      return 1;
+    }
+  }
+  return 0;
+}
 
 // one flip at random + the reductions it makes possible; returns 1 when something was flipped
 static int step(Scheme *cur, uint64_t *rng) {
@@ -128,6 +161,10 @@ static int step(Scheme *cur, uint64_t *rng) {
     if (k != j && (cur->t[k].f[0] == cur->t[j].f[0]) + (cur->t[k].f[1] == cur->t[j].f[1]) + (cur->t[k].f[2] == cur->t[j].f[2]) >= 2) hit = 1;
   }
   if (hit) reduce(cur);
+  else if (g_general) {   // the general reduction on the three groups the flip touched
+    const uint16_t a = cur->t[i].f[f], bi = cur->t[i].f[g], cj = cur->t[j].f[h];
+    if (reduce_group(cur, f, a) || reduce_group(cur, g, bi) || reduce_group(cur, h, cj)) reduce(cur);
+  }
   return 1;
 }
 
@@ -225,6 +262,7 @@ int main(int argc, char **argv) {
   g_target = argc > 3 ? atoi(argv[3]) : 47;
   if (argc > 7) g_path_limit = strtoull(argv[7], NULL, 10);
   if (argc > 8) g_plus = atoi(argv[8]);
+  if (argc > 9) g_general = atoi(argv[9]);
   if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
   memset(g_count, 0, sizeof g_count);
   if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
