@@ -232,8 +232,11 @@ extern "C" int64_t gf2_scheme444_leaves(int levels) { return levels == 4 ? (int6
 
 // can the scheme passes take these leaf shapes?  leaf of A: a_rows x a_cw words; of B: b_rows x b_cw words; of C: a_rows x b_cw
 extern "C" int gf2_scheme444_ok(int levels, int64_t a_rows, int64_t a_cw, int64_t b_rows, int64_t b_cw) {
-  static const int off = getenv("M4RI_AMD_SCHEME") ? atoi(getenv("M4RI_AMD_SCHEME")) : -1;   // developer switch: 0 = Winograd passes everywhere, 4 = only four levels
-  if (off == 0 || (off == 4 && levels != 4)) return 0;
+  // M4RI_AMD_SCHEME: unset = these passes wherever the table beats Strassen applied twice (R < 49: fewer leaves; with R = 49 the Winograd
+  // passes of aux_kernels.hip are the same work and a little faster at two levels); 1 = wherever the shapes allow (how the tests reach
+  // them whatever R is); 0 = never; 4 = only for four fused levels
+  static const int sw = getenv("M4RI_AMD_SCHEME") ? atoi(getenv("M4RI_AMD_SCHEME")) : -1;
+  if (sw == 0 || (sw == 4 && levels != 4) || (sw < 0 && R444 >= 49)) return 0;
   if (levels < 2 || levels > 4) return 0;
   if (a_rows <= 0 || b_rows <= 0 || a_rows % (levels == 2 ? 64 : 32) != 0 || a_cw % 16 != 0 || b_cw % POS_B != 0) return 0;
   if ((a_rows * a_cw) / 2 > 0x7fffffffLL || (b_rows * b_cw) / 32 > 0x7fffffffLL || (a_rows * b_cw) / 32 > 0x7fffffffLL) return 0;

@@ -109,6 +109,7 @@ static void report(const Scheme *s, int thread, uint64_t steps) {
 static Scheme g_start;
 static uint64_t g_path_limit = 20000000;
 static int g_plus = 0, g_general = 1;
+static volatile uint64_t g_moved = 0;
 
 // The general reduction of the flip-graph paper: if among the tensors that share the factor `val` at position f the factors at another
 // position g are linearly DEPENDENT, t_k.g = sum_{i in S} t_i.g, then  val x t_k.g x t_k.h = sum_i val x t_i.g x t_k.h  folds into the others
@@ -224,6 +225,13 @@ static void *walk(void *arg) {
       if (c < POOL) g_pool[cur.r][c] = cur; else g_pool[cur.r][rng_next(&rng) % POOL] = cur;
       g_count[cur.r] = c + 1;
       pthread_mutex_unlock(&g_mu);
+    } else if (g_plus && cur.r == start_rank && verify(&cur)) {
+      // back at the rank it started from, a whole path later (and, where the walk began with a plus transition, possibly in another
+      // component of the graph): it replaces a random member of its pool, so that the pool drifts instead of sitting in one basin
+      pthread_mutex_lock(&g_mu);
+      if (g_count[cur.r] >= POOL) g_pool[cur.r][rng_next(&rng) % POOL] = cur;
+      pthread_mutex_unlock(&g_mu);
+      __sync_fetch_and_add(&g_moved, 1);
     }
   }
   return NULL;
@@ -295,7 +303,7 @@ int main(int argc, char **argv) {
     if (now() - last > 120.0) {   // a checkpoint every two minutes, and where the pools stand
       last = now();
       checkpoint(argc > 5 ? argv[5] : NULL);
-      printf("# %.0f s: best %d, pools", now() - g_t0, g_best.r);
+      printf("# %.0f s: %llu pool members replaced; best %d, pools", now() - g_t0, (unsigned long long)g_moved, g_best.r);
       for (int r = g_best.r + 3; r >= g_best.r; --r) if (r <= 64) printf(" %d:%d", r, g_count[r]);
       printf("\n");
       fflush(stdout);
