@@ -230,6 +230,7 @@ static void *walk(void *arg) {
       // component of the graph): it replaces a random member of its pool, so that the pool drifts instead of sitting in one basin
       pthread_mutex_lock(&g_mu);
       if (g_count[cur.r] >= POOL) g_pool[cur.r][rng_next(&rng) % POOL] = cur;
+      else g_pool[cur.r][g_count[cur.r]++] = cur;
       pthread_mutex_unlock(&g_mu);
       __sync_fetch_and_add(&g_moved, 1);
     }
