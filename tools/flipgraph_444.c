@@ -11,7 +11,7 @@
 // scheme after a path limit, and prints every scheme that beats the best rank so far.
 //
 //   gcc -O2 -pthread tools/flipgraph_444.c -o build/flipgraph_444
-//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit] [1 = with plus transitions]
+//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit] [n > 0: a plus transition when stuck or after n flips without a reduction] [0 = without the general reduction] [margin: ranks above its start a walk may climb by plus transitions]
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -174,6 +174,7 @@ static int step(Scheme *cur, uint64_t *rng) {
 // limit; a quarter of the walks start from the best rank reached so far, however few schemes it has.  Breadth at every level is what
 // gets below the plateaus a single greedy path sticks on.
 #define POOL 256
+static int MARGIN = 4;
 static Scheme g_pool[65][POOL];
 static int g_count[65];
 
@@ -199,23 +200,32 @@ static void *walk(void *arg) {
     cur = g_pool[lvl][rng_next(&rng) % (uint64_t)(g_count[lvl] < POOL ? g_count[lvl] : POOL)];
     pthread_mutex_unlock(&g_mu);
     const int start_rank = cur.r;
-    // a third of the walks begin with a "plus transition" (Kauers & Moosbauer 2023): two tensors become three,
+    // "Plus transitions" (Kauers & Moosbauer 2023; Arai, Ichikawa & Hukushima 2024): two tensors become three,
     //   (a, b, c) + (a', b', c') = (a + a', b, c) + (a', b + b', c) + (a', b', c + c'),
-    // one rank up and into a part of the graph plain flips do not reach; the walk still has to come out BELOW the rank it started from
-    if (g_plus && cur.r < MAXR && cur.r >= 2 && rng_next(&rng) % 3 == 0) {
-      const int i = (int)(rng_next(&rng) % (uint64_t)cur.r);
-      int j = (int)(rng_next(&rng) % (uint64_t)(cur.r - 1));
-      if (j >= i) ++j;
-      const Tri a = cur.t[i], b = cur.t[j];
-      if (a.f[0] != b.f[0] && a.f[1] != b.f[1] && a.f[2] != b.f[2]) {
-        cur.t[i].f[0] = a.f[0] ^ b.f[0];
-        cur.t[j].f[2] = a.f[2] ^ b.f[2];
-        Tri n = {{b.f[0], (uint16_t)(a.f[1] ^ b.f[1]), a.f[2]}};
-        cur.t[cur.r++] = n;
+    // one rank up and into a part of the graph plain flips do not reach.  Schemes of low rank tend to be DEAD ENDS -- no two tensors share
+    // a factor (Strassen applied twice is one: 49 distinct factors in every position) -- so a walk that finds nothing to flip, or has not
+    // lost a rank for g_plus flips, takes a plus transition as long as it stays within MARGIN ranks of where it started.
+    uint64_t p = 0, since = 0;
+    int fails = 0;
+    for (; p < path_limit && !g_stop && cur.r >= start_rank; ++p) {
+      const int before = cur.r;
+      if (step(&cur, &rng)) fails = 0; else ++fails;
+      ++since;
+      if (cur.r < before) since = 0;
+      if (g_plus && (fails > 64 || since > (uint64_t)g_plus) && cur.r < start_rank + MARGIN && cur.r < MAXR - 1 && cur.r >= 2) {
+        const int i = (int)(rng_next(&rng) % (uint64_t)cur.r);
+        int j = (int)(rng_next(&rng) % (uint64_t)(cur.r - 1));
+        if (j >= i) ++j;
+        const Tri a = cur.t[i], b = cur.t[j];
+        if (a.f[0] != b.f[0] && a.f[1] != b.f[1] && a.f[2] != b.f[2]) {
+          cur.t[i].f[0] = a.f[0] ^ b.f[0];
+          cur.t[j].f[2] = a.f[2] ^ b.f[2];
+          Tri n = {{b.f[0], (uint16_t)(a.f[1] ^ b.f[1]), a.f[2]}};
+          cur.t[cur.r++] = n;
+          fails = 0; since = 0;
+        }
       }
     }
-    uint64_t p = 0;
-    for (; p < path_limit && !g_stop && cur.r >= start_rank; ++p) step(&cur, &rng);
     steps += p;
     __sync_fetch_and_add(&g_steps, p);
     if (cur.r < start_rank) {
@@ -272,6 +282,7 @@ int main(int argc, char **argv) {
   if (argc > 7) g_path_limit = strtoull(argv[7], NULL, 10);
   if (argc > 8) g_plus = atoi(argv[8]);
   if (argc > 9) g_general = atoi(argv[9]);
+  if (argc > 10) MARGIN = atoi(argv[10]);
   if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
   memset(g_count, 0, sizeof g_count);
   if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
