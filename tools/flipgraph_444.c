@@ -108,7 +108,7 @@ static void report(const Scheme *s, int thread, uint64_t steps) {
 
 static Scheme g_start;
 static uint64_t g_path_limit = 20000000;
-static int g_plus = 0, g_general = 1;
+static int g_plus = 0, g_general = 1, g_linked = 1;
 static volatile uint64_t g_moved = 0;
 
 // The general reduction of the flip-graph paper: if among the tensors that share the factor `val` at position f the factors at another
@@ -213,14 +213,32 @@ static void *walk(void *arg) {
       ++since;
       if (cur.r < before) since = 0;
       if (g_plus && (fails > 64 || since > (uint64_t)g_plus) && cur.r < start_rank + MARGIN && cur.r < MAXR - 1 && cur.r >= 2) {
-        const int i = (int)(rng_next(&rng) % (uint64_t)cur.r);
-        int j = (int)(rng_next(&rng) % (uint64_t)(cur.r - 1));
-        if (j >= i) ++j;
+        // the pair and the orientation (f, g, h) of the transition: preferably one whose new factor t_i.f + t_j.f is ALREADY the f-th factor
+        // of a third tensor -- the new tensor then has somebody to flip with, and the walk leaves the three tensors of the transition
+        // (a plus transition between tensors that have nothing in common with anybody mostly just undoes itself)
+        int i = (int)(rng_next(&rng) % (uint64_t)cur.r), j = -1, f = (int)(rng_next(&rng) % 3);
+        if (g_linked) {
+          const int j0 = (int)(rng_next(&rng) % (uint64_t)cur.r);
+          for (int q = 0; q < cur.r && j < 0; ++q) {
+            const int jj = (j0 + q) % cur.r;
+            if (jj == i) continue;
+            const uint16_t v = cur.t[i].f[f] ^ cur.t[jj].f[f];
+            for (int k = 0; k < cur.r; ++k)
+              if (k != i && k != jj && cur.t[k].f[f] == v) { j = jj; break; }
+          }
+        }
+        if (j < 0) {
+          j = (int)(rng_next(&rng) % (uint64_t)(cur.r - 1));
+          if (j >= i) ++j;
+        }
+        const int g = (f + 1 + (int)(rng_next(&rng) & 1)) % 3, h = 3 - f - g;
         const Tri a = cur.t[i], b = cur.t[j];
         if (a.f[0] != b.f[0] && a.f[1] != b.f[1] && a.f[2] != b.f[2]) {
-          cur.t[i].f[0] = a.f[0] ^ b.f[0];
-          cur.t[j].f[2] = a.f[2] ^ b.f[2];
-          Tri n = {{b.f[0], (uint16_t)(a.f[1] ^ b.f[1]), a.f[2]}};
+          // (a, b, c) + (a', b', c') = (a + a', b, c) + (a', b + b', c) + (a', b', c + c')   with (f, g, h) in the roles of the three positions
+          cur.t[i].f[f] = a.f[f] ^ b.f[f];
+          cur.t[j].f[h] = a.f[h] ^ b.f[h];
+          Tri n;
+          n.f[f] = b.f[f]; n.f[g] = (uint16_t)(a.f[g] ^ b.f[g]); n.f[h] = a.f[h];
           cur.t[cur.r++] = n;
           fails = 0; since = 0;
         }
@@ -283,6 +301,7 @@ int main(int argc, char **argv) {
   if (argc > 8) g_plus = atoi(argv[8]);
   if (argc > 9) g_general = atoi(argv[9]);
   if (argc > 10) MARGIN = atoi(argv[10]);
+  if (argc > 11) g_linked = atoi(argv[11]);
   if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
   memset(g_count, 0, sizeof g_count);
   if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
