@@ -109,7 +109,7 @@ static void report(const Scheme *s, int thread, uint64_t steps) {
 static Scheme g_start;
 static uint64_t g_path_limit = 20000000;
 static int g_plus = 0, g_general = 1, g_linked = 1;
-static volatile uint64_t g_moved = 0;
+static volatile uint64_t g_moved = 0, g_end_hist[12];   // walks by (rank at the end - rank at the start + 2)
 
 // The general reduction of the flip-graph paper: if among the tensors that share the factor `val` at position f the factors at another
 // position g are linearly DEPENDENT, t_k.g = sum_{i in S} t_i.g, then  val x t_k.g x t_k.h = sum_i val x t_i.g x t_k.h  folds into the others
@@ -246,6 +246,7 @@ static void *walk(void *arg) {
     }
     steps += p;
     __sync_fetch_and_add(&g_steps, p);
+    if (cur.r - start_rank + 2 >= 0 && cur.r - start_rank + 2 < 12) __sync_fetch_and_add(&g_end_hist[cur.r - start_rank + 2], 1);
     if (cur.r < start_rank) {
       if (cur.r < g_best.r) report(&cur, id, steps);
       pthread_mutex_lock(&g_mu);
@@ -336,6 +337,8 @@ int main(int argc, char **argv) {
       checkpoint(argc > 5 ? argv[5] : NULL);
       printf("# %.0f s: %llu pool members replaced; best %d, pools", now() - g_t0, (unsigned long long)g_moved, g_best.r);
       for (int r = g_best.r + 3; r >= g_best.r; --r) if (r <= 64) printf(" %d:%d", r, g_count[r]);
+      printf("; walks ended at start%+d..:", -2);
+      for (int k = 0; k < 9; ++k) printf(" %llu", (unsigned long long)g_end_hist[k]);
       printf("\n");
       fflush(stdout);
     }
