@@ -11,7 +11,7 @@
 // scheme after a path limit, and prints every scheme that beats the best rank so far.
 //
 //   gcc -O2 -pthread tools/flipgraph_444.c -o build/flipgraph_444
-//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit] [n > 0: a plus transition when stuck or after n flips without a reduction] [0 = without the general reduction] [margin: ranks above its start a walk may climb by plus transitions]
+//   build/flipgraph_444 [threads] [seconds] [target rank] [s = start from Strassen squared] [checkpoint out] [checkpoint in] [path limit] [n > 0: a plus transition when stuck or after n flips without a reduction] [0 = without the general reduction] [margin: ranks above its start a walk may climb by plus transitions] [linked plus 0/1] [quality pools 0/1] [span]
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -173,10 +173,34 @@ static int step(Scheme *cur, uint64_t *rng) {
 // the lowest rank whose pool is full -- and run until they lose a rank (the reduced scheme joins the pool of its rank) or reach the path
 // limit; a quarter of the walks start from the best rank reached so far, however few schemes it has.  Breadth at every level is what
 // gets below the plateaus a single greedy path sticks on.
+#ifndef POOL
 #define POOL 256
+#endif
 static int MARGIN = 4;
 static Scheme g_pool[65][POOL];
 static int g_count[65];
+
+// "Quality" of a scheme: the number of pairs of tensors that share a factor, i.e. the flips it offers.  Most schemes of rank 49 and 50 a
+// plain descent reaches offer none or a handful (245 of 256 pooled rank-49 schemes had zero): dead ends.  With g_quality the pools prefer
+// schemes that offer many (tournament replacement), walks start from the better of two random members of one of the SPAN + 1 lowest
+// ranks, and a walk that ends at the rank it began at leaves the richest scheme it passed through in the pool.
+static int g_quality = 0, SPAN = 3;
+static int g_q[65][POOL];
+static int quality(const Scheme *s) {
+  int q = 0;
+  for (int i = 1; i < s->r; ++i)
+    for (int j = 0; j < i; ++j)
+      q += (s->t[i].f[0] == s->t[j].f[0]) + (s->t[i].f[1] == s->t[j].f[1]) + (s->t[i].f[2] == s->t[j].f[2]);
+  return q;
+}
+static void pool_insert(const Scheme *s, uint64_t *rng) {   // g_mu held
+  const int r = s->r, c = g_count[r] < POOL ? g_count[r] : POOL, q = quality(s);
+  if (c < POOL) { g_pool[r][c] = *s; g_q[r][c] = q; g_count[r] = c + 1; return; }
+  int a = (int)(rng_next(rng) % POOL), b = (int)(rng_next(rng) % POOL);
+  if (g_q[r][b] < g_q[r][a]) a = b;
+  if (!g_quality || q >= g_q[r][a] || (rng_next(rng) & 15) == 0) { g_pool[r][a] = *s; g_q[r][a] = q; }
+  g_count[r] = g_count[r] + 1;
+}
 
 static int working_level(void) {   // the lowest rank whose pool is full; before any is (the start, a resumed checkpoint): the highest rank that has schemes
   int lvl = 0;
@@ -197,9 +221,24 @@ static void *walk(void *arg) {
     pthread_mutex_lock(&g_mu);
     int lvl = working_level();
     if ((rng_next(&rng) & 3) == 0) lvl = g_best.r;
+    int q0 = 0;
+    if (g_quality) {
+      for (int tries = 0; tries < 16; ++tries) {
+        lvl = g_best.r + (int)(rng_next(&rng) % (uint64_t)(SPAN + 1));
+        if (lvl > 64 || !g_count[lvl]) { lvl = g_best.r; continue; }
+        const uint64_t n = (uint64_t)(g_count[lvl] < POOL ? g_count[lvl] : POOL);
+        int a = (int)(rng_next(&rng) % n), b = (int)(rng_next(&rng) % n);
+        if (g_q[lvl][b] > g_q[lvl][a]) a = b;
+        cur = g_pool[lvl][a];
+        q0 = g_q[lvl][a];
+        if (q0 || g_plus) break;
+      }
+    } else
     cur = g_pool[lvl][rng_next(&rng) % (uint64_t)(g_count[lvl] < POOL ? g_count[lvl] : POOL)];
     pthread_mutex_unlock(&g_mu);
     const int start_rank = cur.r;
+    Scheme snap = cur;
+    int snap_q = q0;
     // "Plus transitions" (Kauers & Moosbauer 2023; Arai, Ichikawa & Hukushima 2024): two tensors become three,
     //   (a, b, c) + (a', b', c') = (a + a', b, c) + (a', b + b', c) + (a', b', c + c'),
     // one rank up and into a part of the graph plain flips do not reach.  Schemes of low rank tend to be DEAD ENDS -- no two tensors share
@@ -211,6 +250,11 @@ static void *walk(void *arg) {
       const int before = cur.r;
       if (step(&cur, &rng)) fails = 0; else ++fails;
       ++since;
+      if (!g_plus && fails > 4096) break;   // nothing to flip and no plus transitions: a dead end
+      if (g_quality && (p & 2047) == 2047 && cur.r == start_rank) {
+        const int q = quality(&cur);
+        if (q > snap_q) { snap = cur; snap_q = q; }
+      }
       if (cur.r < before) since = 0;
       if (g_plus && (fails > 64 || since > (uint64_t)g_plus) && cur.r < start_rank + MARGIN && cur.r < MAXR - 1 && cur.r >= 2) {
         // the pair and the orientation (f, g, h) of the transition: preferably one whose new factor t_i.f + t_j.f is ALREADY the f-th factor
@@ -250,10 +294,15 @@ static void *walk(void *arg) {
     if (cur.r < start_rank) {
       if (cur.r < g_best.r) report(&cur, id, steps);
       pthread_mutex_lock(&g_mu);
-      const int c = g_count[cur.r];
-      if (c < POOL) g_pool[cur.r][c] = cur; else g_pool[cur.r][rng_next(&rng) % POOL] = cur;
-      g_count[cur.r] = c + 1;
+      pool_insert(&cur, &rng);
       pthread_mutex_unlock(&g_mu);
+    } else if (g_quality) {
+      if (snap_q > q0 && verify(&snap)) {
+        pthread_mutex_lock(&g_mu);
+        pool_insert(&snap, &rng);
+        pthread_mutex_unlock(&g_mu);
+        __sync_fetch_and_add(&g_moved, 1);
+      }
     } else if (g_plus && cur.r == start_rank && verify(&cur)) {
       // back at the rank it started from, a whole path later (and, where the walk began with a plus transition, possibly in another
       // component of the graph): it replaces a random member of its pool, so that the pool drifts instead of sitting in one basin
@@ -303,11 +352,14 @@ int main(int argc, char **argv) {
   if (argc > 9) g_general = atoi(argv[9]);
   if (argc > 10) MARGIN = atoi(argv[10]);
   if (argc > 11) g_linked = atoi(argv[11]);
+  if (argc > 12) g_quality = atoi(argv[12]);
+  if (argc > 13) SPAN = atoi(argv[13]);
   if (argc > 4 && argv[4][0] == 's') strassen_squared(&g_best); else standard(&g_best);
   memset(g_count, 0, sizeof g_count);
   if (!verify(&g_best)) { fprintf(stderr, "the start scheme does not verify\n"); return 2; }
   g_start = g_best;
   g_pool[g_best.r][0] = g_best;
+  g_q[g_best.r][0] = quality(&g_best);
   g_count[g_best.r] = 1;
   if (argc > 6) {   // resume from a checkpoint
     FILE *fi = fopen(argv[6], "r");
@@ -317,7 +369,7 @@ int main(int argc, char **argv) {
       x.r = r;
       for (int t = 0; t < r; ++t) { unsigned a, b, c; if (fscanf(fi, "%x %x %x", &a, &b, &c) != 3) { r = 0; break; } x.t[t].f[0] = (uint16_t)a; x.t[t].f[1] = (uint16_t)b; x.t[t].f[2] = (uint16_t)c; }
       if (!r || !verify(&x)) continue;
-      if (g_count[r] < POOL) g_pool[r][g_count[r]++] = x;
+      if (g_count[r] < POOL) { g_q[r][g_count[r]] = quality(&x); g_pool[r][g_count[r]++] = x; }
       if (r < g_best.r) g_best = x;
     }
     if (fi) fclose(fi);
@@ -336,7 +388,11 @@ int main(int argc, char **argv) {
       last = now();
       checkpoint(argc > 5 ? argv[5] : NULL);
       printf("# %.0f s: %llu pool members replaced; best %d, pools", now() - g_t0, (unsigned long long)g_moved, g_best.r);
-      for (int r = g_best.r + 3; r >= g_best.r; --r) if (r <= 64) printf(" %d:%d", r, g_count[r]);
+      for (int r = g_best.r + 3; r >= g_best.r; --r) if (r <= 64) {
+        long sum = 0; int mx = 0; const int c = g_count[r] < POOL ? g_count[r] : POOL;
+        for (int q = 0; q < c; ++q) { sum += g_q[r][q]; if (g_q[r][q] > mx) mx = g_q[r][q]; }
+        printf(" %d:%d(q %.1f max %d)", r, g_count[r], c ? (double)sum / c : 0.0, mx);
+      }
       printf("; walks ended at start%+d..:", -2);
       for (int k = 0; k < 9; ++k) printf(" %llu", (unsigned long long)g_end_hist[k]);
       printf("\n");
