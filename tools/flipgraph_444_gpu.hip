@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void walk_kernel(Walker *walkers, int nwalk, u
       if (!uni(verdict[wv])) {   // a way down that would leave the scheme (nearly) dead: undo the flip and walk on
         A = pA; B = pB; C = pC; SA = pSA; SB = pSB; SC = pSC;
         ++failed;
+        if (failed >= 48) { ++p; break; }   // the serial path is slow: a walk that keeps coming upon declined reductions rests until the next launch
         continue;
       }
       if (res != 2) { pcg(rng); pcg(rng); pcg(rng); pcg(rng); pcg(rng); pcg(rng); pcg(rng); pcg(rng); }   // the draws the transition used
@@ -385,7 +386,7 @@ int main(int argc, char **argv) {
   const int margin = argc > 6 ? atoi(argv[6]) : 2;
   const int nwalk = argc > 7 ? atoi(argv[7]) : 16384;
   const uint32_t flips = argc > 8 ? (uint32_t)strtoul(argv[8], nullptr, 10) : 1000000u;
-  const bool from_standard = argc > 9 && argv[9][0] == 'x';
+  const bool from_standard = argc > 9 && (argv[9][0] == 'x' || argv[9][0] == 'k');
   const int span = argc > 10 ? atoi(argv[10]) : 3;   // walks start from the pools of the span + 1 lowest ranks
   Thresholds thr;
   memset(&thr, 0, sizeof thr);
@@ -408,6 +409,32 @@ int main(int argc, char **argv) {
     }
     if (!verify(&s)) { fprintf(stderr, "the standard algorithm does not verify\n"); return 2; }
     if (from_standard || !pool_in) pool_add(s);
+    // 'k': the Kronecker products of Strassen's algorithm (rank 7) and the definition of the 2 x 2 product (rank 8), in both orders:
+    // rank 56, half way between the standard algorithm and Strassen applied twice
+    if (argc > 9 && argv[9][0] == 'k') {
+      static const uint8_t S7[7][3] = {{0x9, 0x9, 0x9}, {0xC, 0x1, 0xC}, {0x1, 0xA, 0xA}, {0x8, 0x5, 0x5}, {0x3, 0x8, 0x3}, {0x5, 0x3, 0x8}, {0xA, 0xC, 0x1}};
+      uint8_t S8[8][3];
+      int n8 = 0;
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+        S8[n8][0] = (uint8_t)(1u << (2 * i + j)); S8[n8][1] = (uint8_t)(1u << (2 * j + k)); S8[n8][2] = (uint8_t)(1u << (2 * i + k)); ++n8;
+      }
+      for (int order = 0; order < 2; ++order) {
+        Scheme x;
+        memset(&x, 0, sizeof x);
+        for (int u = 0; u < 7; ++u) for (int v = 0; v < 8; ++v) {
+          for (int f = 0; f < 3; ++f) {
+            const uint8_t outer = order ? S8[v][f] : S7[u][f], inner = order ? S7[u][f] : S8[v][f];
+            uint16_t m = 0;
+            for (int e1 = 0; e1 < 4; ++e1) for (int e2 = 0; e2 < 4; ++e2)
+              if (((outer >> e1) & 1) && ((inner >> e2) & 1)) m |= (uint16_t)(1u << (4 * (2 * (e1 >> 1) + (e2 >> 1)) + 2 * (e1 & 1) + (e2 & 1)));
+            x.t[x.r][f] = m;
+          }
+          ++x.r;
+        }
+        if (!verify(&x)) { fprintf(stderr, "Strassen (x) standard does not verify\n"); return 2; }
+        pool_add(x);
+      }
+    }
   }
   if (pool_in && !from_standard) {
     FILE *fi = fopen(pool_in, "r");
