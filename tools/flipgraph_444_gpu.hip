@@ -22,6 +22,9 @@
 #include <vector>
 
 #define MAXR 64
+#ifndef NDIM
+#define NDIM 4   // -DNDIM=3: the 3 x 3 x 3 product, where rank 27 -> 23 is known to be reachable in seconds: a check of the moves
+#endif
 struct Scheme { uint16_t t[MAXR][3]; int32_t r; };
 struct Walker {
   Scheme s;
@@ -219,6 +222,9 @@ __device__ static inline int nth_bit(uint64_t m, int k, int lane) {
       if (__popcll(gz) >= 2) SZ |= gz; else SZ &= ~(1ull << j);                                                              \
       bool red = !nyi || !nzj || pair != 0;                                                                                  \
       if (!red) red = dependent(grp, Y) || dependent(grp, Z) || dependent(gy, X) || dependent(gy, Z) || dependent(gz, X) || dependent(gz, Y); \
+      /* ... and the two groups the tensors STAYED in with a changed vector: i in the group of its Z (its Y changed), j in that of its Y */ \
+      if (!red) { const uint64_t hz = __ballot(Z == zi && valid); red = dependent(hz, Y) || dependent(hz, X); }               \
+      if (!red) { const uint64_t hy = __ballot(Y == yj && valid); red = dependent(hy, Z) || dependent(hy, X); }               \
       res = red ? 2 : 1;                                                                                                     \
     }                                                                                                                        \
   }
@@ -319,11 +325,12 @@ __global__ __launch_bounds__(256) void walk_kernel(Walker *walkers, int nwalk, u
 
 // ---------------------------------------------------------------- host
 static int verify(const Scheme *s) {
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int j2 = 0; j2 < 4; ++j2) for (int k = 0; k < 4; ++k)
-    for (int i2 = 0; i2 < 4; ++i2) for (int k2 = 0; k2 < 4; ++k2) {
+  const int N = NDIM;
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) for (int j2 = 0; j2 < N; ++j2) for (int k = 0; k < N; ++k)
+    for (int i2 = 0; i2 < N; ++i2) for (int k2 = 0; k2 < N; ++k2) {
       int v = 0;
       for (int r = 0; r < s->r; ++r)
-        v ^= ((s->t[r][0] >> (4 * i + j)) & 1) & ((s->t[r][1] >> (4 * j2 + k)) & 1) & ((s->t[r][2] >> (4 * i2 + k2)) & 1);
+        v ^= ((s->t[r][0] >> (N * i + j)) & 1) & ((s->t[r][1] >> (N * j2 + k)) & 1) & ((s->t[r][2] >> (N * i2 + k2)) & 1);
       if (v != ((i == i2) && (j == j2) && (k == k2))) return 0;
     }
   return 1;
@@ -403,8 +410,8 @@ int main(int argc, char **argv) {
     Scheme s;
     memset(&s, 0, sizeof s);
     s.r = 0;
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int k = 0; k < 4; ++k) {
-      s.t[s.r][0] = (uint16_t)(1u << (4 * i + j)); s.t[s.r][1] = (uint16_t)(1u << (4 * j + k)); s.t[s.r][2] = (uint16_t)(1u << (4 * i + k));
+    for (int i = 0; i < NDIM; ++i) for (int j = 0; j < NDIM; ++j) for (int k = 0; k < NDIM; ++k) {
+      s.t[s.r][0] = (uint16_t)(1u << (NDIM * i + j)); s.t[s.r][1] = (uint16_t)(1u << (NDIM * j + k)); s.t[s.r][2] = (uint16_t)(1u << (NDIM * i + k));
       ++s.r;
     }
     if (!verify(&s)) { fprintf(stderr, "the standard algorithm does not verify\n"); return 2; }
@@ -489,7 +496,8 @@ int main(int argc, char **argv) {
   double last_report = 0;
   uint64_t total = 0, restarts = 0, descents = 0;
   int launches = 0;
-  while (elapsed() < seconds && best > 47) {
+  const int target = NDIM == 4 ? 47 : 23;
+  while (elapsed() < seconds && best > target) {
     int zero = 0;
     CHECK(hipMemcpy(dn, &zero, sizeof zero, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(db, &best, sizeof best, hipMemcpyHostToDevice));
@@ -551,5 +559,5 @@ int main(int argc, char **argv) {
   }
   write_pools(pool_out, best);
   printf("# best rank %d, %.3g flips in %.0f s\n", best, (double)total, elapsed());
-  return best <= 47 ? 0 : 1;
+  return best <= target ? 0 : 1;
 }
