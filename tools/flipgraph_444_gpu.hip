@@ -10,7 +10,7 @@
 // below the best rank.  Developer tool (own code; Kauers & Moosbauer 2022, Arai, Ichikawa & Hukushima 2024 for the method).
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/flipgraph_444_gpu.hip -o build/flipgraph_444_gpu
-//   build/flipgraph_444_gpu [seconds] [pool file in] [pool file out] [path limit] [plus interval] [margin] [walks] [flips per launch] [x = start from the standard algorithm] [span] [thresholds rank:flips,...]
+//   build/flipgraph_444_gpu [seconds] [pool file in] [pool file out] [path limit] [plus interval] [margin] [walks] [flips per launch] [x = start from the standard algorithm] [span] [thresholds rank:flips,...] [lazy mask]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -230,7 +230,7 @@ __device__ static inline int nth_bit(uint64_t m, int k, int lane) {
   }
 
 __global__ __launch_bounds__(256) void walk_kernel(Walker *walkers, int nwalk, uint32_t flips, uint32_t plus_interval, int margin, Found *found,
-                                                   int *nfound, int maxfound, int *best, Thresholds thr, unsigned long long *qhist) {
+                                                   int *nfound, int maxfound, int *best, Thresholds thr, unsigned long long *qhist, uint32_t lazy_mask) {
   __shared__ Scheme sh[4], sh2[4];
   __shared__ int verdict[4];
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256) void walk_kernel(Walker *walkers, int nwalk, u
       }
       ++since;
       if (res == 0) ++failed;
+    }
+    // lazy reduction: of the reducible states the walk comes upon only one in lazy_mask + 1 is entered (the others: the flip is undone), so
+    // that the walk mixes on its plateau before it steps down instead of taking the first way down it sees
+    if (res == 2 && lazy_mask && ((rnd >> 8) * 2654435761u >> 12 & lazy_mask) != 0) {
+      A = pA; B = pB; C = pC; SA = pSA; SB = pSB; SC = pSC;
+      continue;
     }
     const bool can_plus = plus_interval && r < base + margin && r < MAXR - 1;
     const bool want_plus = can_plus && (!total || since > plus_interval);
@@ -342,6 +348,32 @@ static int quality(const Scheme &s) {   // pairs of tensors that share a factor 
     for (int j = 0; j < i; ++j) q += (s.t[i][0] == s.t[j][0]) + (s.t[i][1] == s.t[j][1]) + (s.t[i][2] == s.t[j][2]);
   return q;
 }
+
+static int rank4(uint16_t m) {   // rank over GF(2) of the NDIM x NDIM matrix whose entry (i, j) is bit NDIM i + j
+  uint16_t rows[NDIM];
+  for (int i = 0; i < NDIM; ++i) rows[i] = (uint16_t)((m >> (NDIM * i)) & ((1u << NDIM) - 1));
+  int r = 0;
+  for (int b = 0; b < NDIM; ++b) {
+    int p = -1;
+    for (int i = r; i < NDIM; ++i) if ((rows[i] >> b) & 1) { p = i; break; }
+    if (p < 0) continue;
+    std::swap(rows[r], rows[p]);
+    for (int i = 0; i < NDIM; ++i) if (i != r && ((rows[i] >> b) & 1)) rows[i] ^= rows[r];
+    ++r;
+  }
+  return r;
+}
+// Strassen applied twice has, in each of the three positions, 36 factors of rank 1, 12 of rank 2 and one of rank 4
+static bool strassen_squared_signature(const Scheme &s) {
+  if (s.r != 49) return false;
+  for (int f = 0; f < 3; ++f) {
+    int c[5] = {0, 0, 0, 0, 0};
+    for (int t = 0; t < s.r; ++t) c[rank4(s.t[t][f])]++;
+    if (c[1] != 36 || c[2] != 12 || c[4] != 1) return false;
+  }
+  return true;
+}
+static uint64_t g_sig_strassen = 0, g_sig_other = 0;
 
 static const size_t POOLCAP = 4096;
 static std::vector<Scheme> g_pool[65];
@@ -479,6 +511,7 @@ int main(int argc, char **argv) {
   std::vector<Walker> host((size_t)nwalk);
   memset(host.data(), 0, host.size() * sizeof(Walker));
   for (auto &w : host) restart(w);
+  const uint32_t lazy_mask = argc > 12 ? (uint32_t)strtoul(argv[12], nullptr, 0) : 0u;   // e.g. 1023: one reducible state in 1024 is entered
   Walker *dw; Found *df; int *dn, *db;
   unsigned long long *dq;
   CHECK(hipMalloc(&dq, 65 * 32 * sizeof(unsigned long long)));
@@ -501,7 +534,7 @@ int main(int argc, char **argv) {
     int zero = 0;
     CHECK(hipMemcpy(dn, &zero, sizeof zero, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(db, &best, sizeof best, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(walk_kernel, dim3((unsigned)((nwalk + 3) / 4)), dim3(256), 0, 0, dw, nwalk, flips, plus_interval, margin, df, dn, maxfound, db, thr, dq);
+    hipLaunchKernelGGL(walk_kernel, dim3((unsigned)((nwalk + 3) / 4)), dim3(256), 0, 0, dw, nwalk, flips, plus_interval, margin, df, dn, maxfound, db, thr, dq, lazy_mask);
     CHECK(hipGetLastError());
     CHECK(hipDeviceSynchronize());
     ++launches;
@@ -514,6 +547,7 @@ int main(int argc, char **argv) {
       if (s.r < 1 || s.r > 64 || !verify(&s)) { fprintf(stderr, "a scheme of rank %d from the device does not verify\n", s.r); return 4; }
       ++descents;
       pool_add(s);
+      if (s.r == 49) { if (strassen_squared_signature(s)) ++g_sig_strassen; else ++g_sig_other; }
       if (s.r < best) {
         best = s.r;
         printf("# rank %d after %.1f s (%.3g flips), quality %d\n", s.r, elapsed(), (double)total, quality(s));
@@ -544,6 +578,7 @@ int main(int argc, char **argv) {
       }
       printf("; arrived (with a flip to offer)");
       for (int r = best; r <= best + 2 && r <= 64; ++r) printf(" %d:%llu(%llu)", r, (unsigned long long)g_arrived[r], (unsigned long long)g_arrived_live[r]);
+      printf("; rank 49 with the factor ranks of Strassen squared %llu, other %llu", (unsigned long long)g_sig_strassen, (unsigned long long)g_sig_other);
       printf("; %llu descents, %llu restarts, serial path %.3g of flips, declined reductions %.3g\n", (unsigned long long)descents, (unsigned long long)restarts,
              (double)slow / (double)total, (double)failed / (double)total);
       CHECK(hipMemcpy(hq.data(), dq, hq.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
