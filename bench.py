@@ -5,16 +5,14 @@
 
 A "step" is one whole product C = A*B on device-resident, synthetic (splitmix64, density 1/2) operands, everything through
 libm4ri_amd.so's C ABI.  Inputs are in HBM before the timed region starts.
-
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 65536] [--workload mul|leaf16384|rect131072]
 
 N = 1: Strassen-Winograd levels over batched M4RM leaves on one GPU (m4ri_amd_mul_dev).
-
 N > 1: the command that receives `--gpus N` is a CONTROLLER (under `torch.distributed.run` launcher rank 0 takes the role, the other
 launcher ranks step aside).  It measures, each in processes of its own: the links (every ordered pair of GPUs, `config.links`), the
 SAME product on ONE GPU (`speedup_vs_n1`), the product on N GPUs through a ladder of two transports, and the reference's multi-core
 path on this host (`cpu_baseline`; the reference switches to its multi-core path inside the same command,
-bench/bench_multiplication.c:94-103) -- and always ends with exactly one JSON line (`config.controller_wall_s` says how long it took).
+bench/bench_multiplication.c:94-103) -- and always ends with exactly one JSON line (`config.controller_wall_s`).
   transports  `peer` = ONE process driving all GPUs through libm4ri_amd.so's distributed matrices (m4ri_amd_dmat_mul,
               m4ri_amd/csrc/multi.hip: the schedules behind the C boundary -- what mzd_mul_mp runs -- pieces pulled by
               hipMemcpyPeerAsync on per-link copy streams, one host thread per GPU); `rccl` = one process per GPU, torch.distributed
@@ -791,6 +789,8 @@ def main():
                     f"mzd_mul {M}x{L}x{N} (BASELINE.json configs[4])" if args.workload == "rect131072" else
                     f"mzd_mul {n}x{n}x{n} (BASELINE.json configs[2]/[3]): Strassen-Winograd over M4RM leaves" if (M, L, N) == (65536, 65536, 65536) else
                     f"mzd_mul {M}x{L}x{N} (not a BASELINE.json configuration): Strassen-Winograd over M4RM leaves")
+        if int(stats.levels) >= 2 and int(stats.leaf_products) % 7 ** int(stats.levels):   # fewer leaf products than 7 per level
+            workload = workload.replace("Strassen-Winograd over", "Strassen-Winograd levels, the fused bottom ones by a rank-47 scheme of the 4 x 4 x 4 block product, over")
         out = {
             "metric": "gf2_matmul_n3_equiv_bitops_per_sec", "value": value, "unit": "bit-op/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",

@@ -245,7 +245,7 @@ def test_config2_leaf_16384_vs_reference_fingerprint(oracle):
     m4ri_amd.mul_dev(C2.data_ptr(), n // 64, A.data_ptr(), n // 64, B.data_ptr(), n // 64, n, n, n)
     assert torch.equal(C, C2)
     st = m4ri_amd.get_stats()
-    assert st.levels == m4ri_amd.plan_levels(n, n, n, 0) == 2 and st.leaf_products == 49   # the engine's own depth: leaves of 4096^3
+    assert st.levels == m4ri_amd.plan_levels(n, n, n, 0) == 2 and st.leaf_products == _scheme_leaves(2)   # the engine's own depth: leaves of 4096^3
 
 
 def freivalds(oracle, A, B, C, m, l, n, seed):
@@ -268,7 +268,7 @@ def test_config3_65536_strassen_properties(oracle):
     C = torch.empty((n, w), dtype=torch.int64, device="cuda")
     m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, n, n, n)
     st = m4ri_amd.get_stats()
-    assert st.levels == 4 and st.leaf_products == 2401 and (st.leaf_m, st.leaf_l, st.leaf_n) == (4096, 4096, 4096)
+    assert st.levels == 4 and st.leaf_products == _scheme_leaves(4) and (st.leaf_m, st.leaf_l, st.leaf_n) == (4096, 4096, 4096)
     hC = to_host(C, n, n)
     z = np.load(golden_file("fingerprints_xl.npz"))
     i = [k for k, mt in enumerate(z["meta"]) if tuple(int(x) for x in mt[:3]) == (n, n, n)]
@@ -415,6 +415,18 @@ def _scheme_rank():
     import re
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "m4ri_amd", "csrc", "scheme444.h")).read()
     return int(re.search(r"#define SCHEME444_R (\d+)", text).group(1))
+
+
+def _scheme_leaves(levels):
+    """Leaf products of `levels` Strassen levels as the engine runs them by default: the bottom (up to four) fused levels go through the
+    4 x 4 x 4 scheme of rank R when the table beats Strassen applied twice (R < 49; scheme_passes.hip gf2_scheme444_ok, M4RI_AMD_SCHEME)."""
+    R = _scheme_rank()
+    sw = os.environ.get("M4RI_AMD_SCHEME")
+    on = (R < 49) if sw is None else (int(sw) != 0)
+    fused = min(levels, 4)
+    if not on or fused < 2:
+        return 7 ** levels
+    return 7 ** (levels - fused) * {2: R, 3: 7 * R, 4: R * R}[fused]
 
 
 @pytest.mark.parametrize("m,l,n,levels,add,strided", [
