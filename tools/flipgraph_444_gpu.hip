@@ -10,7 +10,7 @@
 // below the best rank.  Developer tool (own code; Kauers & Moosbauer 2022, Arai, Ichikawa & Hukushima 2024 for the method).
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/flipgraph_444_gpu.hip -o build/flipgraph_444_gpu
-//   build/flipgraph_444_gpu [seconds] [pool file in] [pool file out] [path limit] [plus interval] [margin] [walks] [flips per launch] [x = start from the standard algorithm] [span] [thresholds rank:flips,...] [lazy mask]
+//   build/flipgraph_444_gpu [seconds] [pool file in] [pool file out] [path limit] [plus interval] [margin] [walks] [flips per launch] [x = start from the standard algorithm] [span] [thresholds rank:flips,...] [lazy mask] [target rank]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -529,7 +529,7 @@ int main(int argc, char **argv) {
   double last_report = 0;
   uint64_t total = 0, restarts = 0, descents = 0;
   int launches = 0;
-  const int target = NDIM == 4 ? 47 : 23;
+  const int target = argc > 13 ? atoi(argv[13]) : (NDIM == 4 ? 47 : 23);   // stop at this rank
   while (elapsed() < seconds && best > target) {
     int zero = 0;
     CHECK(hipMemcpy(dn, &zero, sizeof zero, hipMemcpyHostToDevice));
