@@ -446,13 +446,32 @@ def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, levels, add, s
     if os.environ.get("M4RI_AMD_SCHEME") != "1":
         # the library takes the scheme passes by itself only when the table beats Strassen applied twice; the test reaches them whatever the
         # table is by running itself in a child process with the switch set (read once per process)
-        import subprocess
-        import sys
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                            f"test_scheme_passes_match_the_winograd_passes and {m}-{l}-{n}-{levels}-{add}-{strided}"],
-                           capture_output=True, text=True, env=dict(os.environ, M4RI_AMD_SCHEME="1"), timeout=900)
-        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        _in_child_with_scheme("1", "test_scheme_passes_match_the_winograd_passes", m, l, n, levels, add, strided)
         return
+    _fused_against_single_level(oracle, m, l, n, levels, add, strided)
+
+
+@pytest.mark.parametrize("m,l,n,levels,add,strided", [
+    (4096, 16384, 65536, 4, False, False), (4096, 32768, 65536, 4, True, True), (2048, 16384, 32768, 3, True, True), (1024, 4096, 16384, 2, False, False)])
+def test_winograd_passes_on_the_scheme_shapes_with_the_scheme_switched_off(oracle, m, l, n, levels, add, strided):
+    """M4RI_AMD_SCHEME=0 gives the fused Winograd passes (aux_kernels.hip) back on the leaf shapes the scheme passes take by default since
+    the table has rank 47: 7^levels leaf products, the same bits."""
+    if os.environ.get("M4RI_AMD_SCHEME") != "0":
+        _in_child_with_scheme("0", "test_winograd_passes_on_the_scheme_shapes_with_the_scheme_switched_off", m, l, n, levels, add, strided)
+        return
+    _fused_against_single_level(oracle, m, l, n, levels, add, strided)
+
+
+def _in_child_with_scheme(value, name, m, l, n, levels, add, strided):
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        f"{name} and {m}-{l}-{n}-{levels}-{add}-{strided}"],
+                       capture_output=True, text=True, env=dict(os.environ, M4RI_AMD_SCHEME=value), timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _fused_against_single_level(oracle, m, l, n, levels, add, strided):
     hA, hB, hC = Mzd.random(m, l, 91), Mzd.random(l, n, 92), Mzd.random(m, n, 93)
     pad = 4 if strided else 0
     wa, wn = hA.rowstride + pad, hB.rowstride + pad
@@ -462,9 +481,7 @@ def test_scheme_passes_match_the_winograd_passes(oracle, m, l, n, levels, add, s
         t[:, :h.rowstride] = torch.from_numpy(h.rows().view(np.int64).copy()).cuda()
         return t
     A, B, C0 = dev(hA, wa), dev(hB, wn), dev(hC, wn)
-    R = _scheme_rank()
-    fused = min(levels, 4)
-    want_leaves = 7 ** (levels - fused) * {2: R, 3: 7 * R, 4: R * R}[fused]
+    want_leaves = _scheme_leaves(levels)   # by the switch of this process
     out = {}
     old = m4ri_amd.set_max_fuse(0)
     try:
