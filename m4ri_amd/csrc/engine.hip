@@ -134,8 +134,10 @@ struct Engine {
   hipEvent_t last_done    = nullptr;  // on ANOTHER stream first waits for this event (recorded after every product)
   bool have_last          = false;
   std::mutex mu;                      // one host thread at a time plans on this device's workspace; other devices do not wait
-  hipStream_t aux_stream = nullptr;   // second stream of the overlap experiment / the pipelined schedule
+#ifdef M4RI_AMD_DEV_EXPERIMENTS
+  hipStream_t aux_stream = nullptr;   // second stream of the overlap experiment (developer builds; lives as long as the process)
   hipEvent_t aux_ev[2]   = {nullptr, nullptr};
+#endif
 };
 
 std::mutex g_cfg_mu;  // the process-wide knobs (workspace budget, fuse depth)
@@ -225,6 +227,16 @@ LeafKind pick_leaf(int64_t m, int64_t l, int64_t n) {
     if (cost < best_cost) { best_cost = cost; best = k; }
   }
   return best;
+}
+
+// Do the fused bottom `fuse` levels of a product with these LEAF dimensions run through the rank-R scheme of the 4 x 4 x 4 block
+// product (scheme_passes.hip)?  ONE rule for the time model (depth_model_seconds) and the schedule (bfs_product): generation 4's
+// packed A (the scheme's A-side pass writes it), leaf shapes the scheme kernels take, one packed operand within a buffer descriptor.
+bool scheme_applies(int fuse, int64_t leaf_m, int64_t leaf_l, int64_t leaf_n) {
+  if (fuse < 2 || leaf_m <= 0 || leaf_l <= 0 || leaf_n <= 0 || leaf_l % 64 != 0 || leaf_n % 64 != 0) return false;
+  if (pick_leaf(leaf_m, leaf_l, leaf_n).gen != 4) return false;
+  if (gf2_scheme444_ok(fuse, leaf_m, leaf_l / 64, leaf_l, leaf_n / 64) == 0) return false;
+  return (uint64_t)gf2_m4rm8_a4_words(leaf_m, leaf_l, 1) * 8 < (1ull << 32);
 }
 
 // words of packed-A scratch a leaf launch of this shape may need (max over the packed kernels)
@@ -349,7 +361,11 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
     e0 = take_event(e); e1 = take_event(e);
     if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
   }
-  static const int exp_groups = getenv("M4RI_AMD_LEAF_GROUPS") ? atoi(getenv("M4RI_AMD_LEAF_GROUPS")) : 0;  // developer: the batch in this many launches
+#ifdef M4RI_AMD_DEV_EXPERIMENTS  // developer builds only (profiles/r05_overlap_power/): the batch in this many launches
+  static const int exp_groups = getenv("M4RI_AMD_LEAF_GROUPS") ? atoi(getenv("M4RI_AMD_LEAF_GROUPS")) : 0;
+#else
+  constexpr int exp_groups = 0;
+#endif
   if (kind.gen == 4 && exp_groups > 1 && batch % exp_groups == 0 && ksplit == 1) {
     for (int g = 0; g < exp_groups; ++g) {
       LeafArgs part = a;
@@ -470,7 +486,7 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   for (int d = 0; d < L; ++d) p7 *= 7;
   // the fused bottom levels run through the rank-R 4 x 4 x 4 scheme where the leaves allow it: R, 7 R or R^2 products instead of 7^2, 7^3, 7^4
   const int mfuse = L < g_max_fuse ? L : g_max_fuse;
-  const bool scheme = mfuse >= 2 && mm >= 192 && gf2_scheme444_ok(mfuse, mm, words_of(ll), ll, words_of(nn)) != 0;
+  const bool scheme = scheme_applies(mfuse, mm, ll, nn);
   const double srat = scheme ? (double)gf2_scheme444_leaves(mfuse) / (double)ipow7(mfuse) : 1.0;
   p7 *= srat;
   double t = leaf(mm, ll, nn, p7);
@@ -582,8 +598,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // ancestor of the fused pass instead of 7^4, packed A written by the pass itself.  Needs generation 4's packed A and leaf shapes the
   // scheme kernels take; everything else keeps the Winograd passes.
   const int64_t leaf_m = m >> L, leaf_l = l >> L, leaf_n = n >> L;
-  const bool scheme = fuse >= 2 && leaf_kind.gen == 4 && gf2_scheme444_ok(fuse, leaf_m, leaf_l / 64, leaf_l, leaf_n / 64) != 0 &&
-                      (uint64_t)gf2_m4rm8_a4_words(leaf_m, leaf_l, 1) * 8 < (1ull << 32);
+  const bool scheme = scheme_applies(fuse, leaf_m, leaf_l, leaf_n);
   const int64_t leaves = scheme ? ipow7(L - fuse) * gf2_scheme444_leaves(fuse) : ipow7(L);  // products of the leaf launch
   bool prepack = scheme;
   if (!scheme && fuse >= 2 && leaf_kind.gen == 4) {
@@ -665,9 +680,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     }
     d += step;
   }
-  // developer experiment (profiles/r05_overlap_power/): the three four-level passes once more on a second stream UNDER the leaf
-  // launch (same sources, same destinations, same values; the up pass reads half-written products and its output is overwritten
-  // by the real one) -- what the leaf loses to HBM-bound work beside it bounds what a pipelined schedule could win
+#ifdef M4RI_AMD_DEV_EXPERIMENTS
+  // developer experiment, NOT in the product build (profiles/r05_overlap_power/; build with -DM4RI_AMD_DEV_EXPERIMENTS): the three
+  // four-level passes once more on a second stream UNDER the leaf launch (same sources, same destinations, same values; the up pass
+  // reads half-written products and its output is overwritten by the real one -- unsafe by construction, correct only because the
+  // real up pass waits for it) -- what the leaf loses to HBM-bound work beside it bounds what a pipelined schedule could win
   static const int exp_overlap = getenv("M4RI_AMD_OVERLAP_EXP") ? atoi(getenv("M4RI_AMD_OVERLAP_EXP")) : 0;
   const bool overlap_now = exp_overlap && L == 4 && fuse == 4 && prepack && !scheme;
   if (overlap_now) {
@@ -680,6 +697,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     if (exp_overlap & 4) HIPTRY(gf2_launch_winograd_up4(e->aux_stream, 0, Pl[4], C.p, C.stride, 0, 1, cm, cn / 64));
     HIPTRY(hipEventRecord(e->aux_ev[1], e->aux_stream));
   }
+#endif
   // all 7^L leaf products in one launch
   {
     const int64_t lm = m >> L, ll = l >> L, ln = n >> L, cnt = leaves;
@@ -687,7 +705,9 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
                              ll * (ln / 64), lm, ll, ln, cnt, false, 0, prepack))
       return rc;
   }
+#ifdef M4RI_AMD_DEV_EXPERIMENTS
   if (overlap_now) HIPTRY(hipStreamWaitEvent(st, e->aux_ev[1], 0));
+#endif
   // up passes: the fused pass at the bottom first (L -> L - fuse), then level d+1 -> d
   for (int d = L; d > 0;) {
     const int step    = d == L ? fuse : 1;

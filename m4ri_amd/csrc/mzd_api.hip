@@ -409,10 +409,12 @@ struct Pin {
   int64_t rowstride;
   rci_t nrows, ncols;
   word *dbase;
-  bool dev_newer;
+  bool dev_newer;  // written under the pin's device lock (set_newer), read there or by the cheap status query (is_newer): atomic accesses
   mzd_t *owner;
   int device;  // HIP device the copy lives on
 };
+inline void set_newer(Pin &p, bool v) { __atomic_store_n(&p.dev_newer, v, __ATOMIC_RELEASE); }
+inline bool is_newer(const Pin &p) { return __atomic_load_n(&p.dev_newer, __ATOMIC_ACQUIRE); }
 std::list<Pin> g_pins;  // a list: entries stay where they are while other threads pin and unpin (g_pin_mu guards the walk and the edits)
 
 // Locking rule of the table: g_pin_mu guards the walk and the edits of the LIST; the lock of the device a pin lives on
@@ -442,7 +444,7 @@ struct PinLock {
   Pin *p   = nullptr;
   int prev = -1, dev = -1;  // the caller's current device, the pin's (kept here: unpin erases *p before this object goes)
   explicit PinLock(const mzd_t *M) {
-    for (int tries = 0; tries < 64; ++tries) {
+    for (;;) {  // until the look and the lock agree: giving up would report a pinned matrix as "not pinned" (a stale host copy unnoticed)
       const int d = pin_device(M);
       if (d < 0 || d >= ARENA_DEVICES) return;
       lk = std::unique_lock<std::mutex>(g_dev_mu[d]);
@@ -876,7 +878,7 @@ mzd_t *run(mzd_t *C, const mzd_t *A, const mzd_t *B, bool add, bool strassen, in
       const DevMat dst = operand(C, false);
       HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, dC.p, dC.stride, C->nrows, C->ncols));
     }
-    pinC->dev_newer = true;  // the host copy is stale until m4ri_amd_sync / m4ri_amd_unpin
+    set_newer(*pinC, true);  // the host copy is stale until m4ri_amd_sync / m4ri_amd_unpin
   } else {
     if (late) C = late->get();
     download(dC, C);
@@ -920,7 +922,7 @@ void inout_end(InOut &io, mzd_t *M) {
       const DevMat dst = operand(M, false);
       HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, io.d.p, io.d.stride, M->nrows, M->ncols));
     }
-    io.pin->dev_newer = true;
+    set_newer(*io.pin, true);
   } else {
     download(io.d, M);
   }
@@ -959,12 +961,12 @@ void run_trsm(bool upper, const mzd_t *T, mzd_t *B, int cutoff, bool right = fal
 }
 
 void pin_download(Pin &p) {
-  if (!p.dev_newer) return;
+  if (!is_newer(p)) return;
   const int64_t width = words_of(p.ncols);
   if (p.nrows && width)
     HIPDIE(hipMemcpy2D(const_cast<word *>(p.hbase), (size_t)p.rowstride * 8, p.dbase, (size_t)p.rowstride * 8, (size_t)width * 8,
                        (size_t)p.nrows, hipMemcpyDeviceToHost));
-  p.dev_newer = false;
+  set_newer(p, false);
 }
 
 void pin_upload(Pin &p) {
@@ -974,7 +976,7 @@ void pin_upload(Pin &p) {
     HIPDIE(m4ri_amd_mask_tail_dev(p.dbase, p.rowstride, p.nrows, p.ncols, nullptr));
     HIPDIE(hipDeviceSynchronize());
   }
-  p.dev_newer = false;
+  set_newer(p, false);
 }
 
 }  // namespace
@@ -1352,7 +1354,7 @@ mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {  // mzd.c:1118-1139
   if (Pin *pd = find_pin(DST)) {
     const DevMat dst = operand(DST, false);
     HIPDIE(gf2_launch_copy_masked(nullptr, dst.p, dst.stride, dD.p, dD.stride, DST->nrows, DST->ncols));
-    pd->dev_newer = true;
+    set_newer(*pd, true);
   } else {
     download(dD, DST);
   }
@@ -1497,7 +1499,7 @@ void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L)
   int32_t *dj = reinterpret_cast<int32_t *>(arena_raw((size_t)twokay / 2 + 1));
   HIPDIE(hipMemcpyAsync(dj, jstar.data(), (size_t)twokay * 4, hipMemcpyHostToDevice, nullptr));
   HIPDIE(m4ri_amd_make_table_dev(dM.p, dM.stride, W.nrows, M->ncols, 0, c, k, dT.p, dT.p, dT.stride, dj, nullptr));
-  if (pinT) pinT->dev_newer = true;
+  if (pinT) set_newer(*pinT, true);
   else
     HIPDIE(hipMemcpy2D(T->data + (int64_t)T->rowstride + home, (size_t)T->rowstride * 8, dT.p + dT.stride + home, (size_t)dT.stride * 8, (size_t)wide * 8,
                        (size_t)(twokay - 1), hipMemcpyDeviceToHost));
@@ -1593,9 +1595,14 @@ int m4ri_amd_unpin(mzd_t *M) {
   return 0;
 }
 
+// A status query: the list's short lock only, never the device lock -- it does not wait for a product running on the pin's device
+// (the flag it reads is the one the LAST completed call left; a product in flight sets it before it returns)
 int m4ri_amd_is_pinned(const mzd_t *M) {
-  PinLock pl(M);
-  return pl.p ? (pl.p->dev_newer ? 2 : 1) : 0;
+  if (!M || !M->data) return 0;
+  std::lock_guard<std::mutex> pl(g_pin_mu);
+  for (const Pin &p : g_pins)
+    if (M->data >= p.hbase && M->data < p.hbase + p.words && M->rowstride == p.rowstride) return is_newer(p) ? 2 : 1;
+  return 0;
 }
 
 int gf2_multi_wanted(int64_t m, int64_t l, int64_t n);  // multi.hip

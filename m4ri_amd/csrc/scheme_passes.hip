@@ -221,6 +221,7 @@ __global__ __launch_bounds__(POS * UNITS) void scheme_up_kernel(const word *__re
 
 Outer outer_for(int levels, int side) { return Outer{levels == 4 ? R444 : levels == 3 ? 7 : 1, levels - 2, side}; }
 
+constexpr int64_t MAX_GRID_Y = 65535;  // ancestors per launch (they ride on gridDim.y)
 constexpr int POS_B = 64;  // positions per workgroup of the B-side and result kernels' rule for the leaf shapes (cw % 64 == 0)
 
 }  // namespace
@@ -256,13 +257,20 @@ extern "C" hipError_t gf2_launch_scheme_down(hipStream_t s, int levels, int bsid
                                              int64_t nparents, int64_t crows, int64_t cw) {
   const int64_t c_bs = crows * cw;
   if (nparents * c_bs == 0) return hipSuccess;
-  if (levels < 2 || levels > 4 || cw % 64 != 0 || nparents > 65535) return hipErrorInvalidValue;
+  if (levels < 2 || levels > 4 || cw % 64 != 0) return hipErrorInvalidValue;
   const Outer o = outer_for(levels, bside ? 1 : 0);
-  const dim3 g((unsigned)(c_bs / 64), (unsigned)nparents);
-#define L_(G, T, BS) hipLaunchKernelGGL((scheme_down_kernel<G, 64, T / 64, BS>), g, dim3(T), 0, s, anc, p_stride, p_bs, child, c_bs, crows, cw, o)
-  if (bside) SP_DISPATCH(levels, L_(4, 512, true), L_(2, 448, true), L_(1, 64, true));
-  else SP_DISPATCH(levels, L_(4, 512, false), L_(2, 448, false), L_(1, 64, false));
+  const int64_t leaves = gf2_scheme444_leaves(levels);
+  // ancestors ride on gridDim.y (at most 65535): more of them go in several launches
+  for (int64_t p0 = 0; p0 < nparents; p0 += MAX_GRID_Y) {
+    const int64_t np = nparents - p0 < MAX_GRID_Y ? nparents - p0 : MAX_GRID_Y;
+    const word *an = anc + p0 * p_bs;
+    word *ch       = child + p0 * leaves * c_bs;
+    const dim3 g((unsigned)(c_bs / 64), (unsigned)np);
+#define L_(G, T, BS) hipLaunchKernelGGL((scheme_down_kernel<G, 64, T / 64, BS>), g, dim3(T), 0, s, an, p_stride, p_bs, ch, c_bs, crows, cw, o)
+    if (bside) SP_DISPATCH(levels, L_(4, 512, true), L_(2, 448, true), L_(1, 64, true));
+    else SP_DISPATCH(levels, L_(4, 512, false), L_(2, 448, false), L_(1, 64, false));
 #undef L_
+  }
   return hipGetLastError();
 }
 
@@ -270,14 +278,20 @@ extern "C" hipError_t gf2_launch_scheme_down_pack(hipStream_t s, int levels, con
                                                   int64_t nparents, int64_t crows, int64_t cw) {
   if (nparents * crows * cw == 0) return hipSuccess;
   const int pos = levels == 2 ? 64 : 32;
-  if (levels < 2 || levels > 4 || crows % pos != 0 || cw % 16 != 0 || nparents > 65535) return hipErrorInvalidValue;
+  if (levels < 2 || levels > 4 || crows % pos != 0 || cw % 16 != 0) return hipErrorInvalidValue;
   const Outer o = outer_for(levels, 0);
   const int64_t groups = ((crows / pos + 7) / 8) * (cw / 16);
   if (groups * 128 > 0x7fffffffLL) return hipErrorInvalidValue;
-  const dim3 g((unsigned)(groups * 128), (unsigned)nparents);
-#define L_(G, P, T) hipLaunchKernelGGL((scheme_down_pack_kernel<G, P, T / P>), g, dim3(T), 0, s, anc, p_stride, p_bs, reinterpret_cast<uint32_t *>(a4), crows * cw * 2, crows, cw, o)
-  SP_DISPATCH(levels, L_(4, 32, 256), L_(2, 32, 256), L_(1, 64, 64));
+  const int64_t leaves = gf2_scheme444_leaves(levels);
+  for (int64_t p0 = 0; p0 < nparents; p0 += MAX_GRID_Y) {
+    const int64_t np = nparents - p0 < MAX_GRID_Y ? nparents - p0 : MAX_GRID_Y;
+    const word *an = anc + p0 * p_bs;
+    uint32_t *pk   = reinterpret_cast<uint32_t *>(a4) + p0 * leaves * crows * cw * 2;
+    const dim3 g((unsigned)(groups * 128), (unsigned)np);
+#define L_(G, P, T) hipLaunchKernelGGL((scheme_down_pack_kernel<G, P, T / P>), g, dim3(T), 0, s, an, p_stride, p_bs, pk, crows * cw * 2, crows, cw, o)
+    SP_DISPATCH(levels, L_(4, 32, 256), L_(2, 32, 256), L_(1, 64, 64));
 #undef L_
+  }
   return hipGetLastError();
 }
 
@@ -286,13 +300,19 @@ extern "C" hipError_t gf2_launch_scheme_up(hipStream_t s, int levels, int acc, c
                                            int64_t nparents, int64_t crows, int64_t cw) {
   const int64_t p_bs = crows * cw;
   if (nparents * p_bs == 0) return hipSuccess;
-  if (levels < 2 || levels > 4 || cw % 64 != 0 || nparents > 65535) return hipErrorInvalidValue;
+  if (levels < 2 || levels > 4 || cw % 64 != 0) return hipErrorInvalidValue;
   const Outer o = outer_for(levels, 2);
   const int pos = levels == 2 ? 64 : 32;
-  const dim3 g((unsigned)(p_bs / pos), (unsigned)nparents);
-#define L_(G, P, T, AC) hipLaunchKernelGGL((scheme_up_kernel<G, P, T / P, AC>), g, dim3(T), 0, s, prod, p_bs, anc, o_stride, o_bs, crows, cw, o)
-  if (acc) SP_DISPATCH(levels, L_(4, 32, 256, true), L_(2, 32, 256, true), L_(1, 64, 64, true));
-  else SP_DISPATCH(levels, L_(4, 32, 256, false), L_(2, 32, 256, false), L_(1, 64, 64, false));
+  const int64_t leaves = gf2_scheme444_leaves(levels);
+  for (int64_t p0 = 0; p0 < nparents; p0 += MAX_GRID_Y) {
+    const int64_t np = nparents - p0 < MAX_GRID_Y ? nparents - p0 : MAX_GRID_Y;
+    const word *pr = prod + p0 * leaves * p_bs;
+    word *an       = anc + p0 * o_bs;
+    const dim3 g((unsigned)(p_bs / pos), (unsigned)np);
+#define L_(G, P, T, AC) hipLaunchKernelGGL((scheme_up_kernel<G, P, T / P, AC>), g, dim3(T), 0, s, pr, p_bs, an, o_stride, o_bs, crows, cw, o)
+    if (acc) SP_DISPATCH(levels, L_(4, 32, 256, true), L_(2, 32, 256, true), L_(1, 64, 64, true));
+    else SP_DISPATCH(levels, L_(4, 32, 256, false), L_(2, 32, 256, false), L_(1, 64, 64, false));
 #undef L_
+  }
   return hipGetLastError();
 }

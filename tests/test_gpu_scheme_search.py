@@ -63,7 +63,7 @@ def test_the_host_walks_find_rank_23_for_3x3x3():
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-O2", "-pthread", "-DN=3", os.path.join(ROOT, "tools", "flipgraph_444.c"), "-o", exe], check=True, timeout=120)
     # 2 threads, at most 60 s, target 23, from the standard algorithm, no checkpoints, path limit 1e6, no plus transitions, general reduction
-    out = subprocess.run([exe, "2", "60", "23", "x", "/dev/null", "/dev/null", "1000000", "0", "1", "3", "1", "0"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "2", "60", "23", "x", "none", "none", "1000000", "0", "1", "3", "1", "0"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout[-1500:]
     blocks = re.split(r"^# rank (\d+) after.*$", out.stdout, flags=re.M)
     assert int(blocks[-2]) == 23

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 
 #define MAXR 64
@@ -239,7 +240,8 @@ static void *walk(void *arg) {
     Scheme cur;
     pthread_mutex_lock(&g_mu);
     int lvl = working_level();
-    if ((rng_next(&rng) & 3) == 0) lvl = g_best.r;
+    // (report() publishes a new best rank before the walk that found it has put it into its pool: until then that pool may be empty)
+    if ((rng_next(&rng) & 3) == 0 && g_count[g_best.r]) lvl = g_best.r;
     int q0 = 0;
     if (g_quality) {
       for (int tries = 0; tries < 16; ++tries) {
@@ -343,8 +345,17 @@ static void standard(Scheme *s) {  // the definition: a_ij b_jk -> c_ik, rank 64
   }
 }
 
+// A checkpoint path that must not be used: absent, "none" / "-" (as the GPU tool takes them), or something that exists and is not a
+// regular file -- checkpoint() renames a temporary over its path, which as root would REPLACE a device node such as /dev/null by a file
+static int usable_path(const char *path) {
+  if (!path || !path[0] || !strcmp(path, "none") || !strcmp(path, "-")) return 0;
+  struct stat sb;
+  if (stat(path, &sb) == 0 && !S_ISREG(sb.st_mode)) return 0;
+  return 1;
+}
+
 static void checkpoint(const char *path) {   // the pools of the three lowest ranks reached, one scheme per line (rank, then its tensors)
-  if (!path) return;
+  if (!usable_path(path)) return;
   char tmp[512];
   snprintf(tmp, sizeof tmp, "%s.tmp", path);
   pthread_mutex_lock(&g_mu);
@@ -380,7 +391,7 @@ int main(int argc, char **argv) {
   g_pool[g_best.r][0] = g_best;
   g_q[g_best.r][0] = quality(&g_best);
   g_count[g_best.r] = 1;
-  if (argc > 6) {   // resume from a checkpoint
+  if (argc > 6 && usable_path(argv[6])) {   // resume from a checkpoint
     FILE *fi = fopen(argv[6], "r");
     int r;
     while (fi && fscanf(fi, "%d", &r) == 1 && r >= 1 && r <= 64) {
