@@ -241,6 +241,13 @@ int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride
  * (no Strassen levels): for the many small equal products of a blocked algorithm. */
 int m4ri_amd_m4rm_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
                             int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, void *stream);
+/* `batch` independent products of one shape WITH the Strassen-Winograd levels of m4ri_amd_mul_dev, every pass and the leaf launch
+ * shared by the whole batch (what the ranks of a sharded Strassen level use for the several sub-products each of them owns,
+ * multi.hip; the sub-products of strassen.c:111-150 are independent).  Bit-identical to `batch` calls of m4ri_amd_mul_dev. */
+int m4ri_amd_mul_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
+                           int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, int cutoff, void *stream);
+/* the time model's estimate for `batch` products m x l x n scheduled as one at `levels` levels (pure host arithmetic) */
+double m4ri_amd_model_seconds_batch(int64_t m, int64_t l, int64_t n, int levels, int64_t batch);
 /* C = A ^ B on rows x ncols bits: the device twin of _mzd_add (mzd.c:1471-1583).  In-place allowed,
  * operands may have different strides; the last word of every row is written under the column mask
  * and the other bits of C's last word are kept (mzd.c:1489). */
@@ -406,7 +413,8 @@ int m4ri_amd_is_pinned(const mzd_t *M);/* 0 no, 1 yes and host copy current, 2 y
  * additions are ordinary local passes and only slabs of sub-product operands (one way) and of products
  * (the other) cross the links, every rank to every rank.  Dimensions are zero-padded (M, L, N). */
 typedef struct m4ri_amd_shard_plan {
-  int32_t world, levels, nprod, blocks; /* ranks; sharded levels (1|2); 7^levels; 2^levels              */
+  int32_t world, levels, nprod, blocks; /* ranks; sharded levels (1|2); sub-products: 7, 49 or -- two levels as ONE application of the
+                                           rank-R scheme of the 4 x 4 x 4 block product, where its passes take the slabs -- R = 47; 2^levels */
   int64_t m, l, n;                      /* the product C (m x n) = A (m x l) * B (l x n)                */
   int64_t M, L, N;                      /* padded: M % blocks == 0, L and N % (64*blocks) == 0          */
   int64_t bm, bl;                       /* rows of a sub-product's A operand (= of its result), of its B */
@@ -499,6 +507,7 @@ typedef struct m4ri_amd_multi_stats {
                                                 /* ordered rank pairs that copy through the host (no peer access)           */
   int64_t m, l, n;
   double link_bytes;                            /* bytes that crossed between ranks                                          */
+  int32_t group, reserved;                      /* Strassen schedule: sub-products of a rank multiplied as one batched product */
 } m4ri_amd_multi_stats;
 int m4ri_amd_multi_get_stats(m4ri_amd_multi_stats *out);
 /* Marks of rank `rank`'s part of the most recent m4ri_amd_dmat_mul, ms after its compute stream entered the operation

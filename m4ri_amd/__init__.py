@@ -77,7 +77,8 @@ class MultiStats(ctypes.Structure):
 
     _fields_ = [("world", ctypes.c_int32), ("variant", ctypes.c_int32), ("levels", ctypes.c_int32), ("sub_products", ctypes.c_int32),
                 ("chunks", ctypes.c_int32), ("overlap", ctypes.c_int32), ("converted", ctypes.c_int32), ("pairs_staged", ctypes.c_int32),
-                ("m", ctypes.c_int64), ("l", ctypes.c_int64), ("n", ctypes.c_int64), ("link_bytes", ctypes.c_double)]
+                ("m", ctypes.c_int64), ("l", ctypes.c_int64), ("n", ctypes.c_int64), ("link_bytes", ctypes.c_double),
+                ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 (LAYOUT_ROWS, LAYOUT_CYCLIC1, LAYOUT_CYCLIC2, LAYOUT_REPLICATED) = range(4)
@@ -168,6 +169,8 @@ SYMBOLS = {
     "mzd_trtri_upper_russian": (MzdPtr, [MzdPtr, _I]),
     "m4ri_amd_transpose_dev": (_I, [_P, _I64, _P, _I64, _I64, _I64, _P]),
     "m4ri_amd_m4rm_batch_dev": (_I, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "m4ri_amd_mul_batch_dev": (_I, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I, _P]),
+    "m4ri_amd_model_seconds_batch": (ctypes.c_double, [_I64, _I64, _I64, _I, _I64]),
     "m4ri_amd_trtri_upper_dev": (_I, [_P, _I64, _I64, _P]),
     "m4ri_amd_echelonize_dev": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
     "m4ri_amd_apply_p_right_dev": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I, _P]),
@@ -448,6 +451,18 @@ def mul_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int,
             add: bool = False, cutoff: int = 0, stream: int = 0) -> None:
     """C (+)= A*B on device pointers (ints), Strassen-Winograd over batched M4RM leaves."""
     _check(lib().m4ri_amd_mul_dev(C, c_stride, A, a_stride, B, b_stride, m, l, n, int(add), cutoff, stream), "m4ri_amd_mul_dev")
+
+
+def mul_batch_dev(C: int, c_stride: int, c_bs: int, A: int, a_stride: int, a_bs: int, B: int, b_stride: int, b_bs: int, m: int, l: int, n: int,
+                  batch: int, add: bool = False, cutoff: int = 0, stream: int = 0) -> None:
+    """`batch` products of one shape, X_b = X + b * x_bs words, with the levels of mul_dev and every launch shared by the batch."""
+    _check(lib().m4ri_amd_mul_batch_dev(C, c_stride, c_bs, A, a_stride, a_bs, B, b_stride, b_bs, m, l, n, batch, int(add), cutoff, stream),
+           "m4ri_amd_mul_batch_dev")
+
+
+def model_seconds_batch(m: int, l: int, n: int, levels: int = -1, batch: int = 1) -> float:
+    """The engine's time model for `batch` products scheduled as one (levels < 0: at the depth the model picks). Host arithmetic."""
+    return float(lib().m4ri_amd_model_seconds_batch(m, l, n, levels, batch))
 
 
 def m4rm_dev(C: int, c_stride: int, A: int, a_stride: int, B: int, b_stride: int, m: int, l: int, n: int,

@@ -464,7 +464,7 @@ bool closer(int64_t a, int64_t cutoff) { return 3 * a < 4 * cutoff; }  // strass
 //   strips       the three thin products around the even block, the inner one as a read-modify-write of C
 // The constants are one box's; only the ORDER of the depths matters, and that is set by ratios that move together.
 // Pure host arithmetic (m4ri_amd_plan_levels; tests/test_host_logic.py pins the table).
-double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
+double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L, double batch = 1.0) {  // `batch` products of this shape scheduled as one
   // (an unsplit product has no strips: the leaf takes any l and n as they are)
   const int64_t mm = m >> L, ll = L ? (l / (64ll << L)) * 64 : l, nn = L ? (n / (64ll << L)) * 64 : n;
   if (mm == 0 || ll == 0 || nn == 0) return 1e30;
@@ -482,7 +482,7 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
     }
     return tiles * units / CUS * UNIT * 1.08 + 45e-6;  // (+ the pack, the split's reduce pass)
   };
-  double p7 = 1;
+  double p7 = batch;
   for (int d = 0; d < L; ++d) p7 *= 7;
   // the fused bottom levels run through the rank-R 4 x 4 x 4 scheme where the leaves allow it: R, 7 R or R^2 products instead of 7^2, 7^3, 7^4
   const int mfuse = L < g_max_fuse ? L : g_max_fuse;
@@ -498,9 +498,9 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
   double factor = 0;
   for (int d = 0; d < L - fuse; ++d) factor += r(d) + r(d + 1);
   if (L > 0) factor += r(L - fuse) + r(L) * srat;
-  double bytes = (sa + sb + sc) * factor;
-  if (L < 2 || (mm % 32) != 0 || (words_of(ll) % 16) != 0) bytes += 2.0 * sa * r(L);  // the separate pack pass of A: no fused form below two levels or for such leaves
-  if (fuse == 4 && (words_of(nn) % 32) != 0) bytes += sc * (r(L) + 1);  // atomic up pass: zeroed output, children folded by read-modify-write
+  double bytes = (sa + sb + sc) * factor * batch;
+  if (L < 2 || (mm % 32) != 0 || (words_of(ll) % 16) != 0) bytes += 2.0 * sa * r(L) * batch;  // the separate pack pass of A: no fused form below two levels or for such leaves
+  if (fuse == 4 && (words_of(nn) % 32) != 0) bytes += sc * (r(L) + 1) * batch;  // atomic up pass: zeroed output, children folded by read-modify-write
   const int launches = 3 * ((L - fuse > 0 ? L - fuse : 0) + (L > 0 ? 1 : 0)) + 1;
   t += bytes / BW + launches * LAUNCH;
   // strips of a ragged shape: columns beyond the even block, inner bits beyond it (C read and written once more), rows beyond it
@@ -512,15 +512,15 @@ double depth_model_seconds(int64_t m, int64_t l, int64_t n, int L) {
 }
 
 // depth of ONE product of these dimensions by the model (cutoff == 0)
-int model_levels(int64_t m, int64_t l, int64_t n, double *seconds) {
+int model_levels(int64_t m, int64_t l, int64_t n, double *seconds, double batch = 1.0) {
   int L = 0;
   // every depth whose leaves keep a whole tile of rows (half-filled tiles cost whole ones: 16384 x 65536 x 65536 takes 8.6 ms with
   // leaves of 4096 rows and 12.3 ms with 2048); a deeper one has to win by 1 %
   // ... and 1024 inner bits and columns: below that no shape of the sweeps gained (65536 x 4096 x 65536 with leaves of 512 inner
   // bits: 3.02 against 2.67 ms), and the model is not trusted where per-launch constants decide
-  double best = depth_model_seconds(m, l, n, 0);
+  double best = depth_model_seconds(m, l, n, 0, batch);
   for (int d = 1; d <= MAX_LEVELS && (m >> d) >= DEFAULT_CUTOFF_M && (l >> d) >= 1024 && (n >> d) >= 1024; ++d) {
-    const double t = depth_model_seconds(m, l, n, d);
+    const double t = depth_model_seconds(m, l, n, d, batch);
     if (t < 0.99 * best) { best = t; L = d; }
   }
   if (seconds) *seconds = best;
@@ -584,7 +584,10 @@ int plan_levels(int64_t m, int64_t l, int64_t n, int cutoff) {
 
 // breadth-first Strassen-Winograd on the even block: C (m x n) (+)= A (m x l) * B (l x n), with
 // m % 2^L == 0 and l, n % (64 * 2^L) == 0.
-int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra) {
+// `batch` > 1: that many independent products of one shape, X_b = X + b * x_bs words, through the SAME launches (every pass takes
+// a count of parents, the leaf launch a count of products): what fills the chip when one product's leaves do not.
+int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int L, size_t a7_extra, int64_t batch = 1,
+                int64_t c_bs = 0, int64_t a_bs = 0, int64_t b_bs = 0) {
   const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
   // The deepest levels are done by ONE fused pass each way: up to four of them (g_max_fuse), whose
   // intermediate levels are never materialised -- that saves their buffers and a write + a read of
@@ -599,7 +602,8 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // scheme kernels take; everything else keeps the Winograd passes.
   const int64_t leaf_m = m >> L, leaf_l = l >> L, leaf_n = n >> L;
   const bool scheme = scheme_applies(fuse, leaf_m, leaf_l, leaf_n);
-  const int64_t leaves = scheme ? ipow7(L - fuse) * gf2_scheme444_leaves(fuse) : ipow7(L);  // products of the leaf launch
+  const int64_t leaves1 = scheme ? ipow7(L - fuse) * gf2_scheme444_leaves(fuse) : ipow7(L);  // leaf products of ONE product
+  const int64_t leaves  = batch * leaves1;                                                      // products of the leaf launch
   bool prepack = scheme;
   if (!scheme && fuse >= 2 && leaf_kind.gen == 4) {
     static const word aligned16[2] __attribute__((aligned(16))) = {0, 0};
@@ -609,19 +613,20 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
     const uint64_t a4_bytes = (uint64_t)gf2_m4rm8_a4_words(m >> L, l >> L, 1) * 8;  // one packed operand: 32-bit offsets
     prepack = a4_bytes < (1ull << 32) &&
               (fuse >= 3 ? gf2_winograd_down3_pack_ok(aligned16, m >> L, (l >> L) / 64) != 0
-                         : gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? 0 : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0);
+                         : gf2_winograd_down2_pack_ok(pa, pas, d0 == 0 ? a_bs : (m >> d0) * pas, aligned16, m >> L, (l >> L) / 64) != 0);
   }
   // workspace plan
   size_t need = 0;
   auto pad = [](size_t w) { return (w + 31) & ~(size_t)31; };
   for (int d = 1; d <= L; ++d) {
     if (!materialised(d)) continue;
-    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : ipow7(d);
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : batch * ipow7(d);
     need += (prepack && d == L ? 0 : pad((size_t)cnt * md * wl)) + pad((size_t)cnt * (l >> d) * wnn) + pad((size_t)cnt * md * wnn);
   }
   // C += A*B through a three-level up pass: the pass writes a temporary and one XOR pass folds it into
   // C (the accumulating three-level kernel needs > 256 registers per lane and runs at a quarter of the rate)
   const bool acc_via_tmp = add && fuse == 3 && L == 3 && !scheme;
+  if (acc_via_tmp && batch > 1) return (int)hipErrorInvalidValue;  // (engine_mul_batch sends such a batch one product at a time)
   if (acc_via_tmp) need += pad((size_t)m * (n / 64));
   {
     const size_t a7_bfs = packed_a_words(m >> L, l >> L, leaves);
@@ -636,7 +641,7 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   if (prepack && !packed_a_fits(e, leaf_kind, m >> L, l >> L, leaves)) return (int)hipErrorInvalidValue;  // cannot happen: a7_extra covers it
   for (int d = 1; d <= L; ++d) {
     if (!materialised(d)) continue;
-    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : ipow7(d);
+    const int64_t md = m >> d, wl = (l >> d) / 64, wnn = (n >> d) / 64, cnt = d == L ? leaves : batch * ipow7(d);
     if (!(prepack && d == L)) Al[d] = ws_take(e, (size_t)cnt * md * wl);
     Bl[d] = ws_take(e, (size_t)cnt * (l >> d) * wnn);
     Pl[d] = ws_take(e, (size_t)cnt * md * wnn);
@@ -646,12 +651,12 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   // down passes: level d -> d+1, and d -> L for the fused pass at the bottom
   for (int d = 0; d < L;) {
     const int step    = d == L - fuse ? fuse : 1;
-    const int64_t cnt = ipow7(d);
+    const int64_t cnt = batch * ipow7(d);
     const int64_t cm = m >> (d + step), cl = l >> (d + step), cn = n >> (d + step);
     const word *pa = d == 0 ? A.p : Al[d];
-    const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? 0 : (m >> d) * pas;
+    const int64_t pas = d == 0 ? A.stride : (l >> d) / 64, pabs = d == 0 ? a_bs : (m >> d) * pas;
     const word *pb = d == 0 ? B.p : Bl[d];
-    const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? 0 : (l >> d) * pbs;
+    const int64_t pbs = d == 0 ? B.stride : (n >> d) / 64, pbbs = d == 0 ? b_bs : (l >> d) * pbs;
     const int rot = leaf_kind.gen == 4 ? 1 : 0;  // the leaf's pre-rotated index bytes (pack mode)
     if (scheme && step == fuse && step >= 2) {  // the fused bottom levels through the 4 x 4 x 4 scheme, one pass each way (scheme_passes.hip)
       const double rr = (double)gf2_scheme444_leaves(step), blocks = (double)(1 << (2 * step));
@@ -712,11 +717,11 @@ int bfs_product(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int
   for (int d = L; d > 0;) {
     const int step    = d == L ? fuse : 1;
     const int dst     = d - step;
-    const int64_t cnt = ipow7(dst);
+    const int64_t cnt = batch * ipow7(dst);
     const int64_t cm = m >> d, cn = n >> d;
     word *out          = dst == 0 ? C.p : Pl[dst];
     const int64_t ostr = dst == 0 ? C.stride : (n >> dst) / 64;
-    const int64_t obs  = dst == 0 ? 0 : (m >> dst) * ostr;
+    const int64_t obs  = dst == 0 ? c_bs : (m >> dst) * ostr;
     const int acc      = (dst == 0 && add) ? 1 : 0;
     if (scheme && step == fuse && step >= 2) {
       const double rr = (double)gf2_scheme444_leaves(step), blocks = (double)(1 << (2 * step));
@@ -902,6 +907,45 @@ int engine_mul(Engine *e, hipStream_t st, DMat C, DMat A, DMat B, bool add, int 
   return 0;
 }
 
+// `batch` products of ONE shape, X_b = X + b * x_bs words: scheduled as one product with `batch` times the parents in every pass and
+// `batch` times the products in the leaf launch (bfs_product), at the depth the model picks for the batch.  What does not fit that
+// form -- a ragged shape (remainder strips), a workspace beyond the budget, rows worth cutting into blocks -- goes one product at a
+// time through engine_mul: same bits either way.
+int engine_mul_batch(Engine *e, hipStream_t st, DMat C, int64_t c_bs, DMat A, int64_t a_bs, DMat B, int64_t b_bs, int64_t batch, bool add, int cutoff) {
+  const int64_t m = A.nrows, l = A.ncols, n = B.ncols;
+  if (m == 0 || n == 0 || batch <= 0) return 0;
+  auto one_by_one = [&]() {
+    for (int64_t b = 0; b < batch; ++b) {
+      DMat c = C, a = A, bb = B;
+      c.p += b * c_bs; a.p += b * a_bs; bb.p += b * b_bs;
+      if (int rc = engine_mul(e, st, c, a, bb, add, cutoff)) return rc;
+    }
+    return 0;
+  };
+  if (batch == 1 || l == 0) return one_by_one();
+  int L = 0;
+  if (cutoff == 0 && !getenv("M4RI_AMD_LEVELS")) {
+    L = model_levels(m, l, n, nullptr, (double)batch);
+    std::vector<RowBlock> blocks;
+    plan_row_blocks(m, l, n, blocks);
+    if (blocks.size() != 1) return one_by_one();  // rows in blocks: a single product's business
+  } else {
+    L = plan_levels(m, l, n, cutoff);
+  }
+  while (L > 0 && ((m >> L) == 0 || (l / (64ll << L)) == 0 || (n / (64ll << L)) == 0)) --L;
+  if (L > 0 && (m % (1ll << L) != 0 || l % (64ll << L) != 0 || n % (64ll << L) != 0)) return one_by_one();  // strips
+  if (L > 0 && (double)bfs_words_bound(m, l, n, L) * 8.0 * (double)batch > workspace_budget(e)) return one_by_one();
+  const int fuse = L < g_max_fuse ? L : g_max_fuse;
+  if (add && fuse == 3 && L == 3 && !scheme_applies(fuse, m >> L, l >> L, n >> L)) return one_by_one();  // (the accumulate temporary is one product's)
+  e->stats.levels = L;
+  e->df_used = 0;
+  if (L == 0) {
+    if (int rc = reserve_apk(e, packed_a_words(m, l, batch))) return rc;
+    return launch_leaf(e, st, C.p, C.stride, c_bs, A.p, A.stride, a_bs, B.p, B.stride, b_bs, m, l, n, batch, add, 0);
+  }
+  return bfs_product(e, st, C, A, B, add, L, 0, batch, c_bs, a_bs, b_bs);
+}
+
 void reset_stats(Engine *e) {
   const double ws = (double)e->ws_cap * 8.0;
   // keep un-read profiling events out of the next call's sum (cumulative mode keeps them for the total)
@@ -958,6 +1002,23 @@ int m4ri_amd_mul_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride,
   return mark_done(e, (hipStream_t)stream);
 }
 
+// `batch` independent products of one shape, C_b (+)= A_b * B_b with X_b = X + b * x_bs words, with the Strassen-Winograd levels of
+// m4ri_amd_mul_dev and every launch shared by the whole batch: several sub-products of a sharded level on one rank (multi.hip)
+// fill the chip together where each alone leaves its last round of tiles half empty.  Same bits as `batch` calls of m4ri_amd_mul_dev.
+int m4ri_amd_mul_batch_dev(word *C, int64_t c_stride, int64_t c_bs, const word *A, int64_t a_stride, int64_t a_bs, const word *B,
+                           int64_t b_stride, int64_t b_bs, int64_t m, int64_t l, int64_t n, int64_t batch, int add, int cutoff, void *stream) {
+  EngineLock el;
+  Engine *e = el.e;
+  if (!e || cutoff < 0 || m < 0 || l < 0 || n < 0 || batch < 0) return (int)hipErrorInvalidValue;
+  if (batch == 0) return 0;
+  reset_stats(e);
+  if (cutoff > 0) { cutoff = cutoff / 64 * 64; if (cutoff < 64) cutoff = 64; }  // strassen.c:351-354
+  DMat dC{C, m, n, c_stride}, dA{const_cast<word *>(A), m, l, a_stride}, dB{const_cast<word *>(B), l, n, b_stride};
+  if (int rc = order_after_previous(e, (hipStream_t)stream)) return rc;
+  if (int rc = engine_mul_batch(e, (hipStream_t)stream, dC, c_bs, dA, a_bs, dB, b_bs, batch, add != 0, cutoff)) return rc;
+  return mark_done(e, (hipStream_t)stream);
+}
+
 int m4ri_amd_m4rm_dev(word *C, int64_t c_stride, const word *A, int64_t a_stride, const word *B,
                       int64_t b_stride, int64_t m, int64_t l, int64_t n, int add, int ksplit, void *stream) {
   EngineLock el;
@@ -1005,6 +1066,13 @@ int m4ri_amd_mask_tail_dev(word *M, int64_t stride, int64_t rows, int64_t ncols,
 double m4ri_amd_model_seconds(int64_t m, int64_t l, int64_t n, int levels) {
   if (m <= 0 || l <= 0 || n <= 0 || levels < 0 || levels > MAX_LEVELS) return 0.0;
   return depth_model_seconds(m, l, n, levels);
+}
+
+// levels < 0: the depth the model itself picks for the batch
+double m4ri_amd_model_seconds_batch(int64_t m, int64_t l, int64_t n, int levels, int64_t batch) {
+  if (m <= 0 || l <= 0 || n <= 0 || levels > MAX_LEVELS || batch < 1) return 0.0;
+  if (levels < 0) { double t = 0; model_levels(m, l, n, &t, (double)batch); return t; }
+  return depth_model_seconds(m, l, n, levels, (double)batch);
 }
 
 int m4ri_amd_plan_row_blocks(int64_t m, int64_t l, int64_t n, int64_t *rows, int *levels, int cap) {

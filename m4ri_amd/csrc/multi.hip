@@ -53,6 +53,13 @@ hipError_t gf2_launch_winograd_down2(hipStream_t s, int bside, const word *gpare
 hipError_t gf2_launch_winograd_up2(hipStream_t s, int acc, const word *prod, word *gparent, int64_t o_stride, int64_t o_bs,
                                    int64_t nparents, int64_t crows, int64_t cw);
 hipError_t gf2_launch_mask_tail(hipStream_t s, word *M, int64_t stride, int64_t rows, int64_t ncols);
+// the rank-R scheme of the 4 x 4 x 4 block product (scheme_passes.hip): two sharded levels = the scheme once, R sub-products instead of 49
+int gf2_scheme444_rank(void);
+int gf2_scheme444_ok(int levels, int64_t a_rows, int64_t a_cw, int64_t b_rows, int64_t b_cw);
+hipError_t gf2_launch_scheme_down(hipStream_t s, int levels, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *child, int64_t nparents,
+                                  int64_t crows, int64_t cw);
+hipError_t gf2_launch_scheme_up(hipStream_t s, int levels, int acc, const word *prod, word *anc, int64_t o_stride, int64_t o_bs, int64_t nparents,
+                                int64_t crows, int64_t cw);
 }
 
 namespace {
@@ -66,6 +73,20 @@ namespace {
 int64_t cut_of(int64_t rows, int world, int r) { return rows * (int64_t)r / (int64_t)world; }
 int64_t roundup(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 int64_t pad32(int64_t w) { return (w + 31) & ~(int64_t)31; }  // 256-byte granules
+
+// Sub-products of `levels` sharded levels.  Two levels are ONE application of the rank-R scheme for the 4 x 4 x 4 block product where
+// its passes take the slabs (row-major children on both sides: whole 64-word groups per child row, no empty slab) and R < 49: R = 47
+// sub-products instead of Strassen-Winograd's 49 -- on 8 ranks 6 rounds instead of 7.  Every rank must come to the same answer: the
+// rule only looks at the plan.
+int nprod_of(int world, int levels, int64_t bm, int64_t bl, int64_t cwl, int64_t cwn) {
+  if (levels != 2) return 7;
+  const int R = gf2_scheme444_rank();
+  if (R >= 49 || cwl % 64 != 0 || cwn % 64 != 0 || bm < world || bl < world) return 49;
+  if (!gf2_scheme444_ok(2, 64, cwl, 64, cwn)) return 49;  // (the M4RI_AMD_SCHEME switch; the passes' own 32-bit index limits)
+  if ((bm / world + 1) * cwl > 0x3fffffffLL || (bl / world + 1) * cwn > 0x3fffffffLL) return 49;
+  return R;
+}
+bool plan_uses_scheme(const m4ri_amd_shard_plan *p) { return p->levels == 2 && p->nprod != 49; }
 
 int owned_count(const m4ri_amd_shard_plan *p, int rank) {
   return rank < p->nprod ? (p->nprod - rank + p->world - 1) / p->world : 0;
@@ -82,16 +103,17 @@ int m4ri_amd_shard_owner(const m4ri_amd_shard_plan *p, int j) { return j % p->wo
 int m4ri_amd_shard_plan_make(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n, int levels) {
   if (!p || world < 1 || m <= 0 || l <= 0 || n <= 0 || levels < 0 || levels > 2) return -1;
   if (levels == 0) {
-    // fewest "rounds" of sub-products on the busiest rank, as a fraction of the whole: ceil(7^v / W) / 7^v;
-    // the second level only when it wins and its sub-products stay large (>= 2048 on every side)
-    const double f1 = (double)((7 + world - 1) / world) / 7.0, f2 = (double)((49 + world - 1) / world) / 49.0;
+    // fewest "rounds" of sub-products on the busiest rank, as a fraction of the whole: ceil(P / W) / P with P = 7 or the second
+    // level's count (49, or the scheme's 47); the second level only when it wins and its sub-products stay large (>= 2048 on every side)
+    const int64_t M4 = roundup(m, 4), L4 = roundup(l, 256), N4 = roundup(n, 256);
+    const int np2   = nprod_of(world, 2, M4 / 4, L4 / 4, L4 / 256, N4 / 256);
+    const double f1 = (double)((7 + world - 1) / world) / 7.0, f2 = (double)((np2 + world - 1) / world) / (double)np2;
     levels = (f2 < f1 - 1e-9 && m / 4 >= 2048 && l / 4 >= 2048 && n / 4 >= 2048) ? 2 : 1;
   }
   memset(p, 0, sizeof *p);
   p->world  = world;
   p->levels = levels;
   p->blocks = 1 << levels;
-  p->nprod  = levels == 2 ? 49 : 7;
   p->m = m; p->l = l; p->n = n;
   p->M = roundup(m, p->blocks);
   p->L = roundup(l, 64ll * p->blocks);
@@ -100,6 +122,7 @@ int m4ri_amd_shard_plan_make(m4ri_amd_shard_plan *p, int world, int64_t m, int64
   p->bl  = p->L / p->blocks;
   p->cwl = p->L / p->blocks / 64;
   p->cwn = p->N / p->blocks / 64;
+  p->nprod = nprod_of(world, levels, p->bm, p->bl, p->cwl, p->cwn);
   return 0;
 }
 
@@ -151,6 +174,9 @@ int m4ri_amd_shard_down_dev(const m4ri_amd_shard_plan *p, int rank, const word *
   if (p->levels == 1) {
     if (A_local) HIPTRY(gf2_launch_winograd_down(st, 0, A_local, a_stride, 0, child_a, 1, sa, p->cwl));
     if (B_local) HIPTRY(gf2_launch_winograd_down(st, 1, B_local, b_stride, 0, child_b, 1, sb, p->cwn));
+  } else if (plan_uses_scheme(p)) {
+    if (A_local && sa > 0) HIPTRY(gf2_launch_scheme_down(st, 2, 0, A_local, a_stride, 0, child_a, 1, sa, p->cwl));
+    if (B_local && sb > 0) HIPTRY(gf2_launch_scheme_down(st, 2, 1, B_local, b_stride, 0, child_b, 1, sb, p->cwn));
   } else {
     if (A_local) HIPTRY(gf2_launch_winograd_down2(st, 0, A_local, a_stride, 0, child_a, 1, sa, p->cwl));
     if (B_local) HIPTRY(gf2_launch_winograd_down2(st, 1, B_local, b_stride, 0, child_b, 1, sb, p->cwn));
@@ -165,6 +191,7 @@ int m4ri_amd_shard_up_dev(const m4ri_amd_shard_plan *p, int rank, const word *sl
   hipStream_t st = (hipStream_t)stream;
   const int64_t sa = m4ri_amd_shard_slab_rows(p, rank, 0);
   if (p->levels == 1) HIPTRY(gf2_launch_winograd_up(st, add ? 1 : 0, slabs_p, C_local, c_stride, 0, 1, sa, p->cwn));
+  else if (plan_uses_scheme(p)) { if (sa > 0) HIPTRY(gf2_launch_scheme_up(st, 2, add ? 1 : 0, slabs_p, C_local, c_stride, 0, 1, sa, p->cwn)); }
   else HIPTRY(gf2_launch_winograd_up2(st, add ? 1 : 0, slabs_p, C_local, c_stride, 0, 1, sa, p->cwn));
   return 0;
 }
@@ -924,6 +951,7 @@ struct StrassenOp {
   m4ri_amd_shard_plan p;
   int add, cutoff, chunks;
   int64_t seq;
+  int group;  // rounds per batched product: the sub-products a rank owns are multiplied `group` at a time (m4ri_amd_mul_batch_dev)
 };
 
 // row chunk c of a sub-product = the slabs of ranks [lo, hi): rows [cut(lo), cut(hi)) of its A operand and of its result
@@ -974,7 +1002,30 @@ int strassen_rank(const StrassenOp &op, int me, const OpCtx &ctx) {
                       R.lin[(size_t)r]);
   };
   int units = 0;
-  for (int q = 0; q < rounds; ++q) {
+  const int G = (nch == 1 && op.group > 1) ? op.group : 1;
+  for (int q = 0; q < rounds && G > 1; q += G) {
+    // `G` of my sub-products at a time, as ONE batched product: every pass and the leaf launch shared, so that sub-products whose own
+    // leaves leave the chip's last round of tiles half empty fill it together (6 x 16384^3 on a rank of 8: 9 rounds of tiles, not 12).
+    // The operands of group g + 1 travel while group g is multiplied.
+    int cnt = 0;
+    for (int k = 0; k < G && q + k < rounds; ++k)
+      if ((q + k) * W + me < p.nprod) ++cnt;
+    if (cnt == 0) break;
+    for (int k = 0; k < cnt; ++k) {
+      const int j = (q + k) * W + me;
+      for (int x = 0; x < W; ++x) RTRY(pull_operand(1, j, (me + x) % W));  // own slab first
+      for (int x = 0; x < W; ++x) RTRY(pull_operand(0, j, (me + x) % W));
+    }
+    RTRY(join_links(R, true));
+    RTRY(hipEventRecord(R.ev_in[(size_t)units], R.ci));
+    RTRY(hipStreamWaitEvent(R.st, R.ev_in[(size_t)units], 0));
+    RTRY(m4ri_amd_mul_batch_dev(R.buf[B_PROD] + (int64_t)q * p.bm * p.cwn, p.cwn, p.bm * p.cwn, R.buf[B_OPER_A] + (int64_t)q * p.bm * p.cwl, p.cwl, p.bm * p.cwl,
+                                R.buf[B_OPER_B] + (int64_t)q * p.bl * p.cwn, p.cwn, p.bl * p.cwn, p.bm, p.bl, p.cwn * 64, cnt, 0, op.cutoff, R.st));
+    RTRY(hipEventRecord(R.ev_prod[(size_t)units], R.st));
+    R.flag_prod.store(op.seq * 4096 + units + 1, std::memory_order_release);
+    ++units;
+  }
+  for (int q = 0; q < rounds && G == 1; ++q) {
     const int j = q * W + me;
     if (j >= p.nprod) break;
     for (int c = 0; c < nch; ++c, ++units) {
@@ -1008,7 +1059,7 @@ int strassen_rank(const StrassenOp &op, int me, const OpCtx &ctx) {
     m4ri_amd_shard_piece_of(&p, 2, j, me, &pc);
     if (pc.words == 0) continue;
     Rank &O     = *ranks[(size_t)pc.owner];
-    const int u = (j / W) * nch + myc;
+    const int u = G > 1 ? (j / W) / G : (j / W) * nch + myc;  // the owner's unit that holds it
     RTRY(wait_flag(O.flag_prod, op.seq * 4096 + u + 1));
     RTRY(hipStreamWaitEvent(R.lout[(size_t)pc.owner], O.ev_prod[(size_t)u], 0));
     RTRY(copy_words(R, me, W + pc.owner, R.buf[B_SLABS_P] + pc.holder_off, O.buf[B_PROD] + pc.owner_off, pc.owner, O.device, pc.words, R.lout[(size_t)pc.owner]));
@@ -1023,14 +1074,34 @@ int strassen_rank(const StrassenOp &op, int me, const OpCtx &ctx) {
   return op_end(R, ctx);
 }
 
+// How many of a rank's sub-products go into one batched product.  The engine's time model prices a batch of b sub-products
+// (m4ri_amd_model_seconds_batch: tiles in rounds of 256, so two half-filled last rounds become one full one); of the group sizes whose
+// total is within 2 % of the best the SMALLEST wins -- more groups = more of the operand and result transport under multiplications.
+// One sub-product per rank (7 on 8 ranks) or a caller's cutoff: no grouping.
+int pick_group(const m4ri_amd_shard_plan &p, int cutoff) {
+  const int rounds = (p.nprod + p.world - 1) / p.world;
+  if (rounds < 2 || cutoff != 0) return 1;
+  double cost[65], best = 1e300;
+  const int gmax = rounds < 64 ? rounds : 64;
+  for (int g = 1; g <= gmax; ++g) {
+    const int full = rounds / g, rest = rounds % g;
+    cost[g] = full * m4ri_amd_model_seconds_batch(p.bm, p.bl, p.cwn * 64, -1, g) + (rest ? m4ri_amd_model_seconds_batch(p.bm, p.bl, p.cwn * 64, -1, rest) : 0.0);
+    if (cost[g] < best) best = cost[g];
+  }
+  for (int g = 1; g <= gmax; ++g)
+    if (cost[g] <= 1.02 * best) return g;
+  return 1;
+}
+
 // the plan of a product on CYCLIC-v operands: every dimension padded to 256 bits (the layouts' own padding)
 void plan_for(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n, int levels) {
   memset(p, 0, sizeof *p);
-  p->world = world; p->levels = levels; p->blocks = 1 << levels; p->nprod = levels == 2 ? 49 : 7;
+  p->world = world; p->levels = levels; p->blocks = 1 << levels;
   p->m = m; p->l = l; p->n = n;
   p->M = padded(m); p->L = padded(l); p->N = padded(n);
   p->bm = p->M / p->blocks; p->bl = p->L / p->blocks;
   p->cwl = p->L / p->blocks / 64; p->cwn = p->N / p->blocks / 64;
+  p->nprod = nprod_of(world, levels, p->bm, p->bl, p->cwl, p->cwn);
 }
 
 // sharding.default_variant: row slabs up to 4 ranks (2 ranks share ONE link, which the Strassen exchange would saturate) and
@@ -1109,13 +1180,15 @@ int dmat_mul(m4ri_amd_dmat *C, const m4ri_amd_dmat *A, const m4ri_amd_dmat *B, i
     g_mstats.link_bytes = b->layout == M4RI_AMD_LAYOUT_ROWS ? 8.0 * (double)b->stride * (double)l * (double)(W - 1) : 0.0;
     rc = run_op(lane, false, [&](int me, const OpCtx &ctx) { return slabs_rank(op, me, ctx); });
   } else {
-    StrassenOp op{c, a, b, {}, add, cutoff, 1, g_seq};
+    StrassenOp op{c, a, b, {}, add, cutoff, 1, g_seq, 1};
     plan_for(&op.p, W, m, l, n, layout_levels(want));
     // two ROW chunks when one product per rank is all there is to hide transfers behind and its halves keep the engine's Strassen depth
     // (measured: two 16384 x 32768 x 32768 halves cost 1.00 - 1.03 of the whole, profiles/r03_rank_shapes_timing.log)
     op.chunks = (op.p.levels == 1 && op.p.bm >= 4 * 4096 && W >= 2) ? 2 : 1;
     if (const char *env = getenv("M4RI_AMD_MULTI_CHUNKS")) { const int v = atoi(env); if (v >= 1 && v <= W && v <= 16) op.chunks = v; }
-    g_mstats.levels = op.p.levels; g_mstats.sub_products = op.p.nprod; g_mstats.chunks = op.chunks;
+    op.group = op.chunks == 1 ? pick_group(op.p, cutoff) : 1;
+    if (const char *env = getenv("M4RI_AMD_MULTI_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 64 && op.chunks == 1) op.group = v; }
+    g_mstats.levels = op.p.levels; g_mstats.sub_products = op.p.nprod; g_mstats.chunks = op.chunks; g_mstats.group = op.group;
     double moved = 0;
     for (int side = 0; side < 3; ++side)
       for (int j = 0; j < op.p.nprod; ++j)

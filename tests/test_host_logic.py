@@ -116,9 +116,10 @@ def test_schedule_choice_in_c_matches_the_python_rule():
         for shape in [(65536, 65536, 65536), (131072, 8192, 131072), (16384, 16384, 16384), (8192, 65536, 65536), (65536, 16384, 8192),
                       (100003, 50021, 70017), (8190, 16384, 8192)]:
             assert names[m4ri_amd.multi_default_variant(world, *shape)] == sharding.default_variant(world, *shape), (world, shape)
-    assert m4ri_amd.multi_layout_for(0, 8, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC1
+    assert m4ri_amd.multi_layout_for(0, 8, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC2   # 47 sub-products (the scheme once) over 8 ranks: 6 rounds
+    assert m4ri_amd.multi_layout_for(0, 7, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC1   # 7 sub-products, one per rank
     assert m4ri_amd.multi_layout_for(0, 8, 131072, 8192, 131072) == m4ri_amd.LAYOUT_ROWS
-    assert m4ri_amd.multi_layout_for(m4ri_amd.VARIANT_STRASSEN, 4, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC2   # 49 products over 4 ranks
+    assert m4ri_amd.multi_layout_for(m4ri_amd.VARIANT_STRASSEN, 4, 65536, 65536, 65536) == m4ri_amd.LAYOUT_CYCLIC2   # 47 products over 4 ranks
 
 
 @pytest.mark.parametrize("layout", [m4ri_amd.LAYOUT_ROWS, m4ri_amd.LAYOUT_CYCLIC1, m4ri_amd.LAYOUT_CYCLIC2])

@@ -26,20 +26,34 @@ from m4ri_amd.mzd import Mzd  # noqa: E402
 
 
 def test_plan_arithmetic():
-    for world, want in ((2, 2), (3, 2), (4, 2), (7, 1), (8, 1)):
+    for world, want in ((2, 2), (3, 2), (4, 2), (7, 1), (8, 2)):
         assert m4ri_amd.shard_plan(world, 65536, 65536, 65536).levels == want      # fewest rounds on the busiest rank
     assert m4ri_amd.shard_plan(4, 4096, 4096, 4096).levels == 1                    # second level only on large sub-products
+    # 8 ranks: two levels are ONE application of the rank-47 scheme of the 4 x 4 x 4 block product (47 sub-products of (n/4)^3: 6 rounds,
+    # 6/47 of the work on the busiest rank) -- ahead of one Winograd level (7 sub-products: 1/7) and of Strassen-Winograd twice (49: 7/49)
     p = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
+    assert (p.nprod, p.blocks, p.bm, p.bl, p.cwl, p.cwn) == (47, 4, 16384, 16384, 256, 256)
+    assert [len(sharding.owned_products(p, r)) for r in range(8)] == [6] * 7 + [5]
+    # every directed link of the mesh carries the same share of an operand: 1/8 of 32 MiB
+    per_link = {}
+    for side, j, r, pc in sharding.strassen_pieces(p, (0,)):
+        if pc.holder != pc.owner:
+            per_link[(pc.holder, pc.owner)] = per_link.get((pc.holder, pc.owner), 0) + pc.words * 8
+    assert set(per_link.values()) == {6 * (4 << 20), 5 * (4 << 20)} and len(per_link) == 8 * 7
+    # one level on request: the 7 sub-products of one Winograd level, one per rank
+    p = m4ri_amd.shard_plan(8, 65536, 65536, 65536, 1)
     assert (p.nprod, p.blocks, p.bm, p.bl, p.cwl, p.cwn) == (7, 2, 32768, 32768, 512, 512)
     assert [len(sharding.owned_products(p, r)) for r in range(8)] == [1] * 7 + [0]
-    # every directed link of the mesh carries the same share of an operand: 1/8 of 128 MiB
     per_link = {}
     for side, j, r, pc in sharding.strassen_pieces(p, (0,)):
         if pc.holder != pc.owner:
             per_link[(pc.holder, pc.owner)] = per_link.get((pc.holder, pc.owner), 0) + pc.words * 8
     assert set(per_link.values()) == {16 << 20} and len(per_link) == 7 * 7
     p = m4ri_amd.shard_plan(4, 65536, 65536, 65536)
-    assert [len(sharding.owned_products(p, r)) for r in range(4)] == [13, 12, 12, 12]
+    assert p.nprod == 47 and [len(sharding.owned_products(p, r)) for r in range(4)] == [12, 12, 12, 11]
+    # slabs the scheme's passes do not take (children narrower than 64 words): Strassen-Winograd twice, 49
+    p = m4ri_amd.shard_plan(4, 8192, 8192, 8192, 2)
+    assert p.nprod == 49 and [len(sharding.owned_products(p, r)) for r in range(4)] == [13, 12, 12, 12]
     # ragged: padded to whole blocks / words, pieces tile every operand exactly once
     p = m4ri_amd.shard_plan(3, 1001, 777, 130, 2)
     assert (p.M, p.L, p.N) == (1004, 1024, 256) and p.bm == 251 and p.cwl == 4 and p.cwn == 1
@@ -142,7 +156,7 @@ def test_chunk_bounds_cover_the_rows_once():
         b = sharding.chunk_bounds(plan, chunks)
         assert b[0][2] == 0 and sum(x[3] for x in b) == plan.bm and all(x[2] + x[3] == y[2] for x, y in zip(b, b[1:]))
         assert b[0][0] == 0 and b[-1][1] == world and all(x[1] == y[0] for x, y in zip(b, b[1:]))
-    plan = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
+    plan = m4ri_amd.shard_plan(8, 65536, 65536, 65536, 1)
     assert [x[2:] for x in sharding.chunk_bounds(plan, 2)] == [(0, 16384), (16384, 16384)]   # halves of a 32768-row sub-product
     assert sharding.column_bounds(plan, 2) == [(0, 256), (256, 512)] and sharding.column_bounds(plan, 1) == [(0, 512)]
     assert sharding.column_bounds(m4ri_amd.shard_plan(2, 64, 64, 64), 4) == [(0, 1)]        # one word per row: nothing to cut
