@@ -577,6 +577,7 @@ def main():
             chunks = sharding.parse_chunks(args.overlap)
         else:
             chunks = (2, 1) if (plan.levels == 1 and plan.bm >= 4 * sharding.ENGINE_MIN_HALF[0]) else (1, 1)
+        group = m4ri_amd.shard_group(plan, args.cutoff)   # a rank's sub-products in batched products of this many (whole sub-products only)
         for b, (g0, rows) in enumerate(runs_a):   # the slabs are where the inputs live: fill them straight from the streams
             m4ri_amd.fill_rows_dev(bufs["local_a"].data_ptr() + 8 * b * sa * wl, wl, g0, rows, L, seeds[0], stream)
         for b, (g0, rows) in enumerate(runs_b):
@@ -595,9 +596,16 @@ def main():
                                  sb_["oper_b"].data_ptr() + 8 * (jl * plan.bl * plan.cwn + w0), plan.cwn,
                                  rows, plan.bl, (w1 - w0) * 64, False, args.cutoff, stream)
 
+            def do_product_group(q0, count):   # `count` of the rank's sub-products, rounds q0 .., as one batched product
+                m4ri_amd.mul_batch_dev(sb_["prod"].data_ptr() + 8 * q0 * plan.bm * plan.cwn, plan.cwn, plan.bm * plan.cwn,
+                                       sb_["oper_a"].data_ptr() + 8 * q0 * plan.bm * plan.cwl, plan.cwl, plan.bm * plan.cwl,
+                                       sb_["oper_b"].data_ptr() + 8 * q0 * plan.bl * plan.cwn, plan.cwn, plan.bl * plan.cwn,
+                                       plan.bm, plan.bl, plan.cwn * 64, count, False, args.cutoff, stream)
+
             def do_up():
                 m4ri_amd.shard_up_dev(plan, rank, sb_["slabs_p"].data_ptr(), sb_["local_c"].data_ptr(), w, False, stream)
-            return sharding.StrassenShardedStep(plan, rank, sb_, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks_)
+            return sharding.StrassenShardedStep(plan, rank, sb_, do_down, do_product, do_up, exchange, lambda d, s: d.copy_(s), chunks=chunks_,
+                                                group=group if tuple(chunks_) == (1, 1) else 1, product_group=do_product_group)
         # one product at a time (step(), `value`): row chunks hide part of its own transport.  Two products in flight: the neighbours'
         # multiplications hide all of it, so the sub-products stay whole (their halves cost up to 3 % more than the whole)
         single_step = sharded_step(slot_bufs[0], chunks)
@@ -614,7 +622,7 @@ def main():
         config_extra.update({"parallelism": f"strassen-sharded x{world}", "variant": "strassen", "layout": "distributed", "sharded_levels": plan.levels,
                              "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
                              "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": list(chunks),
-                             "overlap_chunks_in_the_pipelined_loop": list(chunks_loop),
+                             "overlap_chunks_in_the_pipelined_loop": list(chunks_loop), "sub_products_per_batched_product": group if tuple(chunks) == (1, 1) else 1,
                              "collective": f"batched isend/irecv (one group per batch: operands out per round and row / column chunk, products back "
                                            f"per unit; {len(sharding.chunk_bounds(plan, chunks[0]))} x {len(sharding.column_bounds(plan, chunks[1]))} unit(s) "
                                            f"x {-(-plan.nprod // world)} round(s))"})
@@ -848,7 +856,7 @@ def main():
             if peer:
                 ms = m4ri_amd.multi_stats()
                 out["config"].update({"schedule_stats": {"variant": m4ri_amd.VARIANT_NAMES.get(ms.variant), "sharded_levels": ms.levels, "sub_products": ms.sub_products,
-                                                         "row_chunks": ms.chunks, "gather_under_first_product": bool(ms.overlap),
+                                                         "row_chunks": ms.chunks, "sub_products_per_batched_product": ms.group, "gather_under_first_product": bool(ms.overlap),
                                                          "operands_converted": ms.converted, "bytes_over_links_per_step": ms.link_bytes,
                                                          "rank_pairs_copying_through_the_host": ms.pairs_staged},
                                       "timeline_ms_last_lane0_product": {str(r): m4ri_amd.multi_timeline(r) for r in range(world)},

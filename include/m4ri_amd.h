@@ -434,6 +434,9 @@ enum { M4RI_AMD_SHARD_BUF_LOCAL_A = 0, M4RI_AMD_SHARD_BUF_LOCAL_B, M4RI_AMD_SHAR
 int m4ri_amd_shard_plan_make(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n, int levels);
 int64_t m4ri_amd_shard_cut(int64_t rows, int world, int r);
 int m4ri_amd_shard_owner(const m4ri_amd_shard_plan *p, int j);             /* rank that multiplies sub-product j */
+/* how many of its sub-products a rank multiplies as ONE batched product (m4ri_amd_mul_batch_dev): rounds q, q + 1, ... of a group go
+ * together -- by the engine's time model, the smallest group within 5 % of the best; 1 = one sub-product at a time.  Host arithmetic. */
+int m4ri_amd_shard_group(const m4ri_amd_shard_plan *p, int cutoff);
 int64_t m4ri_amd_shard_slab_rows(const m4ri_amd_shard_plan *p, int rank, int which); /* 0: of A/C/products, 1: of B */
 int64_t m4ri_amd_shard_buffer_words(const m4ri_amd_shard_plan *p, int rank, int which);
 int m4ri_amd_shard_piece_of(const m4ri_amd_shard_plan *p, int side, int j, int r, m4ri_amd_shard_piece *out);

@@ -200,6 +200,7 @@ SYMBOLS = {
     "m4ri_amd_shard_plan_make": (_I, [ctypes.POINTER(ShardPlan), _I, _I64, _I64, _I64, _I]),
     "m4ri_amd_shard_cut": (_I64, [_I64, _I, _I]),
     "m4ri_amd_shard_owner": (_I, [ctypes.POINTER(ShardPlan), _I]),
+    "m4ri_amd_shard_group": (_I, [ctypes.POINTER(ShardPlan), _I]),
     "m4ri_amd_shard_slab_rows": (_I64, [ctypes.POINTER(ShardPlan), _I, _I]),
     "m4ri_amd_shard_buffer_words": (_I64, [ctypes.POINTER(ShardPlan), _I, _I]),
     "m4ri_amd_shard_piece_of": (_I, [ctypes.POINTER(ShardPlan), _I, _I, _I, ctypes.POINTER(ShardPiece)]),
@@ -490,6 +491,11 @@ def shard_plan(world: int, m: int, l: int, n: int, levels: int = 0) -> ShardPlan
     if lib().m4ri_amd_shard_plan_make(ctypes.byref(p), world, m, l, n, levels) != 0:
         raise ValueError(f"m4ri_amd_shard_plan_make({world}, {m}, {l}, {n}, {levels}) rejected its arguments")
     return p
+
+
+def shard_group(plan: ShardPlan, cutoff: int = 0) -> int:
+    """Rounds of a rank's sub-products that go into one batched product (mul_batch_dev); 1 = one at a time.  Host arithmetic."""
+    return int(lib().m4ri_amd_shard_group(ctypes.byref(plan), cutoff))
 
 
 def shard_piece(plan: ShardPlan, side: int, j: int, r: int) -> ShardPiece:

@@ -1076,7 +1076,9 @@ int strassen_rank(const StrassenOp &op, int me, const OpCtx &ctx) {
 
 // How many of a rank's sub-products go into one batched product.  The engine's time model prices a batch of b sub-products
 // (m4ri_amd_model_seconds_batch: tiles in rounds of 256, so two half-filled last rounds become one full one); of the group sizes whose
-// total is within 2 % of the best the SMALLEST wins -- more groups = more of the operand and result transport under multiplications.
+// total is within 5 % of the best the SMALLEST wins -- more groups = more of the operand and result transport under multiplications,
+// and the model's own noise is a few per cent (6 x 16384^3 on one MI355X: one at a time 3.54 ms, 2 + 2 + 2 3.31, 3 + 3 3.36, all six 3.33;
+// the single 32768^3 of the 7-way split 3.81 -- profiles/r06_rank_batch_timing.log).
 // One sub-product per rank (7 on 8 ranks) or a caller's cutoff: no grouping.
 int pick_group(const m4ri_amd_shard_plan &p, int cutoff) {
   const int rounds = (p.nprod + p.world - 1) / p.world;
@@ -1089,7 +1091,7 @@ int pick_group(const m4ri_amd_shard_plan &p, int cutoff) {
     if (cost[g] < best) best = cost[g];
   }
   for (int g = 1; g <= gmax; ++g)
-    if (cost[g] <= 1.02 * best) return g;
+    if (cost[g] <= 1.05 * best) return g;
   return 1;
 }
 
@@ -1361,6 +1363,8 @@ int m4ri_amd_set_multi_variant(int variant) {
 }
 
 int m4ri_amd_multi_default_variant(int world, int64_t m, int64_t l, int64_t n) { return default_variant(world, m, l, n); }
+
+int m4ri_amd_shard_group(const m4ri_amd_shard_plan *p, int cutoff) { return p && p->world >= 1 && p->nprod >= 1 ? pick_group(*p, cutoff) : 1; }
 
 int m4ri_amd_multi_layout_for(int variant, int world, int64_t m, int64_t l, int64_t n) {
   if (variant == 0) variant = default_variant(world, m, l, n);

@@ -210,9 +210,12 @@ class StrassenShardedStep:
     cross the links while product k is multiplied).  start(); multiply(); finish() in a row is run_strassen_sharded.
     Arguments and schedule: run_strassen_sharded."""
 
-    def __init__(self, plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1):
+    def __init__(self, plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1, group=1, product_group=None):
         self.plan, self.rank, self.bufs = plan, rank, bufs
         self.down, self.product, self.up, self.exchange, self.copy_local = down, product, up, exchange, copy_local
+        # group > 1 (whole sub-products only): rounds q0 .. q0 + group - 1 are multiplied by ONE call product_group(q0, count) -- a batched
+        # product over the rank's consecutive operand / result buffers (m4ri_amd.mul_batch_dev); the batches on the links are the same
+        self.group, self.product_group = (int(group), product_group) if product_group is not None else (1, None)
         self.W = plan.world
         self.rounds = -(-plan.nprod // self.W)
         rchunks, cchunks = parse_chunks(chunks)
@@ -265,6 +268,20 @@ class StrassenShardedStep:
         """Every unit: wait for its operand chunks, multiply, post its part of the result."""
         owned = owned_products(self.plan, self.rank)
         self.returns = []
+        if self.group > 1 and len(self.bounds) == 1 and len(self.cbounds) == 1:
+            lo, hi, _, _ = self.bounds[0]
+            w0, w1 = self.cbounds[0]
+            for q0 in range(0, self.rounds, self.group):
+                qs = range(q0, min(q0 + self.group, self.rounds))
+                for q in qs:
+                    self.inbound[(1, q, 0)].wait()
+                    self.inbound[(0, q, 0)].wait()
+                count = sum(1 for q in qs if q < len(owned))
+                if count:
+                    self.product_group(q0, count)
+                for q in qs:
+                    self.returns.append(self._batch(2, q, lo, hi, w0, w1))
+            return
         for q in range(self.rounds):
             for c, (lo, hi, row0, rows) in enumerate(self.bounds):
                 for h, (w0, w1) in enumerate(self.cbounds):
@@ -282,7 +299,7 @@ class StrassenShardedStep:
         self.up()
 
 
-def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1):
+def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_local, chunks=1, group=1, product_group=None):
     """One product C = A*B over plan.world ranks; this is rank `rank`'s part.
 
     bufs: dict of 1-D word tensors/arrays keyed 'child_a', 'child_b', 'slabs_p', 'oper_a', 'oper_b', 'prod'
@@ -313,7 +330,7 @@ def run_strassen_sharded(plan, rank, bufs, down, product, up, exchange, copy_loc
     synchronous transport is the plain three-phase walk (same bits in every case).  Column chunks are strided views of the
     row-slab pieces; the transport packs what it cannot move as it is (torch_exchange: a contiguous temporary).
     """
-    step = StrassenShardedStep(plan, rank, bufs, down, product, up, exchange, copy_local, chunks)
+    step = StrassenShardedStep(plan, rank, bufs, down, product, up, exchange, copy_local, chunks, group, product_group)
     step.start()
     step.multiply()
     step.finish()

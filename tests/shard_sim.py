@@ -37,6 +37,56 @@ def up(P, levels):
     return np.block([[p[0] ^ p[1], u4 ^ p[2]], [u3 ^ p[3], u3 ^ p[4]]])
 
 
+_SCHEME = None
+
+
+def scheme_tables():
+    """(U, V, W) of m4ri_amd/csrc/scheme444.h: product r = (sum of blocks A_ij with bit 4 i + j of U[r]) * (sum of B_jk with bit 4 j + k of
+    V[r]); C_ik = sum of the products r with bit 4 i + k of W[r] (the table test_host_logic.py verifies against the definition)."""
+    global _SCHEME
+    if _SCHEME is None:
+        import os
+        import re
+        text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "m4ri_amd", "csrc", "scheme444.h")).read()
+        _SCHEME = tuple([int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", re.search(r"SCHEME444_%s\[SCHEME444_R\] = \{([^}]*)\}" % f, text).group(1))] for f in "UVW")
+    return _SCHEME
+
+
+def scheme_down(X, bside):
+    """X: (4 s) x (4 cw) words -> the R operand sums of the 4 x 4 x 4 scheme (s x cw each), in the table's order (scheme_passes.hip)."""
+    U, V, _ = scheme_tables()
+    r, c = X.shape[0] // 4, X.shape[1] // 4
+    out = []
+    for mask in (V if bside else U):
+        acc = np.zeros((r, c), dtype=np.uint64)
+        for f in range(16):
+            if (mask >> f) & 1:
+                acc ^= X[(f >> 2) * r:(f >> 2) * r + r, (f & 3) * c:(f & 3) * c + c]
+        out.append(acc)
+    return out
+
+
+def scheme_up(P):
+    """R products (s x cw each) -> the (4 s) x (4 cw) parent."""
+    _, _, W = scheme_tables()
+    r, c = P[0].shape
+    out = np.zeros((4 * r, 4 * c), dtype=np.uint64)
+    for mask, prod in zip(W, P):
+        for f in range(16):
+            if (mask >> f) & 1:
+                out[(f >> 2) * r:(f >> 2) * r + r, (f & 3) * c:(f & 3) * c + c] ^= prod
+    return out
+
+
+def plan_down(plan, X, bside):
+    """The plan's own operand pass: Winograd levels (7, 49 sub-products) or -- two levels, nprod != 49 -- the rank-R scheme once."""
+    return scheme_down(X, bside) if (plan.levels == 2 and plan.nprod != 49) else down(X, bside, plan.levels)
+
+
+def plan_up(plan, P):
+    return scheme_up(P) if (plan.levels == 2 and plan.nprod != 49) else up(P, plan.levels)
+
+
 def local_parent(plan, rank, which, M: Mzd, width_words):
     """The zero-padded local parent of host matrix M on `rank` (which: 0 rows over bm, 1 rows over bl)."""
     runs = sharding.local_rows(plan, rank, which)
@@ -50,7 +100,7 @@ def local_parent(plan, rank, which, M: Mzd, width_words):
     return out
 
 
-def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
+def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1, group=1):
     """Rank `rank`'s whole part on CPU arrays; returns its local parent of C and its row runs."""
     LA = local_parent(plan, rank, 0, A, plan.L // 64)
     LB = local_parent(plan, rank, 1, B, plan.N // 64)
@@ -63,7 +113,7 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
     def do_down():
         for key, X, bside, s, cw in (("child_a", LA, False, sa, plan.cwl), ("child_b", LB, True, sb, plan.cwn)):
             if s:
-                ch = down(X, bside, plan.levels)
+                ch = plan_down(plan, X, bside)
                 bufs[key][:plan.nprod * s * cw] = np.concatenate([c.reshape(-1) for c in ch])
 
     def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
@@ -79,14 +129,20 @@ def rank_part(plan, rank, A: Mzd, B: Mzd, oracle, exchange, chunks=1):
     def do_up():
         if sa:
             P = [bufs["slabs_p"][j * sa * plan.cwn:(j + 1) * sa * plan.cwn].reshape(sa, plan.cwn) for j in range(plan.nprod)]
-            out["C"] = up(P, plan.levels)
+            out["C"] = plan_up(plan, P)
         else:
             out["C"] = np.zeros((0, plan.N // 64), dtype=np.uint64)
 
     def copy_local(dst, src):
         dst[...] = src
 
-    sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local, chunks=chunks)
+    def do_product_group(q0, count):   # what m4ri_amd_mul_batch_dev does on the device: the rank's sub-products q0 .. q0 + count - 1
+        owned = sharding.owned_products(plan, rank)
+        for q in range(q0, q0 + count):
+            do_product(q, owned[q])
+
+    sharding.run_strassen_sharded(plan, rank, bufs, do_down, do_product, do_up, exchange, copy_local, chunks=chunks, group=group,
+                                  product_group=do_product_group if group > 1 else None)
     return out["C"], sharding.local_rows(plan, rank, 0)
 
 
@@ -109,7 +165,7 @@ def rank_products(plan, rank, pairs, oracle, exchange, inflight=2, chunks=1):
         def do_down():
             for key, X, bside, s_, cw in (("child_a", LA, False, sa, plan.cwl), ("child_b", LB, True, sb, plan.cwn)):
                 if s_:
-                    bufs[key][:plan.nprod * s_ * cw] = np.concatenate([c.reshape(-1) for c in down(X, bside, plan.levels)])
+                    bufs[key][:plan.nprod * s_ * cw] = np.concatenate([c.reshape(-1) for c in plan_down(plan, X, bside)])
 
         def do_product(jl, j, row0=0, rows=None, w0=0, w1=None):
             rows = plan.bm if rows is None else rows
@@ -123,7 +179,7 @@ def rank_products(plan, rank, pairs, oracle, exchange, inflight=2, chunks=1):
         def do_up():
             if sa:
                 P = [bufs["slabs_p"][j * sa * plan.cwn:(j + 1) * sa * plan.cwn].reshape(sa, plan.cwn) for j in range(plan.nprod)]
-                out[k] = up(P, plan.levels)
+                out[k] = plan_up(plan, P)
             else:
                 out[k] = np.zeros((0, plan.N // 64), dtype=np.uint64)
 

@@ -182,13 +182,15 @@ def test_baseline_sizes_from_resident_operands_vs_reference_sha256(m, l, n, seed
     m4ri_amd.set_devices([0] * 8)
     assert m4ri_amd.multi_default_variant(8, m, l, n) == variant
     lay = m4ri_amd.multi_layout_for(0, 8, m, l, n)
-    assert lay == (m4ri_amd.LAYOUT_CYCLIC1 if variant == m4ri_amd.VARIANT_STRASSEN else m4ri_amd.LAYOUT_ROWS)
+    assert lay == (m4ri_amd.LAYOUT_CYCLIC2 if variant == m4ri_amd.VARIANT_STRASSEN else m4ri_amd.LAYOUT_ROWS)   # 47 sub-products over 8 ranks
     dA, dB, dC = Dmat(m, l, lay).fill(seeds[0]), Dmat(l, n, lay).fill(seeds[1]), Dmat(m, n, lay)
     m4ri_amd.dmat_mul(dC, dA, dB)
     m4ri_amd.dmat_mul(dC, dA, dB)          # twice back to back: buffers and events are reused across operations
     m4ri_amd.multi_sync()
     st = m4ri_amd.multi_stats()
     assert (st.variant, st.world, st.converted) == (variant, 8, 0)
+    if variant == m4ri_amd.VARIANT_STRASSEN:   # two levels as ONE application of the rank-47 scheme, a rank's 6 sub-products in batched products
+        assert (st.levels, st.sub_products, st.chunks) == (2, 47, 1) and st.group >= 2, (st.levels, st.sub_products, st.chunks, st.group)
     C = dC.download()
     assert hashlib.sha256(C.masked().tobytes()).hexdigest() == _golden(m, l, n, seeds)
     for d in (dA, dB, dC):

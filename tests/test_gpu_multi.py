@@ -171,17 +171,28 @@ def test_bench_overlapped_strassen_schedule_at_8_ranks():
     product it recomputes alone.  (gloo on one GPU completes every batch when it is posted: the bits and the batch order are
     what is tested here, the overlap itself needs links.)"""
     out, stdout = _bench(["--gpus", "8", "--size", "16384", "--backend", "gloo", "--check", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                          "--overlap", "2x2", "--inflight", "2"], timeout=1500)
+                          "--overlap", "2x2", "--inflight", "2", "--shard-levels", "1"], timeout=1500)
     assert out["n_gpus"] == 8 and out["config"]["variant"] == "strassen" and out["config"]["overlap_chunks"] == [2, 2] and out["config"]["inflight"] == 1
     assert out["config"]["sub_products"] == 7 and stdout.count("-> OK") == 8
 
 
 def test_bench_config4_at_8_ranks_full_size_matches_the_reference():
-    """BASELINE.json configs[3] exactly as the driver's 8-GPU command runs it -- 65536^3, `--variant auto` = the 7 sub-products of the
-    top Strassen-Winograd level over 8 ranks, slab-cyclic layout, two row chunks per sub-product in flight -- minus the links (8
-    processes on this one GPU, gloo): the C gathered from the 8 ranks against the real reference's SHA-256, and every rank's slabs
-    against the product it recomputes alone."""
+    """BASELINE.json configs[3] exactly as the driver's 8-GPU command runs it -- 65536^3, `--variant auto` = the 47 sub-products of the
+    top TWO levels done as one application of the rank-47 scheme (6 rounds on 8 ranks; a rank's sub-products of 16384^3 in batched
+    products), slab-cyclic layout -- minus the links (8 processes on this one GPU, gloo): the C gathered from the 8 ranks against the
+    real reference's SHA-256, and every rank's slabs against the product it recomputes alone."""
     out, stdout = _bench(["--gpus", "8", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1"], timeout=2400)
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["variant"] == "strassen" and cfg["sub_products"] == 47 and cfg["overlap_chunks"] == [1, 1]
+    assert cfg["sharded_levels"] == 2 and cfg["sub_products_on_busiest_rank"] == 6 and cfg["sub_products_per_batched_product"] >= 2
+    assert cfg["per_rank_product"] == [16384, 16384, 16384] and cfg["bytes_over_links_per_step"] == 3 * 47 * 7 * (4 << 20)
+    assert out["verified"]["matches_reference"] is True and stdout.count("-> OK") == 8
+
+
+def test_bench_config4_one_sharded_level_at_8_ranks_full_size_matches_the_reference():
+    """The same with ONE sharded level on request (`--shard-levels 1`): the 7 sub-products of the top Strassen-Winograd level, one per
+    rank, two row chunks per sub-product in flight."""
+    out, stdout = _bench(["--gpus", "8", "--backend", "gloo", "--check", "--steps", "1", "--warmup", "1", "--shard-levels", "1", "--no-cpu-baseline"], timeout=2400)
     cfg = out["config"]
     assert out["n_gpus"] == 8 and cfg["variant"] == "strassen" and cfg["sub_products"] == 7 and cfg["overlap_chunks"] == [2, 1]
     assert cfg["per_rank_product"] == [32768, 32768, 32768] and cfg["bytes_over_links_per_step"] == 3 * 7 * 7 * (16 << 20)
@@ -263,7 +274,8 @@ def test_bench_peer_transport_one_process_all_ranks():
                           "--no-cpu-baseline"])
     cfg = out["config"]
     assert out["n_gpus"] == 8 and cfg["transport"] == "peer" and cfg["variant"] == "strassen" and cfg["transport_fallback"] == []
-    assert cfg["schedule_stats"]["variant"] == "strassen" and cfg["schedule_stats"]["sub_products"] == 7 and cfg["schedule_stats"]["operands_converted"] == 0
+    assert cfg["schedule_stats"]["variant"] == "strassen" and cfg["schedule_stats"]["sub_products"] == 47 and cfg["schedule_stats"]["operands_converted"] == 0
+    assert cfg["schedule_stats"]["sharded_levels"] == 2 and cfg["schedule_stats"]["sub_products_per_batched_product"] >= 1
     assert len(cfg["timeline_ms_last_lane0_product"]) == 8 and out["host_issue_ms_per_step"] > 0 and stdout.count("-> OK") == 1
     assert out["pipelined_value"] > 0 and cfg["schedule_stats"]["rank_pairs_copying_through_the_host"] == 0   # two lanes, both Cs checked by --check
     out, stdout = _bench(["--gpus", "4", "--transport", "peer", "--virtual-ranks", "--dims", "20000,8192,30016", "--check", "--steps", "2", "--warmup", "1",

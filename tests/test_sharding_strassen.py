@@ -73,6 +73,19 @@ def test_plan_arithmetic():
                                                 (4, 2, 203, 300, 257), (8, 1, 130, 129, 200), (8, 2, 64, 512, 256),
                                                 (5, 2, 7, 64, 64)])   # more ranks than rows per block: empty slabs
 def test_all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks):
+    _all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks, 1)
+
+
+@pytest.mark.parametrize("world,m,group", [(8, 100, 1), (8, 100, 2), (8, 64, 3), (8, 33, 6), (3, 50, 4), (5, 40, 2)])
+def test_the_scheme_split_all_ranks_in_one_process(oracle, world, m, group):
+    """Two sharded levels as ONE application of the rank-47 scheme of the 4 x 4 x 4 block product (47 sub-products; multi.hip: nprod_of) with
+    the rounds of a rank multiplied `group` at a time (sharding.StrassenShardedStep: product_group): same batches on the links, same bits."""
+    plan = m4ri_amd.shard_plan(world, m, 16384, 16384, 2)
+    assert plan.nprod == 47 and plan.cwl == 64 and plan.cwn == 64
+    _all_ranks_in_one_process(oracle, world, 2, m, 16384, 16384, 1, group)
+
+
+def _all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks, group):
     A, B = Mzd.random(m, l, 3), Mzd.random(l, n, 4)
     plan = m4ri_amd.shard_plan(world, m, l, n, levels)
     mail, lock, barrier = {}, threading.Lock(), threading.Barrier(world)
@@ -92,7 +105,7 @@ def test_all_ranks_in_one_process(oracle, world, levels, m, l, n, chunks):
 
     def work(rank):
         try:
-            parts[rank] = shard_sim.rank_part(plan, rank, A, B, oracle, make_exchange(rank), chunks=chunks)
+            parts[rank] = shard_sim.rank_part(plan, rank, A, B, oracle, make_exchange(rank), chunks=chunks, group=group)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
             barrier.abort()
@@ -114,7 +127,7 @@ def _free_port():
     return _free_port.n
 
 
-def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
+def _worker(rank, world, port, levels, m, l, n, out_dir, chunks, group=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     # rendezvous through a file in the test's own directory: no port to pick, nothing to collide with when suites run side by side
     dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous_' + str(port))}", rank=rank, world_size=world)
@@ -129,7 +142,7 @@ def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
 
     exchange.post = lambda sends, recvs: torch_x.post([(d, torch.from_numpy(v.view(np.int64))) for d, v in sends],
                                                       [(s, torch.from_numpy(v.view(np.int64))) for s, v in recvs])
-    CL, runs = shard_sim.rank_part(plan, rank, A, B, orc, exchange, chunks=chunks)
+    CL, runs = shard_sim.rank_part(plan, rank, A, B, orc, exchange, chunks=chunks, group=group)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=CL, runs=np.array(runs))
     dist.barrier()
     dist.destroy_process_group()
@@ -138,8 +151,19 @@ def _worker(rank, world, port, levels, m, l, n, out_dir, chunks):
 @pytest.mark.parametrize("levels,m,l,n,chunks", [(1, 200, 256, 320, 1), (2, 131, 257, 129, 1), (1, 200, 256, 320, 2), (2, 131, 257, 129, 2),
                                                  (1, 200, 256, 320, "2x2"), (2, 131, 257, 513, "2x3")])
 def test_two_ranks_gloo(tmp_path, oracle, levels, m, l, n, chunks):
+    _two_ranks_gloo(tmp_path, oracle, levels, m, l, n, chunks, 1)
+
+
+@pytest.mark.parametrize("group", [1, 4])
+def test_the_scheme_split_two_ranks_gloo(tmp_path, oracle, group):
+    """The 47-way split over two gloo ranks, the rank's 24 / 23 sub-products one at a time and four at a time."""
+    assert m4ri_amd.shard_plan(2, 70, 16384, 16384, 2).nprod == 47
+    _two_ranks_gloo(tmp_path, oracle, 2, 70, 16384, 16384, 1, group)
+
+
+def _two_ranks_gloo(tmp_path, oracle, levels, m, l, n, chunks, group):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), levels, m, l, n, str(tmp_path), chunks, group), nprocs=world, join=True)
     plan = m4ri_amd.shard_plan(world, m, l, n, levels)
     parts = {}
     for r in range(world):

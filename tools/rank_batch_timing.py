@@ -1,8 +1,11 @@
 """What ONE rank of the 8-GPU schedule multiplies, timed on one GPU (resident operands, HIP events, min / median of `reps`):
 the 7-way split's single 32768^3 sub-product against the 47-way split's six 16384^3 sub-products -- one call each, and batched
 (m4ri_amd_mul_batch_dev) 2 + 2 + 2, 3 + 3 and 6 at a time.  python tools/rank_batch_timing.py [n] [reps]"""
+import os
 import sys
 import statistics
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import torch
 
