@@ -34,6 +34,9 @@ static bool same(const mzd_t *X, const mzd_t *Y) {
 
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 3;
+  // round 6: argv[2] = g > 1 makes every rank of the distributed Strassen schedule multiply its sub-products g at a time as batched
+  // products (m4ri_amd_mul_batch_dev from the ranks' threads; multi.hip: M4RI_AMD_MULTI_GROUP)
+  if (argc > 2 && atoi(argv[2]) > 1) setenv("M4RI_AMD_MULTI_GROUP", argv[2], 1);
   const int shapes[4][3] = {{1100, 1290, 1411}, {2048, 2048, 4096}, {513, 700, 65}, {1536, 1536, 1536}};
   if (m4ri_amd_init(0)) { fprintf(stderr, "no device\n"); return 2; }
   const int ids[3] = {0, 0, 0};
