@@ -406,8 +406,9 @@ int m4ri_amd_is_pinned(const mzd_t *M);/* 0 no, 1 yes and host copy current, 2 y
 
 /* ---- part 4: one product over several GPUs (m4ri/mp.c:158-324 is the reference's own
  * block-parallel template) ------------------------------------------------------------------------------
- * The units handed out are the 7 (levels = 1) or 49 (levels = 2) sub-products of the top
- * Strassen-Winograd level(s) (strassen.c:111-150).  Layout: with S = 2^levels row blocks per matrix,
+ * The units handed out are the sub-products of the top Strassen level(s) (strassen.c:111-150): 7 (levels = 1), or
+ * (levels = 2) the 47 of ONE application of the rank-47 scheme of the 4 x 4 x 4 block product (scheme444.h) -- 49 of
+ * Strassen-Winograd twice where the scheme's passes cannot take the slabs (children narrower than 64 words).  Layout: with S = 2^levels row blocks per matrix,
  * rank r of `world` holds rows [cut(r), cut(r+1)) of EVERY block ("slab-cyclic"; cut(r) = rows*r/world),
  * stacked into a local parent of 1/world of the rows and the same quadrant structure -- so the level's
  * additions are ordinary local passes and only slabs of sub-product operands (one way) and of products

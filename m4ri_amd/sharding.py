@@ -2,8 +2,10 @@
 
 Three ways to hand the work out, all bit-identical to the single-GPU product:
 
-  * Strassen sub-products (the design for 5+ ranks; StrassenShardedStep, run_strassen_sharded, run_products): the 7 or 49
-    sub-products of the top Strassen-Winograd level(s) (reference m4ri/strassen.c:111-150) go to the ranks, the matrices are
+  * Strassen sub-products (the design for 5+ ranks; StrassenShardedStep, run_strassen_sharded, run_products): the 7, 47 or 49
+    sub-products of the top Strassen level(s) (reference m4ri/strassen.c:111-150; 47 = the rank-47 scheme of the 4 x 4 x 4 block
+    product applied once to two levels, the choice is the C library's: plan.nprod) go to the ranks, a rank's own several in groups
+    as batched products (group / product_group), the matrices are
     distributed slab-cyclically, so the level's additions are local passes and only slabs of operands / products cross the
     xGMI mesh -- every rank to every rank, one send/recv pair per piece, posted in batches laid out so that transport runs under
     the multiplications (row / column chunks inside one product, and -- for a stream of products -- two products in flight).

@@ -204,3 +204,18 @@ def test_the_winograd_level_over_the_scheme_is_a_scheme():
                         for k2 in range(2):
                             got = sum((u >> (2 * i + j)) & (v >> (2 * j2 + k)) & (w >> (2 * i2 + k2)) & 1 for u, v, w in zip(U, V, W)) & 1
                             assert got == int(i == i2 and j == j2 and k == k2)
+
+
+def test_a_rank_multiplies_its_sub_products_in_groups():
+    """m4ri_amd_shard_group / m4ri_amd_model_seconds_batch (pure arithmetic): the sub-products a rank of the sharded Strassen schedule owns go
+    into batched products (m4ri_amd_mul_batch_dev) -- the smallest group within 5 % of the time model's best; measured on one MI355X for the
+    8-rank split of 65536^3: 6 x 16384^3 one at a time 3.54 ms, 2 + 2 + 2 3.31, all six 3.33 (profiles/r06_rank_batch_timing.log)."""
+    p = m4ri_amd.shard_plan(8, 65536, 65536, 65536)
+    assert (p.levels, p.nprod) == (2, 47) and m4ri_amd.shard_group(p) == 2
+    assert m4ri_amd.shard_group(p, 4096) == 1                                          # a caller's cutoff: one at a time
+    assert m4ri_amd.shard_group(m4ri_amd.shard_plan(8, 65536, 65536, 65536, 1)) == 1   # one sub-product per rank
+    assert m4ri_amd.shard_group(m4ri_amd.shard_plan(8, 131072, 131072, 131072)) == 1   # sub-products of 32768^3 fill the chip alone
+    one, two, six = (m4ri_amd.model_seconds_batch(16384, 16384, 16384, -1, b) for b in (1, 2, 6))
+    assert two < 1.9 * one and six < 5.5 * one and six > 4.0 * one                      # half-filled last rounds of tiles become full ones
+    for L in (0, 1, 2, 3):
+        assert m4ri_amd.model_seconds_batch(16384, 16384, 16384, L, 1) == m4ri_amd.model_seconds(16384, 16384, 16384, L)
