@@ -1106,13 +1106,21 @@ void plan_for(m4ri_amd_shard_plan *p, int world, int64_t m, int64_t l, int64_t n
   p->nprod = nprod_of(world, levels, p->bm, p->bl, p->cwl, p->cwn);
 }
 
-// sharding.default_variant: row slabs up to 4 ranks (2 ranks share ONE link, which the Strassen exchange would saturate) and
-// for every product whose halves a sharded Strassen level would leave too thin to pay for the exchange of operands and results
-// (m/2 < 4096, l/2 < 8192 or n/2 < 4096; BASELINE.json configs[4], 131072 x 8192 x 131072, has l/2 < 8192: row slabs of A
-// and C with B replicated, no reduction); the Strassen sub-products from 5 ranks on
+// sharding.default_variant: row slabs on 2 ranks (they share ONE link, which the Strassen exchange would saturate) and for every
+// product whose halves a sharded Strassen level would leave too thin to pay for the exchange of operands and results (m/2 < 4096,
+// l/2 < 8192 or n/2 < 4096; BASELINE.json configs[4], 131072 x 8192 x 131072, has l/2 < 8192: row slabs of A and C with B replicated,
+// no reduction); the Strassen sub-products from 5 ranks on -- and on 3 and 4 ranks where the two sharded levels are the
+// scheme's 47 sub-products of at least 16384 on every side (65536^3 on 4 ranks: 12 sub-products of 16384^3 per rank in batched products
+// 6.58 ms against the row slab's 16384 x 65536 x 65536 in 8.00 ms, one MI355X, profiles/r06_rank_batch_timing.log; below that size
+// nothing was measured and the slabs stay)
 int default_variant(int world, int64_t m, int64_t l, int64_t n) {
-  if (world <= 4) return M4RI_AMD_VARIANT_SLABS;
+  if (world <= 2) return M4RI_AMD_VARIANT_SLABS;
   if (m / 2 < 4096 || l / 2 < 8192 || n / 2 < 4096) return M4RI_AMD_VARIANT_SLABS;
+  if (world <= 4) {
+    m4ri_amd_shard_plan p;
+    const bool big = m / 4 >= 16384 && l / 4 >= 16384 && n / 4 >= 16384;
+    return (big && m4ri_amd_shard_plan_make(&p, world, m, l, n, 2) == 0 && p.nprod != 49) ? M4RI_AMD_VARIANT_STRASSEN : M4RI_AMD_VARIANT_SLABS;
+  }
   return M4RI_AMD_VARIANT_STRASSEN;
 }
 

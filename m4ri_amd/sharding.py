@@ -492,17 +492,24 @@ ENGINE_MIN_HALF = (4096, 8192, 4096)
 def default_variant(world: int, m: int = 0, l: int = 0, n: int = 0) -> str:
     """What `--variant auto` hands out to the ranks.
 
-    * up to 4 ranks: row slabs (one all-gather of B; 2 ranks share a single link, which the Strassen-sharded exchange
-      would saturate);
+    * 2 ranks: row slabs (one all-gather of B; 2 ranks share a single link, which the Strassen-sharded exchange would saturate);
     * from 5 ranks on: the sub-products of the top Strassen level(s) -- but only for a product the single-GPU engine
       would itself split once more in all three dimensions.  A short inner dimension (BASELINE.json configs[4]:
       131072 x 8192 x 131072, l/2 < 8192) or a thin operand leaves nothing for a Strassen level to save: such shapes
       take row slabs of A and C with B replicated at every world size, no reduction (the reference's
-      own row parallelism, m4ri/brilliantrussian.c:1121-1123).
+      own row parallelism, m4ri/brilliantrussian.c:1121-1123);
+    * 3 and 4 ranks: row slabs, except where two sharded levels are the 47 sub-products of the rank-47 scheme and those are at
+      least 16384 on every side (65536^3 on 4 ranks: 12 sub-products per rank in batched products 6.58 ms, the row slab 8.00 ms:
+      profiles/r06_rank_batch_timing.log) -- the rule of m4ri_amd_multi_default_variant (multi.hip), restated.
     The owner layout and the blocks variant scatter from rank 0 inside the timed region and are never selected here.
     """
-    if world <= 4:
+    if world <= 2:
         return "slabs"
     if m and l and n and (m // 2 < ENGINE_MIN_HALF[0] or l // 2 < ENGINE_MIN_HALF[1] or n // 2 < ENGINE_MIN_HALF[2]):
         return "slabs"
+    if world <= 4:
+        if not (m and l and n) or min(m, l, n) // 4 < 16384:
+            return "slabs"
+        import m4ri_amd
+        return "strassen" if m4ri_amd.shard_plan(world, m, l, n, 2).nprod != 49 else "slabs"
     return "strassen"

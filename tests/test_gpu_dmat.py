@@ -198,6 +198,26 @@ def test_baseline_sizes_from_resident_operands_vs_reference_sha256(m, l, n, seed
     m4ri_amd.lib().m4ri_amd_release_workspace()
 
 
+def test_config3_on_4_ranks_takes_the_47_way_split_vs_reference_sha256():
+    """65536^3 on FOUR ranks: the automatic schedule is the 47-way split too (12 sub-products of 16384^3 per rank in batched products:
+    6.58 ms per rank against the row slab's 8.00, profiles/r06_rank_batch_timing.log), below that size and on 2 ranks the row slabs."""
+    m = l = n = 65536
+    m4ri_amd.set_devices([0] * 4)
+    assert m4ri_amd.multi_default_variant(4, m, l, n) == m4ri_amd.VARIANT_STRASSEN and m4ri_amd.multi_default_variant(2, m, l, n) == m4ri_amd.VARIANT_SLABS
+    assert m4ri_amd.multi_default_variant(4, 32768, 32768, 32768) == m4ri_amd.VARIANT_SLABS
+    lay = m4ri_amd.multi_layout_for(0, 4, m, l, n)
+    assert lay == m4ri_amd.LAYOUT_CYCLIC2
+    dA, dB, dC = Dmat(m, l, lay).fill(3), Dmat(l, n, lay).fill(4), Dmat(m, n, lay)
+    m4ri_amd.dmat_mul(dC, dA, dB)
+    m4ri_amd.multi_sync()
+    st = m4ri_amd.multi_stats()
+    assert (st.variant, st.world, st.converted, st.levels, st.sub_products, st.chunks) == (m4ri_amd.VARIANT_STRASSEN, 4, 0, 2, 47, 1) and st.group >= 2
+    assert hashlib.sha256(dC.download().masked().tobytes()).hexdigest() == _golden(m, l, n, (3, 4))
+    for d in (dA, dB, dC):
+        d.free()
+    m4ri_amd.lib().m4ri_amd_release_workspace()
+
+
 def test_a_matrix_of_an_older_device_list_is_refused_not_used():
     m4ri_amd.set_devices([0, 0])
     d = Dmat(256, 256, m4ri_amd.LAYOUT_ROWS).fill(1)

@@ -155,7 +155,11 @@ def test_slab_cuts_and_default_variant():
     assert sharding.default_variant(8, 65536, 65536, 65536) == "strassen"
     assert sharding.default_variant(8, 131072, 8192, 131072) == "slabs"
     assert sharding.default_variant(8, 4096, 65536, 65536) == "slabs" and sharding.default_variant(8, 65536, 65536, 4096) == "slabs"
-    assert sharding.default_variant(4, 65536, 65536, 65536) == "slabs"
+    # 3 and 4 ranks: the 47 sub-products of the rank-47 scheme in batched products where they are at least 16384 on every side (measured
+    # at 65536^3: 6.58 ms per rank against the row slab's 8.00), row slabs below that and on 2 ranks (one link)
+    assert sharding.default_variant(4, 65536, 65536, 65536) == "strassen" and sharding.default_variant(3, 65536, 65536, 65536) == "strassen"
+    assert sharding.default_variant(4, 32768, 32768, 32768) == "slabs" and sharding.default_variant(2, 65536, 65536, 65536) == "slabs"
+    assert sharding.default_variant(4, 131072, 8192, 131072) == "slabs"
 
 
 def test_slab_product_pieces_cover_the_inner_dimension_own_slab_first():

@@ -71,12 +71,36 @@ def main():
                                            q, q, q, g, False, 0, st)
                 b0 += g
         return run
-    for sizes in ([1] * 6, [2, 2, 2], [3, 3], [6], [1] * 5, [3, 2], [5]):
+    del A, B, C
+    A, B = mats(q, 12, 10), mats(q, 12, 40)
+    C = torch.empty_like(A)
+    for sizes in ([1] * 6, [2, 2, 2], [3, 3], [6], [1] * 5, [3, 2], [5], [1] * 12, [2] * 6, [3] * 4, [4] * 3, [6, 6], [12]):
         t = timed(groups(sizes), reps)
         s = m4ri_amd.get_stats()
-        print(f"47-way rank: {sum(sizes)} x {q}^3 as {'+'.join(map(str, sizes)):12s} min {t[0]:8.3f} ms  median {t[1]:8.3f} ms   (last call: L = {int(s.levels)}, "
+        print(f"47-way rank: {sum(sizes)} x {q}^3 as {'+'.join(map(str, sizes)):24s} min {t[0]:8.3f} ms  median {t[1]:8.3f} ms   (last call: L = {int(s.levels)}, "
               f"{int(s.leaf_products)} leaf products in {int(s.leaf_launches)} launch(es); model {1e3 * m4ri_amd.model_seconds_batch(q, q, q, -1, sizes[-1]):.3f} ms)")
+
+
+def slabs():
+    """the row-slab schedule's per-rank product on 4 and on 2 ranks: (n/W) x n x n"""
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+    st = torch.cuda.current_stream().cuda_stream
+    w = n // 64
+    B = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    m4ri_amd.fill_dev(B.data_ptr(), w, n, n, 77, st)
+    for W in (4, 2):
+        rows = n // W
+        A = torch.empty(rows * w, dtype=torch.int64, device="cuda")
+        m4ri_amd.fill_dev(A.data_ptr(), w, rows, n, 78, st)
+        C = torch.empty_like(A)
+        t = timed(lambda: m4ri_amd.mul_dev(C.data_ptr(), w, A.data_ptr(), w, B.data_ptr(), w, rows, n, n, False, 0, st), reps)
+        s = m4ri_amd.get_stats()
+        print(f"row-slab rank of {W}: {rows} x {n} x {n}        min {t[0]:8.3f} ms  median {t[1]:8.3f} ms   (L = {int(s.levels)}, {int(s.leaf_products)} leaf products)")
+        del A, C
 
 
 if __name__ == "__main__":
     main()
+    slabs()
+
