@@ -784,6 +784,13 @@ def main():
             raise SystemExit(3)
 
     if rank == 0:
+        # N > 1, Strassen sub-products: the engine's stats are those of rank 0's LAST call -- one sub-product, or a batched product of the
+        # last group of its sub-products; per rank and product there are `calls_rank` such calls
+        owned0 = len(sharding.owned_products(plan, 0)) if (multi and args.variant == "strassen") else 1
+        grp0 = (config_extra.get("sub_products_per_batched_product", 1) if not peer else int(m4ri_amd.multi_stats().group)) if (multi and args.variant == "strassen") else 1
+        grp0 = max(1, grp0)
+        last_batch = (owned0 % grp0 or grp0) if owned0 else 1
+        sub_leaves = int(stats.leaf_products) // max(1, last_batch)   # leaf products of ONE sub-product (of the whole product at N = 1)
         launches = max(1, int(stats.cum_leaf_launches))
         leaf_launch_ms = stats.cum_leaf_ms / launches               # mean over every leaf launch of the timed steps
         leaf_launch_bytes = stats.leaf_bytes / max(1, stats.leaf_launches)
@@ -811,7 +818,7 @@ def main():
                 # the engine's own plan for the per-rank product: rows in blocks [rows, levels], largest first (one block = one product)
                 "row_blocks": ([list(b) for b in m4ri_amd.plan_row_blocks(*per_rank_product)] if args.workload != "leaf16384" and not args.cutoff else None),
                 "leaf_shape": [int(stats.leaf_m), int(stats.leaf_l), int(stats.leaf_n)],
-                "leaf_products_per_rank": int(stats.leaf_products),
+                "leaf_products_per_rank": sub_leaves * owned0,
                 "workspace_GiB": stats.workspace_bytes / 2 ** 30,
                 **config_extra,
             },
@@ -879,7 +886,7 @@ def main():
                 "achieved": bs / (ms_per_step * 1e-3) / 1e9, "frac": frac,
                 "bytes_moved_by_our_fused_passes": stats.aux_bytes + stats.leaf_bytes,
                 # four fused levels = two applications of a rank-R 4 x 4 x 4 scheme (R^2 leaves, not 7^4); bytes_sched stays the REFERENCE's schedule
-                "leaf_products_run": int(stats.leaf_products), "leaf_products_declared": 7 ** int(stats.levels) * nprod_rank,
+                "leaf_products_run": sub_leaves * nprod_rank, "leaf_products_declared": 7 ** int(stats.levels) * nprod_rank,
                 "pass_pattern_peak": ceiling,
                 "north_star_60pct": bool(frac >= 0.6),
                 "note": "frac = unfused reference schedule bytes (15 quadrant adds/level, SURVEY.md 8(d)) of the rank's sub-product(s) over the measured step "
