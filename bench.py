@@ -623,9 +623,12 @@ def main():
                              "sub_products": plan.nprod, "sub_products_on_busiest_rank": len(sharding.owned_products(plan, 0)),
                              "bytes_over_links_per_step": moved, "links_used": world * (world - 1), "overlap_chunks": list(chunks),
                              "overlap_chunks_in_the_pipelined_loop": list(chunks_loop), "sub_products_per_batched_product": group if tuple(chunks) == (1, 1) else 1,
-                             "collective": f"batched isend/irecv (one group per batch: operands out per round and row / column chunk, products back "
-                                           f"per unit; {len(sharding.chunk_bounds(plan, chunks[0]))} x {len(sharding.column_bounds(plan, chunks[1]))} unit(s) "
-                                           f"x {-(-plan.nprod // world)} round(s))"})
+                             "collective": (f"batched isend/irecv, one batch per group of {group} round(s): the group's operands out, its products back "
+                                            f"({-(-(-(-plan.nprod // world)) // group)} + {-(-(-(-plan.nprod // world)) // group)} batches per product)"
+                                            if group > 1 and tuple(chunks) == (1, 1) else
+                                            f"batched isend/irecv (one group per batch: operands out per round and row / column chunk, products back "
+                                            f"per unit; {len(sharding.chunk_bounds(plan, chunks[0]))} x {len(sharding.column_bounds(plan, chunks[1]))} unit(s) "
+                                            f"x {-(-plan.nprod // world)} round(s))")})
     if dist is not None:
         config_extra.update({"backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (pieces staged through the host: development aid)",
                              "ranks": dist.get_world_size()})

@@ -228,13 +228,14 @@ class StrassenShardedStep:
             self.table.setdefault((side, j // self.W), []).append((r, pc))
         self.inbound, self.returns = {}, []
 
-    def _batch(self, side, q, r_lo, r_hi, w0=0, w1=None):
+    def _pieces(self, side, q, r_lo, r_hi, w0, w1, sends, recvs):
+        """The sends and receives of the pieces (side, round q, slabs r_lo .. r_hi, words w0 .. w1) appended to the two lists, in the
+        canonical order; local pieces are copied at once."""
         plan, rank, bufs = self.plan, self.rank, self.bufs
         child = {0: bufs["child_a"], 1: bufs["child_b"]}
         oper = {0: bufs["oper_a"], 1: bufs["oper_b"]}
         row_words = plan.cwl if side == 0 else plan.cwn
         w1 = row_words if w1 is None else w1
-        sends, recvs = [], []
         for r, pc in self.table.get((side, q), ()):
             if not (r_lo <= r < r_hi):
                 continue
@@ -252,12 +253,33 @@ class StrassenShardedStep:
                 sends.append((to, src))
             elif to == rank:
                 recvs.append((frm, dst))
+
+    def _batch(self, side, q, r_lo, r_hi, w0=0, w1=None):
+        sends, recvs = [], []
+        self._pieces(side, q, r_lo, r_hi, w0, w1, sends, recvs)
+        return _post(self.exchange, sends, recvs)
+
+    def _grouped(self):
+        return self.group > 1 and len(self.bounds) == 1 and len(self.cbounds) == 1
+
+    def _group_batch(self, sides, q0):
+        """ONE batch for the pieces of `sides` of every round of the group that starts at round q0 (whole sub-products): a group's
+        operands -- and its results -- cross the links as one group of point-to-point transfers, so a product of 47 sub-products costs the
+        host as many batches as one of 7 in two row chunks."""
+        sends, recvs = [], []
+        for q in range(q0, min(q0 + self.group, self.rounds)):
+            for side in sides:
+                self._pieces(side, q, 0, self.W, 0, None, sends, recvs)
         return _post(self.exchange, sends, recvs)
 
     def start(self):
         """Local down pass, then every outbound operand chunk posted, in the order the units will want them."""
         self.down()
         self.inbound = {}
+        if self._grouped():
+            for q0 in range(0, self.rounds, self.group):
+                self.inbound[("group", q0)] = self._group_batch((1, 0), q0)
+            return
         for q in range(self.rounds):
             for c, (lo, hi, _, _) in enumerate(self.bounds):
                 for h, (w0, w1) in enumerate(self.cbounds):
@@ -270,19 +292,14 @@ class StrassenShardedStep:
         """Every unit: wait for its operand chunks, multiply, post its part of the result."""
         owned = owned_products(self.plan, self.rank)
         self.returns = []
-        if self.group > 1 and len(self.bounds) == 1 and len(self.cbounds) == 1:
-            lo, hi, _, _ = self.bounds[0]
-            w0, w1 = self.cbounds[0]
+        if self._grouped():
             for q0 in range(0, self.rounds, self.group):
                 qs = range(q0, min(q0 + self.group, self.rounds))
-                for q in qs:
-                    self.inbound[(1, q, 0)].wait()
-                    self.inbound[(0, q, 0)].wait()
+                self.inbound[("group", q0)].wait()
                 count = sum(1 for q in qs if q < len(owned))
                 if count:
                     self.product_group(q0, count)
-                for q in qs:
-                    self.returns.append(self._batch(2, q, lo, hi, w0, w1))
+                self.returns.append(self._group_batch((2,), q0))
             return
         for q in range(self.rounds):
             for c, (lo, hi, row0, rows) in enumerate(self.bounds):
