@@ -99,6 +99,26 @@ def test_addsqr_aliasing(oracle, n, k, cutoff):
     assert C.equal(want)
 
 
+@pytest.mark.parametrize("m,l,n,cutoff", [(111, 111, 111, 64), (248, 92, 1024, 64), (127, 300, 86, 64), (300, 127, 127, 64), (86, 86, 86, 64),
+                                          (200, 200, 200, 128), (255, 171, 255, 128)])
+def test_hints_the_reference_recursion_cannot_take(oracle, m, l, n, cutoff):
+    """A cutoff of 64 (128) with a dimension in 86 .. 127 (171 .. 255) leaves the reference's own recursion with empty quadrants:
+    its _mzd_addmul_even and _mzd_sqr_even (strassen.c:396-420, :210-240, no guard for them) abort in mzd_copy or read out of bounds
+    (found by tests/soak_mul.py).  A hint changes no bit, so the result is the one of cutoff 0 -- which is what the library gives."""
+    A, B = _pair(m, l, n, 35)
+    C0 = Mzd.random(m, n, shapes.seed_of(35, m, l, n, 3))
+    want, want_add = oracle.mul(None, A, B, 0), oracle.addmul(C0.copy(), A, B, 0)
+    assert m4ri_amd.mzd_mul(None, A, B, cutoff).equal(want)
+    assert m4ri_amd.mzd_addmul(C0.copy(), A, B, cutoff).equal(want_add)
+    assert m4ri_amd._mzd_addmul_even(C0.copy(), A, B, cutoff).equal(want_add)
+    if m == l == n:
+        sq, sq_add = oracle.mul(None, A, A, 0), oracle.addmul(C0.copy(), A, A, 0)
+        assert m4ri_amd.mzd_mul(None, A, A, cutoff).equal(sq)
+        C = C0.copy()
+        m4ri_amd.lib()._mzd_addsqr_even(C.ptr, A.ptr, cutoff)
+        assert C.equal(sq_add)
+
+
 @pytest.mark.parametrize("m,l,n", shapes.EMPTY_INNER)
 def test_empty_inner_dimension(m, l, n):
     A, B = Mzd.init(m, l), Mzd.init(l, n)
