@@ -59,6 +59,7 @@ def test_mul(oracle, m, l, n, k, cutoff):
     assert m4ri_amd.mzd_mul(Mzd.random(m, n, 5), A, B, cutoff).equal(want)  # dirty C is overwritten
     assert m4ri_amd.mzd_mul_m4rm(None, A, B, k).equal(want)            # leaf only
     assert m4ri_amd.mzd_mul_mp(None, A, B, cutoff).equal(want)
+    assert m4ri_amd.mzd_mul_mp(Mzd.random(m, n, 7), A, B, cutoff).equal(want)  # dirty C is overwritten (the reference's adds its strips: test_oracle_vs_reference)
     if m and n:
         assert m4ri_amd._mzd_mul_even(Mzd.init(m, n), A, B, max(64, cutoff)).equal(want)
         assert m4ri_amd._mzd_mul_m4rm(Mzd.random(m, n, 6), A, B, k, 1).equal(want)

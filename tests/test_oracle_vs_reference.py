@@ -159,3 +159,25 @@ def test_fill_matches_reference_randomize_custom(oracle, reference):
             w1.fill_splitmix(5)
             ref_fill(w2, 5)
             assert np.array_equal(P1.buf, P2.buf), ("window", c)
+
+
+def test_reference_mul_mp_needs_a_zero_result_block_for_ragged_shapes(oracle):
+    """Pins a defect of the reference the parity runs have to know about (found by tests/soak_large.py): mzd_mul_mp(C, A, B) is documented
+    as C = AB with a preallocated C (mp.h:34-47), but _mzd_mul_mp4 (mp.c:212-235) ADDS the remainder strips of a ragged product onto
+    whatever C held -- so it equals mzd_mul only on a zero result block (or dimensions that are multiples of 128).  libm4ri_amd.so's
+    mzd_mul_mp overwrites C like mzd_mul does; a checker that calls the reference's multi-core path must hand it a zero C."""
+    import cpu_libs
+    omp = cpu_libs.reference(openmp=True)
+    if omp is None or not omp.has_mp:
+        pytest.skip("oracle/_ref/libm4ri_ref_omp.so not built")
+    m, l, n = 6100, 6250, 6190           # above the cutoff in every dimension, none a multiple of 128
+    A, B = Mzd.random(m, l, 71), Mzd.random(l, n, 72)
+    want = oracle.mul(None, A, B, 0)
+    assert omp.mul_mp(Mzd.init(m, n), A, B, 0).equal(want)
+    dirty = omp.mul_mp(Mzd.random(m, n, 73), A, B, 0)
+    assert not dirty.equal(want)
+    a, c = m - m % 128, n - n % 128      # the even block is a product, the strips are not
+    assert np.array_equal(dirty.window(0, 0, a, c).masked(), want.window(0, 0, a, c).masked())
+    mm, ll, nn = 6144, 6272, 6400        # multiples of 128: no strips, no defect
+    A, B = Mzd.random(mm, ll, 74), Mzd.random(ll, nn, 75)
+    assert omp.mul_mp(Mzd.random(mm, nn, 76), A, B, 0).equal(oracle.mul(None, A, B, 0))
