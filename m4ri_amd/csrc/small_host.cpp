@@ -9,11 +9,17 @@
 // interposing.  This is an algorithm choice made on an initialised device, never a fallback: a HIP failure still aborts, and the
 // library still refuses to work without its GPU (the entry points bind the device before they look at the size).
 //
-// Own code, the textbook algorithm: the inner dimension in groups of 4 or 8 rows of B (by the number of rows of A), one table of
-// their XOR combinations per group (built by doubling), every row of A looks its nibble / byte up and adds the entry to an
-// accumulator row; fewer than 16 rows add B's rows bit by bit; windows (row stride
-// larger than the width, dirty bits beyond the last column) are handled by masking what is read and merging what is written
-// under the column mask (mzd.h:117-123).
+// Own code.  Generation 2 (round 6; the first one was the textbook loop: one table per 4 or 8 inner bits, one pass over C per table,
+// 1.2 ... 2 x SLOWER than the reference between 96^3 and 400^3 -- tests/small_host_timing.c):
+//   * the columns of C in blocks of at most 8 words whose width is a compile-time constant: an accumulator row lives in registers,
+//     the word loops vectorise;
+//   * a whole 64-bit word of A per pass: its bits are cut into c chunks of K or K + 1 bits (K from the number of rows:
+//     the minimum of (2^K + m) / K row operations per inner bit), ONE table of XOR combinations of the rows of B per chunk, built by
+//     doubling, and every row of A adds its c table entries to its accumulator row in ONE read-modify-write (what the reference gets
+//     from its eight tables per pass, brilliantrussian.c:1111-1154);
+//   * a handful of rows (at most 12, or 24 when a row of C has more than one word): every set bit of A adds one row of B, no tables;
+//   * windows (row stride larger than the width, dirty bits beyond the last column) are handled by masking what is read -- only
+//     the last word of a row needs it -- and merging what is written under the column mask (mzd.h:117-123).
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -23,73 +29,190 @@
 namespace {
 
 constexpr uint8_t FLAG_WINDOW = 0x4;  // mzd.h:150
+constexpr int MIN_K = 3, MAX_K = 8;
+constexpr int MAX_CHUNKS = 64 / MIN_K + 1;
+constexpr int BLOCK_W = 8;            // words of C per column block
+// at most this many rows: no tables (measured against the tables on 9 ... 64 rows: rows of one word 21.5 against 23.0 us at 12 rows and
+// 29.5 against 26.4 at 16; wider rows 10.5 against 14.4 us at 16 rows, 15.8 against 16.8 at 24, 21.2 against 19.7 at 32)
+inline int bitwise_rows(wi_t wn) { return wn >= 2 ? 24 : 12; }
+constexpr size_t KEEP_WORDS = (size_t)1 << 20;
 
-// row i of M, word k, with the bits beyond the last column cleared
-inline word rd(const mzd_t *M, rci_t i, wi_t k) {
-  const word v = M->data[(int64_t)i * M->rowstride + k];
-  return k == M->width - 1 ? (v & M->high_bitmask) : v;
+struct Scratch {
+  std::vector<word> acc, table;
+};
+thread_local Scratch t_scratch;
+
+// bits per table for m rows: the K that minimises (2^K + m) / K, the row operations per inner bit (table building + lookups)
+int pick_k(int64_t m) {
+  int best = MIN_K;
+  double cost = 1e300;
+  for (int K = MIN_K; K <= MAX_K; ++K) {
+    const double c = ((double)(1 << K) + (double)m) / (double)K;
+    if (c < cost) { cost = c; best = K; }
+  }
+  return best;
+}
+
+// One column block of W words (first word k0 of the rows of B and of the accumulator; `bmask` = mask of the block's last word of B):
+// acc[i][0 .. W) ^= sum over the inner dimension of A[i][j] * B[j][k0 .. k0 + W)
+template <int W>
+void block_tables(word *acc, int64_t acc_stride, const mzd_t *A, const mzd_t *B, wi_t k0, word bmask, int K, word *table) {
+  const rci_t m = A->nrows, l = A->ncols;
+  const wi_t wl = A->width;
+  for (wi_t q = 0; q < wl; ++q) {
+    const int bits = (l - (rci_t)q * 64) < 64 ? (int)(l - (rci_t)q * 64) : 64;
+    const int c    = (bits + K - 1) / K;  // chunks of this word: `extra` of them one bit longer than the others
+    const int base = bits / c, extra = bits % c;
+    int off[MAX_CHUNKS];
+    word msk[MAX_CHUNKS];
+    const word *tab[MAX_CHUNKS];
+    word *t = table;
+    for (int u = 0, o = 0; u < c; ++u) {
+      const int s = base + (u < extra ? 1 : 0);
+      off[u] = o;
+      msk[u] = ((word)1 << s) - 1;
+      tab[u] = t;
+      // t[x] = XOR of the rows 64 q + o + b of B with bit b of x set, by doubling
+      for (int k = 0; k < W; ++k) t[k] = 0;
+      for (int b = 0; b < s; ++b) {
+        const word *brow = B->data + (int64_t)((rci_t)q * 64 + o + b) * B->rowstride + k0;
+        word r[W];
+        for (int k = 0; k < W; ++k) r[k] = brow[k];
+        r[W - 1] &= bmask;
+        const size_t half = (size_t)1 << b;
+        word *dst = t + half * W;
+        for (size_t x = 0; x < half; ++x)
+          for (int k = 0; k < W; ++k) dst[x * W + k] = t[x * W + k] ^ r[k];
+      }
+      t += ((size_t)1 << s) * W;
+      o += s;
+    }
+    // (per-chunk offsets, masks and table pointers from small arrays: the lookups of a row are independent of each other; shifting
+    // the word of A along chunk by chunk instead makes them a dependent chain and measures 10 ... 25 % slower on narrow blocks)
+    const word amask = q == wl - 1 ? A->high_bitmask : ~(word)0;
+    const word *ap   = A->data + q;
+    for (rci_t i = 0; i < m; ++i) {
+      const word a = ap[(int64_t)i * A->rowstride] & amask;
+      if (!a) continue;
+      word *dst = acc + (int64_t)i * acc_stride;
+      word v[W];
+      for (int k = 0; k < W; ++k) v[k] = dst[k];
+      for (int u = 0; u < c; ++u) {
+        const word *e = tab[u] + (size_t)((a >> off[u]) & msk[u]) * W;
+        for (int k = 0; k < W; ++k) v[k] ^= e[k];
+      }
+      for (int k = 0; k < W; ++k) dst[k] = v[k];
+    }
+  }
+}
+
+// the same for a handful of rows: every set bit of A adds one row of B
+template <int W>
+void block_bitwise(word *acc, int64_t acc_stride, const mzd_t *A, const mzd_t *B, wi_t k0, word bmask) {
+  const rci_t m = A->nrows;
+  const wi_t wl = A->width;
+  for (rci_t i = 0; i < m; ++i) {
+    word v[W];
+    word *dst = acc + (int64_t)i * acc_stride;
+    for (int k = 0; k < W; ++k) v[k] = 0;
+    const word *ap = A->data + (int64_t)i * A->rowstride;
+    for (wi_t q = 0; q < wl; ++q) {
+      word a = ap[q] & (q == wl - 1 ? A->high_bitmask : ~(word)0);
+      const word *bq = B->data + (int64_t)q * 64 * B->rowstride + k0;
+      for (; a; a &= a - 1) {
+        const word *brow = bq + (int64_t)__builtin_ctzll(a) * B->rowstride;
+        for (int k = 0; k < W; ++k) v[k] ^= brow[k];
+      }
+    }
+    v[W - 1] &= bmask;  // (XOR and the mask commute: masking the sum once is masking every row)
+    for (int k = 0; k < W; ++k) dst[k] ^= v[k];
+  }
+}
+
+template <int W>
+void block(word *acc, int64_t acc_stride, const mzd_t *A, const mzd_t *B, wi_t k0, word bmask, int K, word *table) {
+  if (K == 0) block_bitwise<W>(acc, acc_stride, A, B, k0, bmask);
+  else block_tables<W>(acc, acc_stride, A, B, k0, bmask, K, table);
+}
+
+// row operations (table entries built + lookups) of the words of A that hold `bits` inner bits, for m rows
+double word_row_ops(int bits, int K, int64_t m) {
+  const int c = (bits + K - 1) / K, base = bits / c, extra = bits % c;
+  return (double)extra * (double)(2 << base) + (double)(c - extra) * (double)(1 << base) + (double)m * (double)c;
 }
 
 }  // namespace
+
+// What the routine below costs, in word operations: its row operations (table entries + lookups, or one per set bit of A for a
+// handful of rows) times the words of a row of C plus 2.5 per column block (a row operation on a block of W words measures 0.084 (W + 2.5) ns on
+// the GPU boxes' host cores: 512^3 41.8 us, 256^3 7.4 us, 512 x 512 x 8 13.4 us -- profiles/r06_small_products_host_routine.log),
+// plus the accumulator's way in and out.  The size switch of the entry points (mzd_api.hip: small_product_wanted) bounds it.
+extern "C" double gf2_small_host_cost(int64_t m, int64_t l, int64_t n) {
+  if (m <= 0 || n <= 0) return 0.0;
+  const double wn = (double)((n + 63) / 64), nblocks = (double)(((n + 63) / 64 + BLOCK_W - 1) / BLOCK_W);
+  double row_ops;
+  if (m <= bitwise_rows((wi_t)((n + 63) / 64))) {
+    row_ops = 0.5 * (double)m * (double)l;
+  } else {
+    const int K = pick_k(m);
+    row_ops     = (double)(l / 64) * word_row_ops(64, K, m) + (l % 64 ? word_row_ops((int)(l % 64), K, m) : 0.0);
+  }
+  return row_ops * (wn + 2.5 * nblocks) + 2.0 * (double)m * wn;
+}
 
 extern "C" int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B, int add) {
   if (!C || !A || !B || A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols) return -1;
   const rci_t m = A->nrows, l = A->ncols, n = B->ncols;
   if (m == 0 || n == 0) return 0;
-  const wi_t wn = C->width, wl = A->width;
-  std::vector<word> acc((size_t)m * (size_t)wn, 0);
-  if (add)
-    for (rci_t i = 0; i < m; ++i)
-      for (wi_t k = 0; k < wn; ++k) acc[(size_t)i * wn + k] = rd(C, i, k);
+  const wi_t wn = C->width;
+  Scratch &S = t_scratch;
+  if (S.acc.size() < (size_t)m * (size_t)wn) S.acc.resize((size_t)m * (size_t)wn);
+  word *acc = S.acc.data();
+  if (add) {
+    for (rci_t i = 0; i < m; ++i) {
+      const word *c = C->data + (int64_t)i * C->rowstride;
+      word *a       = acc + (size_t)i * wn;
+      for (wi_t k = 0; k < wn; ++k) a[k] = c[k];
+      a[wn - 1] &= C->high_bitmask;
+    }
+  } else {
+    std::memset(acc, 0, (size_t)m * (size_t)wn * 8);
+  }
   if (l > 0) {
-    if (m < 16) {
-      // a handful of rows: tables would cost more than they save -- every set bit of A adds one row of B
-      for (rci_t i = 0; i < m; ++i) {
-        word *a = &acc[(size_t)i * wn];
-        for (wi_t q = 0; q < wl; ++q)
-          for (word bitsleft = rd(A, i, q); bitsleft; bitsleft &= bitsleft - 1) {
-            const rci_t j = (rci_t)(q * 64 + __builtin_ctzll(bitsleft));
-            for (wi_t k = 0; k < wn; ++k) a[k] ^= rd(B, j, k);
-          }
+    const int K = m <= bitwise_rows(wn) ? 0 : pick_k(m);  // 0: no tables
+    // the tables of one word of A: at most 64 / K + 1 chunks of at most K + 1 bits
+    const size_t tw = K ? (size_t)(64 / K + 1) * ((size_t)2 << K) * BLOCK_W : 0;
+    if (S.table.size() < tw) S.table.resize(tw);
+    word *table = S.table.data();
+    // column blocks of (almost) equal width: 9 words are 5 + 4, not 8 + 1 -- a one-word block costs as many lookups as a full one
+    const wi_t nblocks = (wn + BLOCK_W - 1) / BLOCK_W, wbase = wn / nblocks, wextra = wn % nblocks;
+    wi_t k0 = 0;
+    for (wi_t blk = 0; blk < nblocks; ++blk) {
+      const int w      = (int)(wbase + (blk < wextra ? 1 : 0));
+      const word bmask = (k0 + w == wn) ? B->high_bitmask : ~(word)0;
+      word *a0         = acc + k0;
+      switch (w) {
+        case 1: block<1>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 2: block<2>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 3: block<3>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 4: block<4>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 5: block<5>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 6: block<6>(a0, wn, A, B, k0, bmask, K, table); break;
+        case 7: block<7>(a0, wn, A, B, k0, bmask, K, table); break;
+        default: block<8>(a0, wn, A, B, k0, bmask, K, table); break;
       }
-    } else {
-      // groups of K rows of B, one table of their 2^K XOR combinations per group; per inner bit that costs (2^K + m) / K row
-      // operations: K = 4 below 224 rows, K = 8 above (both divide 64: a group never straddles a word of A)
-      const int K = m < 224 ? 4 : 8;
-      std::vector<word> table(((size_t)1 << K) * (size_t)wn);
-      for (rci_t g0 = 0; g0 < l; g0 += K) {
-        const int bits = (l - g0) < K ? (int)(l - g0) : K;
-        // table[x] = XOR of the rows g0 + b of B with bit b of x set, by doubling: the second half of every step is the first
-        // half plus one more row
-        std::memset(table.data(), 0, (size_t)wn * 8);
-        for (int b = 0; b < bits; ++b) {
-          const size_t half = (size_t)1 << b;
-          for (size_t x = 0; x < half; ++x) {
-            const word *src = &table[x * (size_t)wn];
-            word *dst       = &table[(x + half) * (size_t)wn];
-            for (wi_t k = 0; k < wn; ++k) dst[k] = src[k] ^ rd(B, g0 + b, k);
-          }
-        }
-        const wi_t aw      = g0 / 64;
-        const int shift    = g0 % 64;
-        const word lowbits = ((word)1 << bits) - 1;
-        for (rci_t i = 0; i < m; ++i) {
-          const size_t x = (size_t)((rd(A, i, aw) >> shift) & lowbits);
-          if (!x) continue;
-          const word *t = &table[x * (size_t)wn];
-          word *a       = &acc[(size_t)i * wn];
-          for (wi_t k = 0; k < wn; ++k) a[k] ^= t[k];
-        }
-      }
+      k0 += w;
     }
   }
   // the result, under the column mask: bits of C's last word beyond its columns keep their value in a window and end up zero otherwise
   const bool window = (C->flags & FLAG_WINDOW) != 0;
   for (rci_t i = 0; i < m; ++i) {
-    word *c = C->data + (int64_t)i * C->rowstride;
-    for (wi_t k = 0; k + 1 < wn; ++k) c[k] = acc[(size_t)i * wn + k];
-    const word v = acc[(size_t)i * wn + wn - 1] & C->high_bitmask;
+    word *c       = C->data + (int64_t)i * C->rowstride;
+    const word *a = acc + (size_t)i * wn;
+    for (wi_t k = 0; k + 1 < wn; ++k) c[k] = a[k];
+    const word v = a[wn - 1] & C->high_bitmask;
     c[wn - 1]    = window ? ((c[wn - 1] & ~C->high_bitmask) | v) : v;
   }
+  if (S.acc.size() > KEEP_WORDS) std::vector<word>().swap(S.acc);  // a thread keeps at most 8 MiB of accumulator between calls
   return 0;
 }

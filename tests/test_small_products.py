@@ -93,13 +93,14 @@ def test_entry_points_take_the_host_routine_exactly_when_they_should(oracle):
 
 
 def test_host_routine_fuzz_shapes_and_windows(oracle):
-    """Seeded fuzz of the host routine alone: random shapes around its three regimes (fewer than 16 rows, 4-bit tables, 8-bit tables),
-    mul and addmul, operands and result windows of larger parents; every word of C's parent is compared."""
+    """Seeded fuzz of the host routine alone: random shapes around its regimes (at most 8 rows: no tables; 3- to 8-bit tables by the
+    number of rows; one to several column blocks), mul and addmul, operands and result windows of larger parents; every word of C's
+    parent is compared."""
     import os
     rng = np.random.default_rng(int(os.environ.get("M4RI_AMD_FUZZ_SEED", "20260929")))
     for case in range(int(os.environ.get("M4RI_AMD_FUZZ_CASES", "150"))):
-        m = int(rng.choice([rng.integers(1, 16), rng.integers(16, 224), rng.integers(224, 400)]))
-        l, n = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        m = int(rng.choice([rng.integers(1, 16), rng.integers(16, 224), rng.integers(224, 400), rng.integers(400, 1600)]))
+        l, n = int(rng.integers(1, 400)), int(rng.choice([rng.integers(1, 400), rng.integers(400, 1300)]))
         add = bool(rng.integers(0, 2))
 
         def operand(rows, cols, seed):
@@ -125,16 +126,21 @@ def test_host_routine_fuzz_shapes_and_windows(oracle):
 
 
 def test_which_products_the_host_routine_takes_is_a_cost_rule():
-    """m * l * n alone sent 1 x 1 x 2^26 and 2^26 x 1 x 1 to a single-threaded loop: the rule now also bounds the
-    routine's own cost in row-word operations (pure arithmetic: m4ri_amd_small_product_wanted, default threshold 2^26)."""
-    old = m4ri_amd.set_small_product_threshold(1 << 26)
+    """m * l * n alone sent 1 x 1 x 2^26 and 2^26 x 1 x 1 to a single-threaded loop: the rule also bounds the
+    routine's own cost in word operations of ITS algorithm (pure arithmetic: m4ri_amd_small_product_wanted, default threshold 2^27 since
+    the routine's second generation: profiles/r06_small_products_host_routine.log)."""
+    old = m4ri_amd.set_small_product_threshold(1 << 27)
     try:
         w = m4ri_amd.lib().m4ri_amd_small_product_wanted
-        for shape in [(1, 1, 1), (64, 64, 64), (256, 256, 256), (384, 384, 384), (1000, 10, 20), (16, 4096, 16), (4096, 16, 64), (64, 64, 4096), (2048, 64, 64)]:
-            assert w(*shape) == 1, shape                 # the measured wins of profiles/r04_crossover_cpu_gpu.log stay on the host
-        for shape in [(1, 1, 1 << 26), (1 << 26, 1, 1), (1, 1 << 26, 1), (8, 8192, 1024), (512, 512, 512), (1 << 20, 8, 8), (100000, 1, 600)]:
-            assert w(*shape) == 0, shape                 # degenerate or simply too large: the GPU
+        for shape in [(1, 1, 1), (64, 64, 64), (256, 256, 256), (384, 384, 384), (512, 512, 512), (1000, 10, 20), (16, 4096, 16), (4096, 16, 64),
+                      (64, 64, 4096), (2048, 64, 64), (1024, 256, 256), (256, 1024, 256), (256, 256, 1024), (2048, 16, 2048), (512, 512, 8)]:
+            assert w(*shape) == 1, shape                 # the measured wins against the GPU path stay on the host
+        for shape in [(1, 1, 1 << 26), (1 << 26, 1, 1), (1, 1 << 26, 1), (8, 8192, 1024), (576, 576, 576), (1024, 1024, 1024), (1 << 20, 8, 8),
+                      (100000, 1, 600), (2048, 2048, 16), (4096, 64, 4096), (128, 128, 8192)]:
+            assert w(*shape) == 0, shape                 # degenerate, or the GPU path is as fast or faster: the GPU
         assert w(0, 5, 5) == 0 and w(5, 0, 5) == 1       # an empty inner dimension is a clear of C: nothing to upload
+        m4ri_amd.set_small_product_threshold(1 << 26)    # the bound scales with the threshold
+        assert w(384, 384, 384) == 1 and w(512, 512, 512) == 0
         m4ri_amd.set_small_product_threshold(0)
         assert w(4, 4, 4) == 0
     finally:
@@ -148,7 +154,7 @@ def test_parity_at_the_default_threshold(oracle):
     names, every result the oracle's."""
     assert m4ri_amd.lib().m4ri_amd_device_count() >= 1
     m4ri_amd.init(0)
-    old = m4ri_amd.set_small_product_threshold(1 << 26)
+    old = m4ri_amd.set_small_product_threshold(1 << 27)
     try:
         took_host = took_gpu = 0
         for (m, l, n, k, cutoff) in shapes.MUL + shapes.EDGE + [(1, 1, 70000, 0, 0), (3000, 2, 3000, 0, 0)]:
