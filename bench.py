@@ -69,7 +69,7 @@ def cpu_baseline_or_note(n_workload: int):
 # ---------------------------------------------------------------------------------------------------
 # models and measurements around the number
 # ---------------------------------------------------------------------------------------------------
-LEAF_KERNELS = {1: "m4rm_leaf_kernel", 4: "m4rm8q_kernel"}
+LEAF_KERNELS = {1: "m4rm_leaf_kernel", 4: "m4rm8q_kernel", 5: "m4rm_small_kernel"}
 # (tile rows, tile columns, inner bits per stage, LDS-array clocks per stage): gathers at 256 B/clk/CU
 # + table writes at 128 B/clk/CU, both measured with tools/ubench.hip
 LEAF_LDS_MODEL = {4: (4096, 512, 32, 4608)}

@@ -320,7 +320,7 @@ typedef struct m4ri_amd_stats {
   int64_t leaf_products;    /* products those launches computed (batch members)     */
   int32_t leaf_m, leaf_l, leaf_n; /* shape of the batched leaves                     */
   int32_t leaf_gen;         /* generation of the leaf kernel used: 1 m4rm_leaf,
-                               3 m4rm8, 4 m4rm8q                                     */
+                               4 m4rm8q, 5 m4rm_small (small products, one launch)  */
   double leaf_ms;           /* sum of leaf launch durations (profiling on), else 0  */
   double leaf_bytes;        /* algorithmic bytes of the leaf launches:
                                8*(m*W(l) + l*W(n) + m*W(n)) per product             */

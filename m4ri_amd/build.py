@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libm4ri_amd.so")
-SOURCES = ["m4rm_leaf.hip", "a4_pack.hip", "m4rm8q_leaf.hip", "aux_kernels.hip", "scheme_passes.hip", "engine.hip", "mzd_api.hip", "multi.hip", "trsm.hip", "ple.hip", "elim.hip", "echelon.hip", "solve.hip", "transpose.hip", "io.cpp", "small_host.cpp"]
+SOURCES = ["m4rm_leaf.hip", "a4_pack.hip", "m4rm8q_leaf.hip", "m4rm_small.hip", "aux_kernels.hip", "scheme_passes.hip", "engine.hip", "mzd_api.hip", "multi.hip", "trsm.hip", "ple.hip", "elim.hip", "echelon.hip", "solve.hip", "transpose.hip", "io.cpp", "small_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fvisibility-inlines-hidden"]
 
 

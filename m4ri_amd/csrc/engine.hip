@@ -28,6 +28,8 @@
 
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
+hipError_t gf2_launch_m4rm_small(hipStream_t stream, LeafArgs a);
+int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *gchild,
@@ -229,6 +231,19 @@ LeafKind pick_leaf(int64_t m, int64_t l, int64_t n) {
   return best;
 }
 
+// Small products take the light one-launch kernel (m4rm_small.hip, "generation 5"): below this much work the three dependent
+// launches of generation 4 (pack, split leaf, reduce) cost more than its better tables save.  M4RI_AMD_SMALL_LEAF=0 never, =1 whenever
+// the kernel can (tests), unset: the measured rule.
+bool small_leaf_wanted(int64_t m, int64_t l, int64_t n, int64_t batch) {
+  static const int sw = getenv("M4RI_AMD_SMALL_LEAF") ? atoi(getenv("M4RI_AMD_SMALL_LEAF")) : -1;
+  if (sw == 0) return false;
+  if (m > INT32_MAX / 2 || l > INT32_MAX / 2 || n > INT32_MAX / 2) return false;
+  if (((m + 255) / 256) * ((words_of(n) + 7) / 8) * batch * 32 > 0x7fffffffLL) return false;
+  if (sw > 0) return true;
+  static const double max_work = getenv("M4RI_AMD_SMALL_LEAF_WORK") ? atof(getenv("M4RI_AMD_SMALL_LEAF_WORK")) : 17179869184.0;  // 2^34 bit operations
+  return (double)m * (double)l * (double)n * (double)batch <= max_work;
+}
+
 // Do the fused bottom `fuse` levels of a product with these LEAF dimensions run through the rank-R scheme of the 4 x 4 x 4 block
 // product (scheme_passes.hip)?  ONE rule for the time model (depth_model_seconds) and the schedule (bfs_product): generation 4's
 // packed A (the scheme's A-side pass writes it), leaf shapes the scheme kernels take, one packed operand within a buffer descriptor.
@@ -261,8 +276,42 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   // 32-bit byte offsets inside one operand (raw buffer addressing)
   if ((uint64_t)m * (uint64_t)as * 8 >= (1ull << 32) || (uint64_t)l * (uint64_t)bs * 8 >= (1ull << 32))
     return (int)hipErrorInvalidValue;
-  LeafKind kind      = pick_leaf(m, l, n);
   const int64_t wn   = words_of(n);
+  if (!a_prepacked && ksplit_req <= 0 && l > 0 && small_leaf_wanted(m, l, n, batch)) {
+    // a small product: ONE launch of the light kernel (m4rm_small.hip) instead of pack + split leaf + reduce
+    const int64_t tiles = ((m + 255) / 256) * ((wn + 7) / 8) * batch;
+    const int ks        = gf2_m4rm_small_ksplit(tiles, words_of(l), e->cus);
+    if (ks > 1 && !add) {  // the splits meet by atomic XOR: they start from zero
+      if (cs == wn && (batch == 1 || cbs == m * wn)) HIPTRY(hipMemsetAsync(C, 0, (size_t)batch * m * wn * 8, st));
+      else
+        for (int64_t b = 0; b < batch; ++b) HIPTRY(gf2_launch_rowwise(st, 2, C + b * cbs, cs, nullptr, 0, nullptr, 0, m, wn));
+    }
+    LeafArgs a{};
+    a.A = A; a.B = B; a.C = C;
+    a.a_stride = as; a.b_stride = bs; a.c_stride = cs;
+    a.a_bs = abs_; a.b_bs = bbs; a.c_bs = cbs;
+    a.m = (int32_t)m; a.l = (int32_t)l; a.n = (int32_t)n;
+    a.batch = (int32_t)batch; a.ksplit = ks;
+    a.mode  = (add || ks > 1) ? 1 : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e->profiling) {
+      e0 = take_event(e); e1 = take_event(e);
+      if (e0 && e1) HIPTRY(hipEventRecord(e0, st));
+    }
+    HIPTRY(gf2_launch_m4rm_small(st, a));
+    if (e->profiling && e0 && e1) {
+      HIPTRY(hipEventRecord(e1, st));
+      e->pending.push_back({e0, e1, e->call_seq});
+      e->pending_stream = st;
+    }
+    e->stats.leaf_launches += 1;
+    e->stats.leaf_products += batch;
+    e->stats.leaf_m = (int32_t)m; e->stats.leaf_l = (int32_t)l; e->stats.leaf_n = (int32_t)n;
+    e->stats.leaf_gen = 5;
+    e->stats.leaf_bytes += 8.0 * (double)batch * ((double)m * words_of(l) + (double)l * wn + (double)m * wn * (add ? 2 : 1));
+    return 0;
+  }
+  LeafKind kind      = pick_leaf(m, l, n);
   const int64_t tw   = kind.gen == 4 ? 8 : LEAF_TW;  // tile width in words
   const int64_t tiles = ((m + kind.rows - 1) / kind.rows) * ((wn + tw - 1) / tw) * batch;
   const int64_t sbits  = kind.gen == 4 ? 32 : 16;  // inner bits per stage (barrier to barrier)
