@@ -138,7 +138,7 @@ extern "C" int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus) {
   if (tiles <= 0 || wl < 4) return 1;
   int64_t ks = (cus + tiles - 1) / tiles;  // one workgroup per CU
   if (ks > wl / 2) ks = wl / 2;
-  if (ks > 32) ks = 32;
+  if (ks > 256) ks = 256;  // (ks * tiles stays about one workgroup per CU: the atomics are few)
   return ks < 2 ? 1 : (int)ks;
 }
 
