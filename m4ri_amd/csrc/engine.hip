@@ -29,7 +29,7 @@
 extern "C" {
 hipError_t gf2_launch_m4rm_leaf(hipStream_t stream, LeafArgs a, int rg);
 hipError_t gf2_launch_m4rm_small(hipStream_t stream, LeafArgs a);
-int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus);
+int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus, int64_t c_words);
 hipError_t gf2_launch_a4_pack_rot(hipStream_t stream, LeafArgs a, word *a4_ws, int rot);
 int gf2_winograd_down2_pack_ok(const word *gparent, int64_t p_stride, int64_t p_bs, const word *a4, int64_t crows, int64_t cw);
 hipError_t gf2_launch_winograd_down3(hipStream_t s, int bside, const word *anc, int64_t p_stride, int64_t p_bs, word *gchild,
@@ -280,7 +280,8 @@ int launch_leaf_one(Engine *e, hipStream_t st, word *C, int64_t cs, int64_t cbs,
   if (!a_prepacked && ksplit_req <= 0 && l > 0 && small_leaf_wanted(m, l, n, batch)) {
     // a small product: ONE launch of the light kernel (m4rm_small.hip) instead of pack + split leaf + reduce
     const int64_t tiles = ((m + 255) / 256) * ((wn + 7) / 8) * batch;
-    const int ks        = gf2_m4rm_small_ksplit(tiles, words_of(l), e->cus);
+    static const int ks_env = getenv("M4RI_AMD_SMALL_KS") ? atoi(getenv("M4RI_AMD_SMALL_KS")) : 0;  // developer: force the inner split of the small leaf
+    const int ks        = ks_env > 0 ? (ks_env < words_of(l) ? ks_env : (int)words_of(l)) : gf2_m4rm_small_ksplit(tiles, words_of(l), e->cus, batch * m * wn);
     if (ks > 1 && !add) {  // the splits meet by atomic XOR: they start from zero
       if (cs == wn && (batch == 1 || cbs == m * wn)) HIPTRY(hipMemsetAsync(C, 0, (size_t)batch * m * wn * 8, st));
       else
