@@ -373,10 +373,10 @@ int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes);
    below 54 columns / 16 rows, m4ri/brilliantrussian.c:1063-1068, m4ri/mzd.c:1141-1172); here the switch sits where a call's upload,
    launches and download (28 ... 80 us whatever the size) stop paying: a product with m * l * n at or below the threshold whose
    matrices live in host memory is computed by the library's own host Method of Four Russians (small_host.cpp) on the calling
-   thread -- on an initialised device, never instead of one: without a GPU the entry points still abort.  Default 2^27 (512^3: 42 us
-   on the host, 59 us through the GPU); 0 sends every product to the GPU; returns the previous value, negative arguments only query.
-   The routine's own cost is bounded as well (threshold / 256 word operations of its algorithm, 44 us at the default: degenerate
-   shapes such as 1 x 1 x 2^26 go to the GPU whatever m * l * n says);
+   thread -- on an initialised device, never instead of one: without a GPU the entry points still abort.  Default 2^27; 0 sends
+   every product to the GPU; returns the previous value, negative arguments only query.  The routine's own cost is bounded as well
+   (threshold / 320 word operations of its algorithm, 35 us at the default: 448^3 -- 33 us on the host, 38 through the GPU -- is the
+   largest cube it takes, and degenerate shapes such as 1 x 1 x 2^26 go to the GPU whatever m * l * n says);
    m4ri_amd_small_product_wanted is that rule (pure arithmetic, no GPU: 1 = the host routine would take this product).  The device
    lock is released while the routine runs: small products of many threads run side by side.  m4ri_amd_small_product_count: how
    many products took that path.  m4ri_amd_small_mul_host is the routine itself: C (+)= A * B on host mzd_t (windows allowed, the
