@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/tsan_obj
-SRCS="m4rm_leaf.hip a4_pack.hip m4rm8q_leaf.hip aux_kernels.hip scheme_passes.hip engine.hip mzd_api.hip multi.hip trsm.hip ple.hip elim.hip echelon.hip solve.hip transpose.hip io.cpp small_host.cpp"
+SRCS="m4rm_leaf.hip a4_pack.hip m4rm8q_leaf.hip m4rm_small.hip aux_kernels.hip scheme_passes.hip engine.hip mzd_api.hip multi.hip trsm.hip ple.hip elim.hip echelon.hip solve.hip transpose.hip io.cpp small_host.cpp"
 for s in $SRCS; do
   hipcc --offload-arch=gfx950 -O1 -g -fsanitize=thread -std=c++17 -fPIC -c m4ri_amd/csrc/$s -o build/tsan_obj/${s%.*}.o &
 done

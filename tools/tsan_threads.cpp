@@ -96,9 +96,31 @@ int main(int argc, char **argv) {
     for (int r = 0; r < 200 * reps; ++r)
       for (int i = 2; i < 4; ++i) { (void)m4ri_amd_is_pinned(A[i]); (void)m4ri_amd_is_pinned(B[i]); if (r % 16 == 0) (void)m4ri_amd_sync(B[i]); }
   });
+  // round 6, third session: two more threads stream SMALL products through the entry points -- the library's host routine (thread-local
+  // scratch, the device lock released while it runs) and, above its bound, the one-launch small leaf -- while the others run
+  int bad_small[2] = {0, 0};
+  for (int k = 0; k < 2; ++k)
+    th.emplace_back([&, k] {
+      if (m4ri_amd_init(0)) { bad_small[k] = 100; return; }
+      const int sh[4][3] = {{64, 64, 64}, {200, 300, 100}, {448, 448, 448}, {600, 520, 700}};
+      for (int q = 0; q < 4; ++q) {
+        mzd_t *X = random_matrix(sh[q][0], sh[q][1], 300 + 10 * k + q), *Y = random_matrix(sh[q][1], sh[q][2], 400 + 10 * k + q);
+        mzd_t *first = mzd_mul(NULL, X, Y, 0);
+        for (int r = 0; r < 20 * reps; ++r) {
+          mzd_t *C = mzd_mul(NULL, X, Y, 0);
+          bad_small[k] += !same(C, first);
+          mzd_addmul(C, X, Y, 0);
+          for (rci_t i = 0; i < C->nrows; ++i)
+            for (wi_t w = 0; w < C->width; ++w) bad_small[k] += C->data[(int64_t)i * C->rowstride + w] != 0;
+          m4ri_amd_result_free(C);
+        }
+        m4ri_amd_result_free(first); m4ri_amd_mzd_free(X); m4ri_amd_mzd_free(Y);
+      }
+    });
   for (auto &t : th) t.join();
+  printf("small-product threads: %d + %d mismatches (%lld products took the host routine)\n", bad_small[0], bad_small[1], (long long)m4ri_amd_small_product_count());
   printf("lanes thread: %d mismatches\n", bad_lane);
-  int total = bad_lane;
+  int total = bad_lane + bad_small[0] + bad_small[1];
   for (int i = 0; i < 4; ++i) { printf("thread %d: %d mismatches\n", i, bad[i]); total += bad[i]; }
   m4ri_amd_release_workspace();
   printf("%s\n", total ? "TSAN_THREADS FAILED" : "TSAN_THREADS results ok");
