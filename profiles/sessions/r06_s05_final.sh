@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, the final code: smoke, the driver-style bench lines, the rocprofv3 passes over the default bench, BASELINE configs 2 and 5 on one GPU,
 # the complete N = 8 line on virtual ranks, the whole -m gpu suite
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r06; mkdir -p $O
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=${OUT:-gpurun_out/r06}; mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > $O/bench65536_final.json 2> $O/bench65536_final.err; tail -c 300 $O/bench65536_final.err | grep -v amdgpu
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench65536_final_steps20.json 2>/dev/null
