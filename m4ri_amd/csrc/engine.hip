@@ -238,7 +238,7 @@ bool small_leaf_wanted(int64_t m, int64_t l, int64_t n, int64_t batch) {
   static const int sw = getenv("M4RI_AMD_SMALL_LEAF") ? atoi(getenv("M4RI_AMD_SMALL_LEAF")) : -1;
   if (sw == 0) return false;
   if (m > INT32_MAX / 2 || l > INT32_MAX / 2 || n > INT32_MAX / 2) return false;
-  if (((m + 255) / 256) * ((words_of(n) + 7) / 8) * batch * 256 > 0x7fffffffLL) return false;
+  if ((double)((m + 255) / 256) * (double)((words_of(n) + 7) / 8) * (double)batch * 256.0 > 2147483647.0) return false;  // workgroups of one launch
   if (sw > 0) return true;
   static const double max_work = getenv("M4RI_AMD_SMALL_LEAF_WORK") ? atof(getenv("M4RI_AMD_SMALL_LEAF_WORK")) : 17179869184.0;  // 2^34 bit operations
   return (double)m * (double)l * (double)n * (double)batch <= max_work;
