@@ -350,6 +350,11 @@ int m4ri_amd_plan_levels(int64_t m, int64_t l, int64_t n, int cutoff);
    one level over rows that do not tile).  Writes the first `cap` blocks to rows[] / levels[] (either
    may be NULL) and returns the number of blocks of the plan. */
 int m4ri_amd_plan_row_blocks(int64_t m, int64_t l, int64_t n, int64_t *rows, int *levels, int cap);
+
+/* Does a direct (no Strassen level) product of `batch` members of this shape take the one-launch small leaf (m4rm_small.hip), and with
+   how many inner-dimension splits?  0: no (generation 4 / 1); k >= 1: yes, k splits (k > 1: the splits meet by atomic XOR).  `cus`: the
+   compute units the launch is planned for (0 = 256, an MI355X).  Pure host arithmetic, callable without a GPU. */
+int m4ri_amd_plan_small_leaf(int64_t m, int64_t l, int64_t n, int64_t batch, int cus);
 /* What the engine's time model gives ONE m x l x n product at `levels` Strassen-Winograd levels, in seconds on the box the
    constants were measured on (the plans above are minima of sums of it; tools/depth_model_sweep.py prints it beside measurements). */
 double m4ri_amd_model_seconds(int64_t m, int64_t l, int64_t n, int levels);

@@ -187,6 +187,7 @@ SYMBOLS = {
     "m4ri_amd_set_profiling": (None, [_I]),
     "m4ri_amd_set_max_fuse": (_I, [_I]),
     "m4ri_amd_plan_levels": (_I, [_I64, _I64, _I64, _I]),
+    "m4ri_amd_plan_small_leaf": (_I, [_I64, _I64, _I64, _I64, _I]),
     "m4ri_amd_plan_row_blocks": (_I, [_I64, _I64, _I64, ctypes.c_void_p, ctypes.c_void_p, _I]),
     "m4ri_amd_model_seconds": (ctypes.c_double, [_I64, _I64, _I64, _I]),
     "m4ri_amd_set_workspace_budget": (_I64, [_I64]),

@@ -1125,6 +1125,12 @@ double m4ri_amd_model_seconds_batch(int64_t m, int64_t l, int64_t n, int levels,
   return depth_model_seconds(m, l, n, levels, (double)batch);
 }
 
+int m4ri_amd_plan_small_leaf(int64_t m, int64_t l, int64_t n, int64_t batch, int cus) {
+  if (m <= 0 || l <= 0 || n <= 0 || batch <= 0 || !small_leaf_wanted(m, l, n, batch)) return 0;
+  const int64_t wn = words_of(n), tiles = ((m + 255) / 256) * ((wn + 7) / 8) * batch;
+  return gf2_m4rm_small_ksplit(tiles, words_of(l), cus > 0 ? cus : 256, batch * m * wn);
+}
+
 int m4ri_amd_plan_row_blocks(int64_t m, int64_t l, int64_t n, int64_t *rows, int *levels, int cap) {
   if (m <= 0 || l <= 0 || n <= 0) return 0;
   std::vector<RowBlock> blocks;

@@ -219,3 +219,26 @@ def test_a_rank_multiplies_its_sub_products_in_groups():
     assert two < 1.9 * one and six < 5.5 * one and six > 4.0 * one                      # half-filled last rounds of tiles become full ones
     for L in (0, 1, 2, 3):
         assert m4ri_amd.model_seconds_batch(16384, 16384, 16384, L, 1) == m4ri_amd.model_seconds(16384, 16384, 16384, L)
+
+
+def test_which_direct_products_take_the_small_leaf_and_how_they_are_split():
+    """engine.hip: small_leaf_wanted + m4rm_small.hip: gf2_m4rm_small_ksplit, through m4ri_amd_plan_small_leaf (pure arithmetic).  The rule:
+    direct products of up to 2^34 bit operations, batch included; the inner splits minimise rounds x steps x 1.9 us + 38.5 ps per word of C
+    and split -- pinned here against the picks that were measured on one MI355X (profiles/r06_small_leaf_vs_generation4.log)."""
+    import os
+    if os.environ.get("M4RI_AMD_SMALL_LEAF") or os.environ.get("M4RI_AMD_SMALL_LEAF_WORK"):
+        pytest.skip("the small-leaf rule is overridden by the environment")
+    plan = m4ri_amd.lib().m4ri_amd_plan_small_leaf
+    for (m, l, n, batch, want) in [(512, 512, 512, 1, 8), (2048, 2048, 2048, 1, 4), (2560, 2560, 2560, 1, 4), (8192, 8192, 200, 1, 8), (64, 1 << 20, 64, 1, 256),
+                                   (4096, 256, 4096, 1, 1), (1, 1, 1, 1, 1), (64, 64, 64, 1, 1)]:
+        assert plan(m, l, n, batch, 256) == want, (m, l, n, batch, plan(m, l, n, batch, 256))
+    assert 4 <= plan(1536, 1536, 1536, 1, 256) <= 8 and 12 <= plan(4096, 4096, 256, 1, 256) <= 16   # flat optima: any of these measured the same
+    for (m, l, n, batch) in [(4096, 4096, 4096, 1), (3072, 3072, 3072, 1), (2048, 2048, 2048, 3), (464, 16384, 16421, 1), (0, 5, 5, 1), (5, 0, 5, 1)]:
+        assert plan(m, l, n, batch, 256) == 0, (m, l, n, batch)     # above 2^34 bit operations (batch included), or nothing to multiply
+    assert plan(1024, 1024, 1024, 4, 256) >= 1 and plan(1024, 1024, 1024, 32, 256) == 0
+    # fewer compute units, fewer splits; a split count is always one the launcher keeps (whole steps per split)
+    assert plan(512, 512, 512, 1, 8) <= plan(512, 512, 512, 1, 256)
+    for l in range(64, 64 * 40, 64):
+        k = plan(256, l, 256, 1, 256)
+        steps = -(-(l // 64) // k)
+        assert k >= 1 and -(-(l // 64) // steps) == k, (l, k)
