@@ -1,6 +1,6 @@
 """Developer probe: N calls of mzd_mul on small host matrices (run under rocprofv3 --kernel-trace --stats to see what a call launches)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import m4ri_amd
 from m4ri_amd.mzd import Mzd
 n = int(sys.argv[1]); reps = int(sys.argv[2])
