@@ -380,7 +380,7 @@ int64_t m4ri_amd_set_host_pipeline(int64_t min_bytes);
    matrices live in host memory is computed by the library's own host Method of Four Russians (small_host.cpp) on the calling
    thread -- on an initialised device, never instead of one: without a GPU the entry points still abort.  Default 2^27; 0 sends
    every product to the GPU; returns the previous value, negative arguments only query.  The routine's own cost is bounded as well
-   (threshold / 320 word operations of its algorithm, 35 us at the default: 448^3 -- 33 us on the host, 38 through the GPU -- is the
+   (threshold / 240 word operations of its algorithm, 39 us at the default: 512^3 -- 31 us on the host, 40 through the GPU -- is the
    largest cube it takes, and degenerate shapes such as 1 x 1 x 2^26 go to the GPU whatever m * l * n says);
    m4ri_amd_small_product_wanted is that rule (pure arithmetic, no GPU: 1 = the host routine would take this product).  The device
    lock is released while the routine runs: small products of many threads run side by side.  m4ri_amd_small_product_count: how

@@ -495,20 +495,20 @@ int norm_cutoff(int cutoff, const char *who) {  // strassen.c:348-354
 // exposed.  Same bits as the one-shot schedule (every step is an ordinary product or addmul).  Returns false when the
 // product is too small to pay for it.
 // m * l * n at or below which a product from host memory is computed on the host (m4ri_amd_set_small_product_threshold; the measured
-// crossover against the GPU path on the GPU box, with the small leaf in the engine: 448^3 33 us on the host, 38 through the GPU;
-// 512^3 43 against 37 -- profiles/r06_small_products_host_routine.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
+// crossover against the GPU path on the GPU box, with the small leaf in the engine: 512^3 31 us on the host, 40 through the GPU;
+// 576^3 49 against 47 -- profiles/r06_small_products_host_routine.log).  M4RI_AMD_SMALL_THRESHOLD overrides the default.
 std::atomic<int64_t> g_small_threshold{getenv("M4RI_AMD_SMALL_THRESHOLD") ? atoll(getenv("M4RI_AMD_SMALL_THRESHOLD")) : ((int64_t)1 << 27)};
 std::atomic<int64_t> g_small_count{0};  // products that took the host path
 
 // Does a product of these dimensions go to the host routine?  m * l * n at most the threshold AND the routine's own cost
-// (gf2_small_host_cost of small_host.cpp: word operations of ITS algorithm) at most threshold / 320 -- 2^27 / 320 = 419430, 35 us at the
-// 0.084 ns per word operation it runs at: below the 24 ... 60 us a call through the GPU costs whatever its size.  The second bound is
+// (gf2_small_host_cost of small_host.cpp: word operations of ITS algorithm) at most threshold / 240 -- 2^27 / 240 = 559240, 39 us at the
+// 0.07 ns per word operation it runs at: below the 25 ... 60 us a call through the GPU costs whatever its size.  The second bound is
 // what keeps degenerate shapes -- 1 x 1 x 2^26, 2^26 x 1 x 1 -- away from a single-threaded loop.
 extern "C" double gf2_small_host_cost(int64_t m, int64_t l, int64_t n);
 bool small_product_wanted(int64_t m, int64_t l, int64_t n, int64_t threshold) {
   if (threshold <= 0 || m <= 0 || n <= 0) return false;
   if ((double)m * (double)l * (double)n > (double)threshold) return false;
-  return gf2_small_host_cost(m, l, n) <= (double)threshold / 320.0;
+  return gf2_small_host_cost(m, l, n) <= (double)threshold / 240.0;
 }
 std::atomic<size_t> g_pipeline_min_bytes{(size_t)64 << 20};  // A + B + C bytes from which blocks are used (16384^3: 2.62 -> 2.42 ms, 24576^3: 6.3 -> 5.3 ms); 0 disables (m4ri_amd_set_host_pipeline)
 hipStream_t g_compute_stream[ARENA_DEVICES];

@@ -13,7 +13,8 @@
 // 1.2 ... 2 x SLOWER than the reference between 96^3 and 400^3 -- tests/small_host_timing.c):
 //   * the columns of C in blocks of at most 8 words whose width is a compile-time constant: an accumulator row lives in registers,
 //     the word loops vectorise;
-//   * a whole 64-bit word of A per pass: its bits are cut into c chunks of K or K + 1 bits (K from the number of rows:
+//   * a whole 64-bit word of A per pass (full words with the chunk layout as compile-time constants: offsets, masks and table positions
+//     fold into the instructions -- from small arrays they cost three more loads per lookup): its bits are cut into c chunks of K or K + 1 bits (K from the number of rows:
 //     the minimum of (2^K + m) / K row operations per inner bit), ONE table of XOR combinations of the rows of B per chunk, built by
 //     doubling, and every row of A adds its c table entries to its accumulator row in ONE read-modify-write (what the reference gets
 //     from its eight tables per pass, brilliantrussian.c:1111-1154);
@@ -48,9 +49,57 @@ int pick_k(int64_t m) {
   double cost = 1e300;
   for (int K = MIN_K; K <= MAX_K; ++K) {
     const double c = ((double)(1 << K) + (double)m) / (double)K;
-    if (c < cost) { cost = c; best = K; }
+    if (c <= cost) { cost = c; best = K; }  // (ties go to the larger K: fewer tables to set up)
   }
   return best;
+}
+
+// The lookups of one FULL word of A (64 inner bits) with the chunk layout as compile-time constants -- offsets, masks and table positions
+// fold into the instructions, one load per looked-up word (from small arrays they cost three more loads per lookup: on blocks of one
+// word the load ports were the bound, 13.4 -> 8 us at 16 x 4096 x 16).  Same layout as the builder below: c = ceil(64 / K) chunks, the
+// first 64 % c of them one bit longer.
+template <int W, int K, int U = 0, int O = 0, int T = 0>
+inline void lookups_full(word (&v)[W], word a, const word *table) {
+  constexpr int c = (64 + K - 1) / K, base = 64 / c, extra = 64 % c;
+  if constexpr (U < c) {
+    constexpr int s = base + (U < extra ? 1 : 0);
+    const word *e   = table + (size_t)T * W + (size_t)((a >> O) & (((word)1 << s) - 1)) * W;
+    for (int k = 0; k < W; ++k) v[k] ^= e[k];
+    lookups_full<W, K, U + 1, O + s, T + (1 << s)>(v, a, table);
+  }
+}
+// ... and the tables of a full word with the same constants: chunk U = rows O .. O + s of the word's 64 rows of B, by doubling
+template <int W, int K, int U = 0, int O = 0, int T = 0>
+inline void build_full(word *table, const word *b0, int64_t b_stride, word bmask) {
+  constexpr int c = (64 + K - 1) / K, base = 64 / c, extra = 64 % c;
+  if constexpr (U < c) {
+    constexpr int s = base + (U < extra ? 1 : 0);
+    word *t = table + (size_t)T * W;
+    for (int k = 0; k < W; ++k) t[k] = 0;
+    for (int b = 0; b < s; ++b) {
+      const word *brow = b0 + (int64_t)(O + b) * b_stride;
+      word r[W];
+      for (int k = 0; k < W; ++k) r[k] = brow[k];
+      r[W - 1] &= bmask;
+      const int half = 1 << b;
+      word *dst = t + (size_t)half * W;
+      for (int x = 0; x < half; ++x)
+        for (int k = 0; k < W; ++k) dst[x * W + k] = t[x * W + k] ^ r[k];
+    }
+    build_full<W, K, U + 1, O + s, T + (1 << s)>(table, b0, b_stride, bmask);
+  }
+}
+template <int W, int K>
+void gather_full(word *acc, int64_t acc_stride, const word *ap, int64_t a_stride, rci_t m, const word *table) {
+  for (rci_t i = 0; i < m; ++i) {
+    const word a = ap[(int64_t)i * a_stride];
+    if (!a) continue;
+    word *dst = acc + (int64_t)i * acc_stride;
+    word v[W];
+    for (int k = 0; k < W; ++k) v[k] = dst[k];
+    lookups_full<W, K>(v, a, table);
+    for (int k = 0; k < W; ++k) dst[k] = v[k];
+  }
 }
 
 // One column block of W words (first word k0 of the rows of B and of the accumulator; `bmask` = mask of the block's last word of B):
@@ -61,6 +110,20 @@ void block_tables(word *acc, int64_t acc_stride, const mzd_t *A, const mzd_t *B,
   const wi_t wl = A->width;
   for (wi_t q = 0; q < wl; ++q) {
     const int bits = (l - (rci_t)q * 64) < 64 ? (int)(l - (rci_t)q * 64) : 64;
+    if (bits == 64) {  // a full word of A (no bits beyond the last column: no mask): everything with compile-time chunk layouts
+      const word *b0 = B->data + (int64_t)q * 64 * B->rowstride + k0, *ap = A->data + q;
+#define FULL_(KK) build_full<W, KK>(table, b0, B->rowstride, bmask); gather_full<W, KK>(acc, acc_stride, ap, A->rowstride, m, table)
+      switch (K) {
+        case 3: FULL_(3); break;
+        case 4: FULL_(4); break;
+        case 5: FULL_(5); break;
+        case 6: FULL_(6); break;
+        case 7: FULL_(7); break;
+        default: FULL_(8); break;
+      }
+#undef FULL_
+      continue;
+    }
     const int c    = (bits + K - 1) / K;  // chunks of this word: `extra` of them one bit longer than the others
     const int base = bits / c, extra = bits % c;
     int off[MAX_CHUNKS];
@@ -87,10 +150,10 @@ void block_tables(word *acc, int64_t acc_stride, const mzd_t *A, const mzd_t *B,
       t += ((size_t)1 << s) * W;
       o += s;
     }
-    // (per-chunk offsets, masks and table pointers from small arrays: the lookups of a row are independent of each other; shifting
-    // the word of A along chunk by chunk instead makes them a dependent chain and measures 10 ... 25 % slower on narrow blocks)
-    const word amask = q == wl - 1 ? A->high_bitmask : ~(word)0;
-    const word *ap   = A->data + q;
+    const word *ap = A->data + q;
+    // the last, partial word of A: per-chunk offsets, masks and table pointers from small arrays (the lookups of a row stay independent
+    // of each other; shifting the word along chunk by chunk instead makes them a dependent chain: 10 ... 25 % slower on narrow blocks)
+    const word amask = A->high_bitmask;
     for (rci_t i = 0; i < m; ++i) {
       const word a = ap[(int64_t)i * A->rowstride] & amask;
       if (!a) continue;
@@ -144,8 +207,8 @@ double word_row_ops(int bits, int K, int64_t m) {
 }  // namespace
 
 // What the routine below costs, in word operations: its row operations (table entries + lookups, or one per set bit of A for a
-// handful of rows) times the words of a row of C plus 2.5 per column block (a row operation on a block of W words measures 0.084 (W + 2.5) ns on
-// the GPU boxes' host cores: 512^3 41.8 us, 256^3 7.4 us, 512 x 512 x 8 13.4 us -- profiles/r06_small_products_host_routine.log),
+// handful of rows) times the words of a row of C plus 1.1 per column block (a row operation on a block of W words measures 0.07 (W + 1.1) ns
+// on the GPU boxes' host cores: 512^3 30.0 us, 256^3 5.2 us, 2048 x 2048 x 16 95 us -- profiles/r06_small_products_host_routine.log),
 // plus the accumulator's way in and out.  The size switch of the entry points (mzd_api.hip: small_product_wanted) bounds it.
 extern "C" double gf2_small_host_cost(int64_t m, int64_t l, int64_t n) {
   if (m <= 0 || n <= 0) return 0.0;
@@ -157,7 +220,7 @@ extern "C" double gf2_small_host_cost(int64_t m, int64_t l, int64_t n) {
     const int K = pick_k(m);
     row_ops     = (double)(l / 64) * word_row_ops(64, K, m) + (l % 64 ? word_row_ops((int)(l % 64), K, m) : 0.0);
   }
-  return row_ops * (wn + 2.5 * nblocks) + 2.0 * (double)m * wn;
+  return row_ops * (wn + 1.1 * nblocks) + 2.0 * (double)m * wn;
 }
 
 extern "C" int m4ri_amd_small_mul_host(mzd_t *C, const mzd_t *A, const mzd_t *B, int add) {

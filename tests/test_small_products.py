@@ -132,15 +132,15 @@ def test_which_products_the_host_routine_takes_is_a_cost_rule():
     old = m4ri_amd.set_small_product_threshold(1 << 27)
     try:
         w = m4ri_amd.lib().m4ri_amd_small_product_wanted
-        for shape in [(1, 1, 1), (64, 64, 64), (256, 256, 256), (384, 384, 384), (448, 448, 448), (1000, 10, 20), (16, 4096, 16), (4096, 16, 64),
+        for shape in [(1, 1, 1), (64, 64, 64), (256, 256, 256), (384, 384, 384), (448, 448, 448), (512, 512, 512), (1000, 10, 20), (16, 4096, 16), (4096, 16, 64),
                       (64, 64, 4096), (2048, 64, 64), (1024, 256, 256), (256, 1024, 256), (256, 256, 1024), (2048, 16, 2048), (512, 512, 8)]:
             assert w(*shape) == 1, shape                 # the measured wins against the GPU path stay on the host
-        for shape in [(1, 1, 1 << 26), (1 << 26, 1, 1), (1, 1 << 26, 1), (8, 8192, 1024), (512, 512, 512), (576, 576, 576), (1024, 1024, 1024), (1 << 20, 8, 8),
+        for shape in [(1, 1, 1 << 26), (1 << 26, 1, 1), (1, 1 << 26, 1), (8, 8192, 1024), (576, 576, 576), (1024, 1024, 1024), (1 << 20, 8, 8),
                       (100000, 1, 600), (2048, 2048, 16), (4096, 64, 4096), (128, 128, 8192)]:
             assert w(*shape) == 0, shape                 # degenerate, or the GPU path is as fast or faster: the GPU
         assert w(0, 5, 5) == 0 and w(5, 0, 5) == 1       # an empty inner dimension is a clear of C: nothing to upload
         m4ri_amd.set_small_product_threshold(1 << 26)    # the bound scales with the threshold
-        assert w(320, 320, 320) == 1 and w(448, 448, 448) == 0
+        assert w(384, 384, 384) == 1 and w(448, 448, 448) == 0
         m4ri_amd.set_small_product_threshold(0)
         assert w(4, 4, 4) == 0
     finally:
