@@ -7,9 +7,11 @@
 // in ONE launch.
 //
 //   * a workgroup of 256 threads owns 256 rows x 512 columns of C, one ROW PER THREAD, the row's 8 words in registers;
-//   * the inner dimension in steps of 64 bits = one word of A per row: the 64 rows of B of the step are staged in LDS (4 KiB), SIXTEEN
-//     4-bit tables (16 entries of 64 bytes each, 16 KiB) are built from them -- thread (t, e) forms entry e of table t from at most four
-//     staged rows -- and every row adds its sixteen entries: 64 ds_read_b128 per row and step;
+//   * the inner dimension in steps of 64 bits = one word of A per row: SIXTEEN 4-bit tables of the step's 64 rows of B (16 entries of 64 bytes
+//     each, 16 KiB) are built straight from registers -- a thread owns one 16-byte slot of four entries of one table and needs that slot of four
+//     rows of B, loaded from global memory one step ahead, under the lookups -- into the OTHER of two table sets, and every row adds its sixteen
+//     entries: 64 ds_read_b128 per row and step, ONE barrier per step (the first version staged the rows in LDS: two barriers, nothing in flight;
+//     2048^3 33.0 -> 30.5 us, 1024 x 1024 x 16384 36.6 -> 30.2, 3 x 100000 x 5000 143 -> 100);
 //   * entries are stored with their four 16-byte slots XOR-swizzled by (entry >> 2): the sixteen entries of a table then occupy sixteen
 //     different bank positions for every slot number, so lanes with different indices never collide and lanes with equal indices
 //     broadcast -- conflict-free for ANY indices, writes included;
@@ -31,10 +33,11 @@ constexpr int SM_ROWS = 256, SM_TW = 8, SM_THREADS = 256;
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
-template <bool XOR_OUT>
+// PIPE: more than one step per workgroup -- two table sets (32 KiB), the next step's rows of B in flight under the lookups; a launch of
+// single steps (inner dimension of at most 64 bits per split: the rank-64 updates of the solvers) keeps one set, 16 KiB, and its occupancy
+template <bool XOR_OUT, bool PIPE>
 __global__ __launch_bounds__(SM_THREADS) void m4rm_small_kernel(const LeafArgs p) {
-  __shared__ __attribute__((aligned(16))) word brows[64 * SM_TW];        // the 64 rows of B of the step, 8 words each
-  __shared__ __attribute__((aligned(16))) word tab[16 * 16 * SM_TW];     // [table][entry][slot ^ (entry >> 2)][2 words]
+  __shared__ __attribute__((aligned(16))) word tab[PIPE ? 2 : 1][16 * 16 * SM_TW];  // [step parity][table][entry][slot ^ (entry >> 2)][2 words]
   const int tid = threadIdx.x;
   uint32_t b    = blockIdx.x;
   const int ks     = (int)(b % (uint32_t)p.ksplit);  b /= (uint32_t)p.ksplit;
@@ -60,42 +63,50 @@ __global__ __launch_bounds__(SM_THREADS) void m4rm_small_kernel(const LeafArgs p
   const word *arow = A + (int64_t)row * p.a_stride;
   word a_next      = (live && q_begin < q_end) ? arow[q_begin] : 0;
 
-  // build role: entry e of table t
-  const int bt = tid >> 4, be = tid & 15, bh = be >> 2;
+  // Build role: table bt, 16-byte slot bs of the entries br, 4 + br, 8 + br, 12 + br (low two index bits br: rows 0 and 1 of the table's four
+  // rows of B, the high two bits walk rows 2 and 3).  Sixteen consecutive lanes = the (br, bs) of ONE table: in write number h they hit the
+  // sixteen bank positions (br, bs ^ h) -- conflict-free.  The thread needs slot bs of four rows of B: two words each, straight from global
+  // memory into registers one step ahead (the sixteen threads that share a row hit the same lines), no staging copy, no second barrier.
+  const int bt = tid >> 4, br = (tid >> 2) & 3, bs = tid & 3;
+  const bool c0 = 2 * bs < tw, c1 = 2 * bs + 1 < tw;
+  const word *bcol = B + w0 + 2 * bs;
+  word rr[4][2];
+  auto load_rows = [&](int q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = (int64_t)q * 64 + 4 * bt + j;
+      const bool in   = r < p.l;
+      rr[j][0] = (in && c0) ? bcol[r * p.b_stride] : (word)0;
+      rr[j][1] = (in && c1) ? bcol[r * p.b_stride + 1] : (word)0;
+    }
+  };
+  auto build = [&](int buf) {
+    word e0 = (br & 1) ? rr[0][0] : 0, e1 = (br & 1) ? rr[0][1] : 0;
+    e0 ^= (br & 2) ? rr[1][0] : 0;
+    e1 ^= (br & 2) ? rr[1][1] : 0;
+    unsigned char *tb = reinterpret_cast<unsigned char *>(tab[buf]) + bt * 1024 + br * 64;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {  // entry 4 h + br
+      const word x0 = e0 ^ ((h & 1) ? rr[2][0] : 0) ^ ((h & 2) ? rr[3][0] : 0);
+      const word x1 = e1 ^ ((h & 1) ? rr[2][1] : 0) ^ ((h & 2) ? rr[3][1] : 0);
+      *reinterpret_cast<uint4 *>(tb + h * 256 + ((bs ^ h) << 4)) = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
+    }
+  };
+  if (q_begin < q_end) {
+    load_rows(q_begin);
+    build(0);
+  }
+  __syncthreads();
   for (int q = q_begin; q < q_end; ++q) {
-    // 1. the step's 64 rows of B: consecutive threads take consecutive words of a row (64-byte runs)
-#pragma unroll
-    for (int k = tid; k < 64 * SM_TW; k += SM_THREADS) {
-      const int j = k / SM_TW, c = k % SM_TW;
-      const int64_t br = (int64_t)q * 64 + j;
-      brows[k] = (br < p.l && c < tw) ? B[br * p.b_stride + w0 + c] : (word)0;
+    const int buf = PIPE ? ((q - q_begin) & 1) : 0;
+    const word a  = a_next;
+    if (PIPE && q + 1 < q_end) {
+      load_rows(q + 1);  // in flight under the lookups
+      if (live) a_next = arow[q + 1];
     }
-    const word a = a_next;
-    if (live && q + 1 < q_end) a_next = arow[q + 1];
-    __syncthreads();  // rows staged; every wave is also past its lookups of the previous step, so the tables may be overwritten
-    // 2. the tables
-    {
-      uint4 v[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const uint32_t keep = ((be >> bb) & 1) ? ~0u : 0u;
-        const uint4 *r      = reinterpret_cast<const uint4 *>(&brows[(4 * bt + bb) * SM_TW]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const uint4 x = r[s];
-          v[s].x ^= x.x & keep; v[s].y ^= x.y & keep; v[s].z ^= x.z & keep; v[s].w ^= x.w & keep;
-        }
-      }
-      uint4 *e = reinterpret_cast<uint4 *>(&tab[(bt * 16 + be) * SM_TW]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) e[s ^ bh] = v[s];
-    }
-    __syncthreads();
-    // 3. the lookups: sixteen entries per row, folded two at a time
+    // the lookups: sixteen entries per row, folded two at a time
     if (live && a) {
-      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab);
+      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab[buf]);
 #pragma unroll
       for (int t = 0; t < 16; t += 2) {
         const uint32_t i0 = (uint32_t)(a >> (4 * t)) & 15u, i1 = (uint32_t)(a >> (4 * t + 4)) & 15u;
@@ -113,6 +124,9 @@ __global__ __launch_bounds__(SM_THREADS) void m4rm_small_kernel(const LeafArgs p
         }
       }
     }
+    if (!PIPE) break;  // (a single step)
+    if (q + 1 < q_end) build(buf ^ 1);
+    __syncthreads();  // the next step's tables are complete, and nobody still reads the ones the step after it will overwrite
   }
   if (!live) return;
   word *crow = C + (int64_t)row * p.c_stride + w0;
@@ -169,7 +183,13 @@ extern "C" hipError_t gf2_launch_m4rm_small(hipStream_t stream, LeafArgs a) {
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch * a.ksplit;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nwg), block(SM_THREADS);
-  if (a.mode == 0) hipLaunchKernelGGL((m4rm_small_kernel<false>), grid, block, 0, stream, a);
-  else             hipLaunchKernelGGL((m4rm_small_kernel<true>), grid, block, 0, stream, a);
+  const bool pipe = a.chunks_per_split > 1;
+  if (a.mode == 0) {
+    if (pipe) hipLaunchKernelGGL((m4rm_small_kernel<false, true>), grid, block, 0, stream, a);
+    else      hipLaunchKernelGGL((m4rm_small_kernel<false, false>), grid, block, 0, stream, a);
+  } else {
+    if (pipe) hipLaunchKernelGGL((m4rm_small_kernel<true, true>), grid, block, 0, stream, a);
+    else      hipLaunchKernelGGL((m4rm_small_kernel<true, false>), grid, block, 0, stream, a);
+  }
   return hipGetLastError();
 }
