@@ -147,10 +147,10 @@ __global__ __launch_bounds__(SM_THREADS) void m4rm_small_kernel(const LeafArgs p
 }  // namespace
 
 // Inner-dimension splits of a small product of `tiles` tiles, `wl` 64-bit steps and `c_words` words of C in all: the minimum of
-//     rounds of workgroups over the CUs x steps per split x 1.9 us  +  38.5 ps per word of C and split (the atomics)
+//     rounds of workgroups over the CUs (two per CU) x steps per split x 1.9 us  +  38.5 ps per word of C and split (the atomics)
 // -- both constants fitted on one MI355X (M4RI_AMD_SMALL_KS sweep of 2048^3: 1 / 2 / 4 / 8 splits = 65.9 / 39.0 / 28.9 / 31.4 us; the model's
-// picks against the sweep: 512^3 8 (best measured 8), 1536^3 6 (4 ... 8 equal), 2560^3 4 (4), 4096 x 4096 x 256 14 (16), 8192 x 8192 x 200
-// 8 (8)).  1 = unsplit (plain stores, no zeroing of C).
+// picks against the sweep: 512^3 8 (best measured 8), 1536^3 6 (4 ... 8 equal), 2560^3 4 (4), 4096 x 4096 x 256 13 (16), 8192 x 8192 x 200
+// 12 (16)).  1 = unsplit (plain stores, no zeroing of C).
 extern "C" int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus, int64_t c_words) {
   if (tiles <= 0 || wl < 2) return 1;
   if (cus < 1) cus = 1;
@@ -160,7 +160,7 @@ extern "C" int gf2_m4rm_small_ksplit(int64_t tiles, int64_t wl, int cus, int64_t
   for (int64_t ks = 1; ks <= cap; ++ks) {
     const int64_t steps = (wl + ks - 1) / ks;
     if ((wl + steps - 1) / steps != ks) continue;  // the launcher would round this count to a smaller one
-    const double rounds = (double)((tiles * ks + cus - 1) / cus);
+    const double rounds = (double)((tiles * ks + 2 * cus - 1) / (2 * cus));  // (two workgroups per CU run side by side at no cost: 8192 x 8192 x 200 with 16 splits 31.4 us, with 8 36.3)
     const double cost   = rounds * (double)steps * 1.9 + (ks > 1 ? 38.5e-6 * (double)c_words * (double)ks : 0.0);
     if (cost < best_cost * 0.97) { best_cost = cost; best = (int)ks; }
   }
